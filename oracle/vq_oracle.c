@@ -1,0 +1,222 @@
+/*
+ * vq_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the arithmetic of the reference's VQ codebook-lookup path
+ * (magic-research/vector_quantization).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (vector_quantization_amd) never does.
+ *
+ * The reference composes stock ATen ops; the one op whose result is NOT defined bit-for-bit by the
+ * reference is the distance GEMM (torch.cdist's mm path / einsum): its summation order belongs to
+ * whatever BLAS runs underneath.  This oracle therefore FIXES an order — the k-ordered fp32 fmaf chain,
+ * which is also what gfx950's v_mfma_f32_32x32x2_f32 computes — and every other step follows the
+ * reference expression literally.  Pinning status: the reference ships no tests or golden vectors
+ * (SURVEY.md §4); the oracle is pinned against fixtures produced in the build container by the ATen
+ * ops the reference calls (oracle/make_golden.py → tests/golden/), bit-exactly on order-independent
+ * (integer-valued) vectors and on well-separated rows, and by the fp32 rounding-envelope rule on the
+ * rest (tests/test_oracle_golden.py).
+ *
+ * Reference lines restated (paths relative to /root/reference):
+ *   vqo_l2_*      vq/algorithms/vq/distances.py:28-32  (torch.cdist, mm path:
+ *                 sqrt(clamp_min([-2x, |x|^2, 1] . [e, 1, |e|^2]^T, 0)))
+ *   vqo_cos_*     vq/algorithms/vq/distances.py:35-46  (1 - normalize(x) . normalize(e)^T)
+ *   *_argmin      vq/algorithms/vq/quantizers.py:99    (torch.argmin(distance, dim=-1))
+ *   *_col_argmin  vq/algorithms/cvqvae/anchors.py:83   (d.argmin(0))
+ *   vqo_normalize_rows  vq/algorithms/vq/callbacks/normalize.py:24-27 (F.normalize, eps=1e-12)
+ *   vqo_gather_ste      vq/algorithms/vq/quantizers.py:107, .../quantizers/utils/ste.py:10
+ *   vqo_mse             vq/algorithms/vq/losses.py:50,62 (mean squared error, mean reduction)
+ *   vqo_bincount        vq/algorithms/vq/utils.py:42
+ *   vqo_scatter_add_rows vq/algorithms/vqkd/quantizers/callbacks.py:60-62
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off; fmaf() is IEEE-exact with or without -mfma).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VQO_LANES 64
+
+/* Sum of squares in the oracle's fixed order: 64 interleaved fmaf partials (partial j takes elements
+ * j, j+64, j+128, ... in increasing order), then a halving tree 32,16,8,4,2,1.  For D < 64 the unused
+ * partials are +0 and do not perturb the tree. */
+float vqo_sqnorm(const float *v, int D) {
+    float p[VQO_LANES];
+    for (int j = 0; j < VQO_LANES; ++j) p[j] = 0.0f;
+    for (int d = 0; d < D; ++d) p[d % VQO_LANES] = fmaf(v[d], v[d], p[d % VQO_LANES]);
+    for (int off = VQO_LANES / 2; off >= 1; off >>= 1)
+        for (int j = 0; j < off; ++j) p[j] = p[j] + p[j + off];
+    return p[0];
+}
+
+void vqo_row_sqnorm(const float *v, int64_t R, int D, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r) out[r] = vqo_sqnorm(v + r * (int64_t)D, D);
+}
+
+/* F.normalize(v, p=2, dim=1, eps): v / max(||v||_2, eps), NaN norm stays NaN (clamp_min semantics). */
+void vqo_normalize_rows(const float *v, int64_t R, int D, float eps, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r) {
+        const float *a = v + r * (int64_t)D;
+        float nrm = sqrtf(vqo_sqnorm(a, D));
+        float den = (nrm < eps) ? eps : nrm;
+        for (int d = 0; d < D; ++d) out[r * (int64_t)D + d] = a[d] / den;
+    }
+}
+
+static float *transpose_kd(const float *e, int64_t K, int D) {
+    float *t = (float *)malloc(sizeof(float) * (size_t)K * (size_t)D);
+    for (int64_t k = 0; k < K; ++k)
+        for (int d = 0; d < D; ++d) t[(int64_t)d * K + k] = e[k * (int64_t)D + d];
+    return t;
+}
+
+/* chain[k] = fmaf(a[D-1]*s, e[k][D-1], ... fmaf(a[0]*s, e[k][0], 0)) for every k; s = -2 (L2) or 1. */
+static void dot_chain_row(const float *a, float s, const float *eT, int64_t K, int D, float *acc) {
+    for (int64_t k = 0; k < K; ++k) acc[k] = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float ad = a[d] * s; /* exact for s = -2, 1 */
+        const float *col = eT + (int64_t)d * K;
+        for (int64_t k = 0; k < K; ++k) acc[k] = fmaf(ad, col[k], acc[k]);
+    }
+}
+
+static inline float l2_finish(float c, float xn, float en) {
+    float t = (c + xn) + en;         /* inner index order D, D+1 of the padded GEMM */
+    t = (t < 0.0f) ? 0.0f : t;       /* clamp_min_(0): NaN stays NaN */
+    return sqrtf(t);
+}
+
+/* torch.argmin over a row: NaN counts as the minimum, lowest index wins on ties. */
+static inline void argmin_update(float v, int64_t k, float *best, int64_t *bi) {
+    if (isnan(*best)) return;
+    if (isnan(v) || v < *best) { *best = v; *bi = k; }
+}
+
+/* Full [N,K] L2 distance matrix (torch.cdist mm path). */
+void vqo_l2_dist(const float *x, const float *e, int64_t N, int64_t K, int D, float *d) {
+    float *eT = transpose_kd(e, K, D);
+    float *en = (float *)malloc(sizeof(float) * (size_t)K);
+    vqo_row_sqnorm(e, K, D, en);
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        float *row = d + n * K;
+        float xn = vqo_sqnorm(x + n * (int64_t)D, D);
+        dot_chain_row(x + n * (int64_t)D, -2.0f, eT, K, D, row);
+        for (int64_t k = 0; k < K; ++k) row[k] = l2_finish(row[k], xn, en[k]);
+    }
+    free(en); free(eT);
+}
+
+/* idx[n] = argmin_k cdist(x,e)[n,k]; mind (nullable) = that distance. */
+void vqo_l2_argmin(const float *x, const float *e, int64_t N, int64_t K, int D,
+                   int64_t *idx, float *mind) {
+    float *eT = transpose_kd(e, K, D);
+    float *en = (float *)malloc(sizeof(float) * (size_t)K);
+    vqo_row_sqnorm(e, K, D, en);
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            float xn = vqo_sqnorm(x + n * (int64_t)D, D);
+            dot_chain_row(x + n * (int64_t)D, -2.0f, eT, K, D, row);
+            float best = l2_finish(row[0], xn, en[0]); int64_t bi = 0;
+            for (int64_t k = 1; k < K; ++k) argmin_update(l2_finish(row[k], xn, en[k]), k, &best, &bi);
+            idx[n] = bi; if (mind) mind[n] = best;
+        }
+        free(row);
+    }
+    free(en); free(eT);
+}
+
+/* Full [N,K] cosine distance 1 - normalize(x).normalize(e)^T (both re-normalised, eps=1e-12). */
+void vqo_cos_dist(const float *x, const float *e, int64_t N, int64_t K, int D, float *d) {
+    float *xh = (float *)malloc(sizeof(float) * (size_t)N * (size_t)D);
+    float *eh = (float *)malloc(sizeof(float) * (size_t)K * (size_t)D);
+    vqo_normalize_rows(x, N, D, 1e-12f, xh);
+    vqo_normalize_rows(e, K, D, 1e-12f, eh);
+    float *eT = transpose_kd(eh, K, D);
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        float *row = d + n * K;
+        dot_chain_row(xh + n * (int64_t)D, 1.0f, eT, K, D, row);
+        for (int64_t k = 0; k < K; ++k) row[k] = 1.0f - row[k];
+    }
+    free(eT); free(eh); free(xh);
+}
+
+void vqo_cos_argmin(const float *x, const float *e, int64_t N, int64_t K, int D,
+                    int64_t *idx, float *mind) {
+    float *xh = (float *)malloc(sizeof(float) * (size_t)N * (size_t)D);
+    float *eh = (float *)malloc(sizeof(float) * (size_t)K * (size_t)D);
+    vqo_normalize_rows(x, N, D, 1e-12f, xh);
+    vqo_normalize_rows(e, K, D, 1e-12f, eh);
+    float *eT = transpose_kd(eh, K, D);
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            dot_chain_row(xh + n * (int64_t)D, 1.0f, eT, K, D, row);
+            float best = 1.0f - row[0]; int64_t bi = 0;
+            for (int64_t k = 1; k < K; ++k) argmin_update(1.0f - row[k], k, &best, &bi);
+            idx[n] = bi; if (mind) mind[n] = best;
+        }
+        free(row);
+    }
+    free(eT); free(eh); free(xh);
+}
+
+/* d.argmin(0) on a materialised [N,K] matrix: for each code the nearest token, lowest n on ties. */
+void vqo_col_argmin(const float *d, int64_t N, int64_t K, int64_t *idx) {
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < K; ++k) {
+        float best = d[k]; int64_t bi = 0;
+        for (int64_t n = 1; n < N; ++n) argmin_update(d[n * K + k], n, &best, &bi);
+        idx[k] = bi;
+    }
+}
+
+/* row argmin on a materialised matrix (torch.argmin(d, -1)). */
+void vqo_row_argmin(const float *d, int64_t N, int64_t K, int64_t *idx) {
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n) {
+        float best = d[n * K]; int64_t bi = 0;
+        for (int64_t k = 1; k < K; ++k) argmin_update(d[n * K + k], k, &best, &bi);
+        idx[n] = bi;
+    }
+}
+
+/* z = e[idx]; out = x + (z - x)  (nn.Embedding gather, then the literal STE expression). */
+void vqo_gather_ste(const float *x, const float *e, const int64_t *idx, int64_t N, int D,
+                    float *z, float *out) {
+    for (int64_t n = 0; n < N; ++n)
+        for (int d = 0; d < D; ++d) {
+            float zv = e[idx[n] * (int64_t)D + d], xv = x[n * (int64_t)D + d];
+            z[n * (int64_t)D + d] = zv;
+            if (out) out[n * (int64_t)D + d] = xv + (zv - xv);
+        }
+}
+
+/* mean((a-b)^2) with fp32 differences/squares and a double accumulator (any fp32 summation order
+ * of the reference lands within ~1e-7 relative of this). */
+float vqo_mse(const float *a, const float *b, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) { float df = a[i] - b[i]; s += (double)(df * df); }
+    return (float)(s / (double)n);
+}
+
+void vqo_bincount(const int64_t *idx, int64_t N, int64_t K, int64_t *out) {
+    memset(out, 0, sizeof(int64_t) * (size_t)K);
+    for (int64_t n = 0; n < N; ++n) out[idx[n]] += 1;
+}
+
+/* dst[idx[n], :] += src[n, :] sequentially in n (the order torch's CPU scatter_add_ uses). */
+void vqo_scatter_add_rows(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst) {
+    (void)K;
+    for (int64_t n = 0; n < N; ++n)
+        for (int d = 0; d < D; ++d) dst[idx[n] * (int64_t)D + d] += src[n * (int64_t)D + d];
+}
+
+int vqo_version(void) { return 1; }

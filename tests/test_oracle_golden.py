@@ -1,0 +1,161 @@
+"""Pin the C oracle against the fixtures produced by the reference's ATen ops (CPU, no GPU).
+
+Rule (SURVEY.md §7 hard part 1): the distance GEMM's summation order is not part of the reference's
+contract, so indices are compared
+  * bit-exactly on order-independent (integer-valued) vectors and on well-separated data, and
+  * by the fp32 rounding envelope elsewhere: the reference's pick must be within a few ulps of the
+    oracle's minimum under the oracle's own metric (and vice versa through ``mind``).
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co, synth
+
+EXACT_KINDS = {'int', 'normal', 'planted', 'unit', 'normal_bf16x'}
+
+
+def _cases(golden_dir):
+    out = []
+    for p in sorted(glob.glob(os.path.join(golden_dir, '*.npz'))):
+        z = np.load(p)
+        if 'spec' in z.files and 'quant' in z.files and 'distance' in json.loads(str(z['spec'])) \
+                and 'kind' in json.loads(str(z['spec'])):
+            out.append(p)
+    return out
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ENCODE_FILES = _cases(GOLDEN)
+
+
+def load_case(path):
+    z = np.load(path)
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs(spec['kind'], spec['seed'], spec['N'], spec['K'], spec['D'])
+    assert synth.sha(x) == str(z['x_sha']), 'synthetic input generator drifted'
+    assert synth.sha(w) == str(z['w_sha']), 'synthetic input generator drifted'
+    if 'x' in z.files:
+        np.testing.assert_array_equal(z['x'], x)
+        np.testing.assert_array_equal(z['w'], w)
+    return z, spec, x, w
+
+
+def oracle_encode(spec, x, w):
+    if spec['normalize']:                       # NormalizeCallback.before_encode
+        x, w = co.normalize_rows(x), co.normalize_rows(w)
+    if spec['distance'] == 'L2':
+        idx, mind = co.l2_argmin(x, w, with_min=True)
+        d = co.l2_dist(x, w)
+    else:
+        idx, mind = co.cos_argmin(x, w, with_min=True)
+        d = co.cos_dist(x, w)
+    return x, w, idx, mind, d
+
+
+def envelope(spec, x, w, d):
+    """Per-row tolerance on the distance value: a few ulps of the cancelling terms, mapped through sqrt."""
+    eps = np.float32(2.0 ** -23)
+    if spec['distance'] == 'L2':
+        xn = (x.astype(np.float64) ** 2).sum(1)
+        en = (w.astype(np.float64) ** 2).sum(1).max()
+        mag = xn + en + 2 * np.sqrt(xn * en)
+        dmin = np.maximum(d.min(1).astype(np.float64), 1e-30)
+        return 4 * eps * mag / (2 * dmin) + 4 * eps * dmin
+    return np.full(x.shape[0], 8 * eps, np.float64)
+
+
+@pytest.mark.parametrize('path', ENCODE_FILES, ids=[os.path.basename(p)[:-4] for p in ENCODE_FILES])
+def test_oracle_matches_reference_ops(path):
+    z, spec, x, w = load_case(path)
+    xe, we, idx, mind, d = oracle_encode(spec, x, w)
+    gq = z['quant'].astype(np.int64)
+    N = spec['N']
+    neq = idx != gq
+    tiny = spec['N'] <= 25 and spec['K'] <= 25       # torch.cdist non-mm path: envelope only
+    if spec['kind'] in EXACT_KINDS and not tiny:
+        assert not neq.any(), f'{neq.sum()} index mismatches on well-conditioned data'
+    # envelope rule on every row (trivially true where equal)
+    env = envelope(spec, xe, we, d)
+    rows = np.arange(N)
+    gap = d[rows, gq].astype(np.float64) - d[rows, idx].astype(np.float64)
+    assert (gap >= 0).all(), 'oracle argmin is not the minimum of its own distances'
+    assert (gap <= env).all(), f'reference pick outside envelope: max gap {gap.max():.3e}'
+    assert neq.mean() <= 0.05
+    # the minimum distance itself agrees to fp32 rounding
+    np.testing.assert_allclose(mind, z['mind'], rtol=2e-5, atol=float(env.max()))
+    # row argmin of the materialised matrix == fused argmin (oracle self-consistency)
+    np.testing.assert_array_equal(co.row_argmin(d), idx)
+    # downstream elementwise stages are bit-exact given the same indices
+    zz, zste = co.gather_ste(xe, we, gq)
+    if spec['normalize']:      # F.normalize's norm uses another summation order: last-bit differences
+        np.testing.assert_allclose(zz[:8], z['z_head'], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(zste[:8], z['zste_head'], rtol=0, atol=1e-6)
+    else:
+        assert synth.sha(zz) == str(z['z_sha'])
+        assert synth.sha(zste) == str(z['zste_sha'])
+    np.testing.assert_array_equal(co.bincount(gq, spec['K']), z['hist'].astype(np.int64))
+    # losses within the north-star tolerance (1e-5, fp32)
+    if spec['loss'] == 'vqgan':
+        loss = co.vqgan_loss(zz, xe)
+    else:
+        loss = co.mse(co.normalize_rows(zz), co.normalize_rows(xe))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-5 * max(1.0, abs(float(z['loss'])))
+
+
+def test_nonfinite_semantics(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'special_nonfinite.npz'))
+    x, w, wn = z['x'], z['w'], z['w_nan']
+    np.testing.assert_array_equal(co.l2_argmin(x, w), z['quant_l2'].astype(np.int64))
+    np.testing.assert_array_equal(co.l2_argmin(x, wn), z['quant_l2_wnan'].astype(np.int64))
+    np.testing.assert_array_equal(co.cos_argmin(x, w), z['quant_cos'].astype(np.int64))
+
+
+def test_update_vqkd(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'update_vqkd.npz'))
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs('normal', spec['seed'], spec['N'], spec['K'], spec['D'])
+    w = synth.unit_rows(w)
+    assert synth.sha(x) == str(z['x_sha']) and synth.sha(w) == str(z['w_sha'])
+    xn = co.normalize_rows(x)
+    quant = co.cos_argmin(xn, w)
+    np.testing.assert_array_equal(quant, z['quant'].astype(np.int64))
+
+    def step(xs, qs, hist=None, sums=None):
+        xs = co.normalize_rows(xs)                           # callbacks.py:124
+        e = co.kmeans_centroids(xs, qs, w, hist, sums)       # :125
+        e = co.normalize_rows(e)                             # :126
+        e = co.ema(w, e, 0.99)                               # :127
+        return co.normalize_rows(e)                          # :73-75
+
+    np.testing.assert_allclose(step(xn, quant), z['w_new'], rtol=0, atol=2e-6)
+    K = spec['K']
+    hist = co.bincount(quant[0::2], K) + co.bincount(quant[1::2], K)
+    sums = co.scatter_add_rows(co.normalize_rows(xn[0::2]), quant[0::2], K) + \
+        co.scatter_add_rows(co.normalize_rows(xn[1::2]), quant[1::2], K)
+    np.testing.assert_allclose(step(xn[0::2], quant[0::2], hist, sums), z['w_new_2rank'], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('dist', ['l2', 'cosine'])
+def test_update_cvq(golden_dir, dist):
+    z = np.load(os.path.join(golden_dir, f'update_cvq_{dist}.npz'))
+    spec = json.loads(str(z['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    dfn = co.l2_dist if dist == 'l2' else co.cos_dist
+    d = dfn(x, w)
+    quant = co.row_argmin(d)
+    np.testing.assert_array_equal(quant, z['quant'].astype(np.int64))
+    col = co.col_argmin(d)
+    np.testing.assert_array_equal(col, z['col_idx'].astype(np.int64))
+    freq = (co.bincount(quant, K) / np.int64(N)).astype(np.float32)
+    p1 = co.ema(np.zeros(K, np.float32), freq, 0.99)
+    np.testing.assert_allclose(p1, z['p1'], rtol=1e-6, atol=1e-9)
+    decay = co.cvq_decay(p1, K, 0.99, 1e-3)
+    np.testing.assert_allclose(decay, z['decay'], rtol=1e-5, atol=1e-6)
+    w_new = co.ema(w, x[col], decay)
+    np.testing.assert_allclose(w_new, z['w_new'], rtol=0, atol=2e-6)
