@@ -1,0 +1,132 @@
+/*
+ * vqhip.h — C ABI of the MI355X (gfx950) VQ codebook-lookup library (libvqhip.so).
+ *
+ * Drop-in boundary for ONE path of magic-research/vector_quantization: the `vq.algorithms` quantizer
+ * forward (distance over the whole codebook → row argmin → gather/STE/loss → codebook update).  The
+ * reference has no FFI of its own (it is pure Python on ATen ops); each entry point below replaces the
+ * ATen call(s) named next to it (paths relative to the reference root), and is what the reference-side
+ * binding in INTEGRATION.md (a ctypes stub inside the quantizer modules) calls.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless noted; tensors are dense row-major; `stream`
+ * is a hipStream_t passed as void*; functions never allocate, never synchronise, never touch another
+ * stream; they return 0 or a negative VQHIP_E* code.  x_dtype selects the latent storage type
+ * (fp32, or bf16 as produced under autocast); codebooks are fp32 like nn.Embedding.weight.
+ */
+#ifndef VQHIP_H_
+#define VQHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQHIP_VERSION 100
+
+#define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
+#define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
+
+#define VQHIP_DTYPE_F32 0
+#define VQHIP_DTYPE_BF16 1
+
+#define VQHIP_OK 0
+#define VQHIP_EINVAL (-22)      /* bad argument (null pointer, unsupported D, ...) */
+#define VQHIP_ELAUNCH (-5)      /* hip launch error */
+
+int vqhip_version(void);
+const char *vqhip_last_error(void); /* host string describing the last non-zero return on this thread */
+
+/* ---- sizes of caller-owned buffers -------------------------------------------------------------- */
+/* bytes of the prepared-codebook image produced by vqhip_codebook_prepare for a [K,D] codebook */
+int64_t vqhip_codebook_bytes(int64_t K, int D);
+/* bytes of per-call scratch for vqhip_argmin / vqhip_argmin_exact / vqhip_col_argmin over N rows */
+int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D);
+
+/* ---- codebook preparation --------------------------------------------------------------------------
+ * Reads e[K,D] fp32 and writes into `cb` (vqhip_codebook_bytes): the oracle-order row norms |e_k|^2,
+ * for COS the normalised codebook F.normalize(e) (distances.py:41), a power-of-two-scaled fp16 copy in
+ * MFMA-fragment order, and the error bounds the exact re-rank needs.  Must be re-run whenever e changes
+ * (callbacks rebind weight.data every forward: vq/algorithms/vq/callbacks/update.py:56). */
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream);
+
+/* ---- fused distance + argmin  (replaces quantizers.py:97-99: distance(x, W) → torch.argmin(d, -1)) ---
+ * idx[n] = argmin_k d(x_n, e_k), lowest k on ties, bit-identical to the fp32 definition
+ *   L2 : sqrt(clamp_min((sum_d(-2 x_d e_kd) + |x|^2) + |e_k|^2, 0))   (torch.cdist mm path)
+ *   COS: 1 - sum_d xh_d eh_kd, xh/eh = F.normalize(.)                  (x must already be normalised:
+ *        pass the output of vqhip_normalize_rows; the codebook is normalised by codebook_prepare)
+ * evaluated with k-ordered fp32 fma chains (see DESIGN.md "Arithmetic contract").  A fp16 MFMA pass
+ * proposes candidates under a rigorous error bound and an exact fp32 re-rank decides; rows the bound
+ * cannot settle are re-evaluated over the whole codebook in fp32.  Optional outputs (nullable):
+ *   hist[K] int32 += code-hit histogram (quant.bincount, vq/algorithms/vq/utils.py:42);
+ * `ws` = vqhip_workspace_bytes(N,K,D) of scratch. */
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D,
+                 int metric, int64_t *idx, int32_t *hist, void *ws, void *stream);
+
+/* Same result computed entirely in fp32 (v_mfma_f32_32x32x2_f32) without the fp16 proposal pass.
+ * dmin (nullable) receives the winning distance.  For COS `e` must be the normalised codebook. */
+int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
+                       int64_t *idx, float *dmin, int32_t *hist, void *ws, void *stream);
+
+/* Materialise d[N,K] fp32 (memo['distance'], quantizers.py:98) for consumers that need the matrix
+ * (EntropyLoss losses.py:143, MultinomialAnchor anchors.py:100).  COS: x and e already normalised. */
+int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
+                   float *d, void *ws, void *stream);
+
+/* NearestAnchor: col_idx[k] = argmin_n d[n,k], lowest n on ties (vq/algorithms/cvqvae/anchors.py:83),
+ * same arithmetic contract as vqhip_argmin_exact; never materialises d. */
+int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
+                     int64_t *col_idx, void *ws, void *stream);
+
+/* ---- row kernels ------------------------------------------------------------------------------------ */
+/* out[r] = |v_r|^2 in the oracle's order (64 interleaved fma partials + halving tree) */
+int vqhip_row_sqnorm(const void *v, int dtype, int64_t R, int D, float *out, void *stream);
+/* out = F.normalize(v, dim=1, eps) (callbacks/normalize.py:24,27; distances.py:40-41) */
+int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, float *out, void *stream);
+
+/* ---- decode + straight-through + loss partial sums --------------------------------------------------
+ * z[n] = e[idx[n]]                       (nn.Embedding gather, quantizers.py:107)
+ * z_ste[n] = x[n] + (z[n] - x[n])        (utils/ste.py:10)        — either output may be NULL
+ * sse[0] += sum (z - x)^2 in double      (both MSE terms of losses.py:50,62 share this sum; the host
+ *                                         divides by N*D).  sse may be NULL. */
+int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
+                          float *z, float *z_ste, double *sse, void *stream);
+
+/* hist[K] int32 += bincount(idx) (utils.py:42; runners/metrics.py:40-44) */
+int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream);
+
+/* dst[idx[n], :] += src[n, :]  (centroids.scatter_add_, vqkd/quantizers/callbacks.py:60-62; also the
+ * dense embedding backward).  fp32 atomics. */
+int vqhip_scatter_add_rows(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst,
+                           void *stream);
+
+/* ---- codebook updates ------------------------------------------------------------------------------- */
+/* VQKDCallback._kmeans tail + after_encode (callbacks.py:66-70,126-128,73-75):
+ *   c = where(hist>0, sums/max(hist,1), w); c = normalize(c); c = w*decay + c*(1-decay); w = normalize(c)
+ * hist int64[K] / sums[K,D] are the (all-reduced) statistics.  In place on w. */
+int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay,
+                      void *stream);
+/* CVQVAECallback.after_encode (quantizer_callback.py:94-102):
+ *   p = p*ema_decay + (hist/numel)*(1-ema_decay);  decay_k = 1 - exp(-p_k*K*10/(1-ema_decay) - eps)
+ *   w_k = w_k*decay_k + anchors_k*(1-decay_k)      — in place on p[K] and w[K,D]. */
+int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K,
+                     int D, float ema_decay, float eps, void *stream);
+/* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
+int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
+                      void *stream);
+
+/* ---- diagnostics ------------------------------------------------------------------------------------
+ * Copies the counters of the last vqhip_argmin on `ws` to out[4] (DEVICE int32): rows sent to the
+ * whole-codebook fp32 pass, rows with more than one candidate (re-ranked exactly), reserved x2. */
+int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream);
+
+/* Per-launch timing of the proposal (distance+argmin) kernel with HIP events recorded on the caller's stream
+ * around that launch (bench.py's roofline leg).  enable(1) starts collecting, collect() synchronises on the
+ * recorded events, returns the summed kernel milliseconds and launch count (HOST pointers) and resets. */
+int vqhip_profile_enable(int on);
+int vqhip_profile_collect(double *ms_sum, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H_ */

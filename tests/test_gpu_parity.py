@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.
+
+Bar: token indices bit-exact against the oracle on every case (the oracle fixes the fp32 summation
+order, see oracle/vq_oracle.c) and against the reference-op fixtures wherever those are well conditioned;
+gather/STE bit-exact; losses within 1e-5 (fp32), the tolerance BASELINE.json's north_star states.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+EXACT_KINDS = {'int', 'normal', 'planted', 'unit', 'normal_bf16x'}
+
+
+def _encode_files():
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, '*.npz'))):
+        z = np.load(p)
+        if 'spec' in z.files and 'quant' in z.files and 'kind' in json.loads(str(z['spec'])):
+            out.append(p)
+    return out
+
+
+ENCODE_FILES = _encode_files()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from vector_quantization_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def gpu_encode(ops, spec, x, w, x_dtype=None):
+    """Mirror of the quantizer's encode: optional NormalizeCallback, distance-specific preparation, argmin."""
+    xd, wd = dev(x, x_dtype), dev(w)
+    if spec['normalize']:
+        xd, wd = ops.normalize_rows(xd), ops.normalize_rows(wd)
+    metric = spec['distance']
+    xq = ops.normalize_rows(xd) if metric == 'Cosine' else xd
+    cb = ops.prepare_codebook(wd, metric)
+    idx, st = ops.argmin(xq, cb, return_stats=True)
+    return xd, wd, xq, cb, idx, st
+
+
+@pytest.mark.parametrize('path', ENCODE_FILES, ids=[os.path.basename(p)[:-4] for p in ENCODE_FILES])
+def test_encode_matches_oracle_and_golden(ops, path):
+    z = np.load(path)
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs(spec['kind'], spec['seed'], spec['N'], spec['K'], spec['D'])
+    assert synth.sha(x) == str(z['x_sha'])
+    xo, wo = (co.normalize_rows(x), co.normalize_rows(w)) if spec['normalize'] else (x, w)
+    oracle_idx = (co.l2_argmin if spec['distance'] == 'L2' else co.cos_argmin)(xo, wo)
+
+    xd, wd, xq, cb, idx, st = gpu_encode(ops, spec, x, w)
+    torch.cuda.synchronize()
+    if spec['normalize']:       # the normalisation kernel itself is bit-exact against the oracle's order
+        np.testing.assert_array_equal(xd.cpu().numpy(), xo)
+        np.testing.assert_array_equal(wd.cpu().numpy(), wo)
+    got = idx.cpu().numpy()
+    np.testing.assert_array_equal(got, oracle_idx)                       # bit-exact vs oracle, every case
+    tiny = spec['N'] <= 25 and spec['K'] <= 25
+    if spec['kind'] in EXACT_KINDS and not tiny and not spec['normalize']:
+        np.testing.assert_array_equal(got, z['quant'].astype(np.int64))   # and vs the reference ops
+    # the fp32-only entry point agrees bit for bit
+    wq = ops.normalize_rows(wd) if spec['distance'] == 'Cosine' else wd
+    idx2, dmin = ops.argmin_exact(xq, wq, spec['distance'], return_min=True)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), oracle_idx)
+    o_idx, o_min = (co.l2_argmin if spec['distance'] == 'L2' else co.cos_argmin)(xo, wo, with_min=True)
+    np.testing.assert_array_equal(dmin.cpu().numpy(), o_min)
+    # histogram fused into the epilogue
+    hist = torch.zeros(spec['K'], dtype=torch.int32, device='cuda')
+    ops.argmin(xq, cb, hist=hist)
+    np.testing.assert_array_equal(hist.cpu().numpy().astype(np.int64), co.bincount(oracle_idx, spec['K']))
+    # decode + STE bit-exact, loss within 1e-5
+    zt, zs, sse = ops.gather_ste_loss(xd, wd, idx)
+    zo, zso = co.gather_ste(xo, wo, oracle_idx)
+    np.testing.assert_array_equal(zt.cpu().numpy(), zo)
+    np.testing.assert_array_equal(zs.cpu().numpy(), zso)
+    mse = float(sse.item()) / (spec['N'] * spec['D'])
+    ref = float(co.mse(zo, xo))
+    assert abs(mse - ref) <= 1e-5 * max(1.0, abs(ref))
+    if spec['loss'] == 'vqgan' and not spec['normalize'] and spec['kind'] in EXACT_KINDS and not tiny:
+        assert abs(1.25 * mse - float(z['loss'])) <= 1e-5 * max(1.0, abs(float(z['loss'])))
+    print(f"{spec['name']}: flagged={int(st[0])} multi={int(st[1])} of {spec['N']}")
+
+
+def test_bf16_latents_same_as_fp32_values(ops):
+    z = np.load(os.path.join(GOLDEN, 'l2_c2_bf16x_s3407.npz'))
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs(spec['kind'], spec['seed'], spec['N'], spec['K'], spec['D'])
+    _, wd, _, cb, idx, _ = gpu_encode(ops, spec, x, w, x_dtype=torch.bfloat16)   # x is exactly bf16-representable
+    np.testing.assert_array_equal(idx.cpu().numpy(), z['quant'].astype(np.int64))
+    zt, zs, sse = ops.gather_ste_loss(dev(x, torch.bfloat16), wd, idx)
+    zo, zso = co.gather_ste(x, w, z['quant'].astype(np.int64))
+    np.testing.assert_array_equal(zs.cpu().numpy(), zso)
+
+
+def test_nonfinite_inputs(ops):
+    z = np.load(os.path.join(GOLDEN, 'special_nonfinite.npz'))
+    x, w, wn = z['x'], z['w'], z['w_nan']
+    for ww, key in ((w, 'quant_l2'), (wn, 'quant_l2_wnan')):
+        cb = ops.prepare_codebook(dev(ww), 'L2')
+        idx = ops.argmin(dev(x), cb)
+        np.testing.assert_array_equal(idx.cpu().numpy(), z[key].astype(np.int64))
+        np.testing.assert_array_equal(ops.argmin_exact(dev(x), dev(ww), 'L2').cpu().numpy(), z[key].astype(np.int64))
+    xq = ops.normalize_rows(dev(x))
+    cb = ops.prepare_codebook(dev(w), 'Cosine')
+    np.testing.assert_array_equal(ops.argmin(xq, cb).cpu().numpy(), z['quant_cos'].astype(np.int64))
+
+
+@pytest.mark.parametrize('metric', ['L2', 'Cosine'])
+def test_distance_matrix_and_col_argmin(ops, metric):
+    x, w = synth.make_inputs('normal', 77, 200, 333, 32)
+    if metric == 'Cosine':
+        xo, wo = co.normalize_rows(x), co.normalize_rows(w)
+        d_ref = co.cos_dist(x, w)
+    else:
+        xo, wo = x, w
+        d_ref = co.l2_dist(x, w)
+    d = ops.distance(dev(xo), dev(wo), metric)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)
+    col = ops.col_argmin(dev(xo), dev(wo), metric)
+    np.testing.assert_array_equal(col.cpu().numpy(), co.col_argmin(d_ref))
+
+
+def test_row_kernels(ops):
+    v = synth.normal(5, 1000, 256)
+    np.testing.assert_array_equal(ops.row_sqnorm(dev(v)).cpu().numpy(), co.row_sqnorm(v))
+    for D in (8, 32, 48, 256, 768):
+        v = synth.normal(6, 257, D)
+        v[3] = 0
+        np.testing.assert_array_equal(ops.normalize_rows(dev(v)).cpu().numpy(), co.normalize_rows(v))
+
+
+def test_hist_scatter_gather(ops):
+    g = synth.rng(9)
+    N, K, D = 5000, 300, 32
+    idx = g.integers(0, K, N)
+    src = synth.normal(10, N, D)
+    np.testing.assert_array_equal(ops.hist(dev(idx), K).cpu().numpy().astype(np.int64), co.bincount(idx, K))
+    out = ops.scatter_add_rows(dev(src), dev(idx), K).cpu().numpy()
+    np.testing.assert_allclose(out, co.scatter_add_rows(src, idx, K), rtol=1e-5, atol=1e-4)
+    rows = g.integers(0, N, K)
+    np.testing.assert_array_equal(ops.gather_rows(dev(src), dev(rows)).cpu().numpy(), src[rows])
+
+
+def test_vqkd_update_matches_golden(ops):
+    z = np.load(os.path.join(GOLDEN, 'update_vqkd.npz'))
+    spec = json.loads(str(z['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    xn = ops.normalize_rows(dev(x))
+    cb = ops.prepare_codebook(dev(w), 'Cosine')
+    quant = ops.argmin(ops.normalize_rows(xn), cb)
+    np.testing.assert_array_equal(quant.cpu().numpy(), z['quant'].astype(np.int64))
+    xs = ops.normalize_rows(xn)                                   # callbacks.py:124
+    hist = ops.hist(quant, K).long()
+    sums = ops.scatter_add_rows(xs, quant, K)
+    wd = dev(w).clone()
+    ops.vqkd_update_(wd, hist, sums, 0.99)
+    np.testing.assert_allclose(wd.cpu().numpy(), z['w_new'], rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize('dist', ['L2', 'Cosine'])
+def test_cvq_update_matches_golden(ops, dist):
+    z = np.load(os.path.join(GOLDEN, f'update_cvq_{dist.lower()}.npz'))
+    spec = json.loads(str(z['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    xd, wd = dev(x), dev(w).clone()
+    p = torch.zeros(K, device='cuda')
+    for step, (qk, ck, pk, wk) in enumerate((('quant', 'col_idx', 'p1', 'w_new'), ('quant2', 'col_idx2', 'p2', 'w_new2'))):
+        if dist == 'Cosine':
+            xq, wq = ops.normalize_rows(xd), ops.normalize_rows(wd)
+        else:
+            xq, wq = xd, wd
+        cb = ops.prepare_codebook(wd, dist)
+        quant = ops.argmin(xq, cb)
+        col = ops.col_argmin(xq, wq, dist)
+        if step == 0:      # identical inputs: indices are bit-exact; step 2 starts from a tolerance-equal codebook
+            np.testing.assert_array_equal(quant.cpu().numpy(), z[qk].astype(np.int64))
+            np.testing.assert_array_equal(col.cpu().numpy(), z[ck].astype(np.int64))
+        hist = ops.hist(quant, K).long()
+        anchors = ops.gather_rows(xd, col)
+        ops.cvq_update_(wd, p, hist, N, anchors, 0.99, 1e-3)
+        np.testing.assert_allclose(p.cpu().numpy(), z[pk], rtol=1e-5, atol=1e-8)
+        if step == 0:
+            np.testing.assert_allclose(wd.cpu().numpy(), z[wk], rtol=0, atol=3e-6)
+
+
+# ---- BASELINE.json sizes: size-independent properties --------------------------------------------------
+
+def test_full_size_properties(ops):
+    """K=16384, D=256, N=65536 (configs[1]/[4] shapes): decode->encode round trip, proposal pass == fp32 pass,
+    histogram mass, and a checksum against the oracle on a row sample."""
+    K, D, N = 16384, 256, 65536
+    g = torch.Generator(device='cuda').manual_seed(3407)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g).bfloat16()
+    cb = ops.prepare_codebook(w, 'L2')
+    hist = torch.zeros(K, dtype=torch.int32, device='cuda')
+    idx, st = ops.argmin(x, cb, hist=hist, return_stats=True)
+    assert int(hist.sum()) == N and int(idx.min()) >= 0 and int(idx.max()) < K
+    # (1) against the fp32-only pass on the whole batch
+    idx_exact = ops.argmin_exact(x, w, 'L2')
+    assert torch.equal(idx, idx_exact)
+    # (2) round trip: encoding the decoded codes returns the codes (codebook rows are distinct)
+    perm = torch.randperm(K, device='cuda', generator=g)
+    z, _, _ = ops.gather_ste_loss(torch.zeros(K, D, device='cuda'), w, perm, need_ste=False, need_sse=False)
+    assert torch.equal(ops.argmin(z, cb), perm)
+    # (3) idempotence: quantising the quantised latents changes nothing
+    zq, _, _ = ops.gather_ste_loss(x, w, idx, need_ste=False, need_sse=False)
+    assert torch.equal(ops.argmin(zq, cb), idx)
+    # (4) oracle on a sample of rows
+    rows = torch.arange(0, N, 257, device='cuda')
+    xs = x[rows].float().cpu().numpy()
+    np.testing.assert_array_equal(idx[rows].cpu().numpy(), co.l2_argmin(xs, w.cpu().numpy()))
+    print(f'full size: flagged={int(st[0])} multi={int(st[1])} of {N}')
+
+
+def test_empty_and_ragged(ops):
+    w = dev(synth.normal(1, 100, 16))
+    cb = ops.prepare_codebook(w, 'L2')
+    assert ops.argmin(torch.empty(0, 16, device='cuda'), cb).numel() == 0
+    for N in (1, 31, 33, 257):
+        x = synth.normal(N, N, 16)
+        np.testing.assert_array_equal(ops.argmin(dev(x), cb).cpu().numpy(), co.l2_argmin(x, w.cpu().numpy()))

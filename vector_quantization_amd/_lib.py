@@ -1,0 +1,82 @@
+"""ctypes binding of libvqhip.so (C ABI in include/vqhip.h).
+
+The library is built in-tree by ``vector_quantization_amd/csrc/build.sh`` (hipcc, gfx950).  There is no
+CPU or PyTorch fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvqhip.so')
+
+METRIC_L2, METRIC_COS = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/vqhip.h one to one
+SIGNATURES = {
+    'vqhip_version': (_i32, []),
+    'vqhip_last_error': (ctypes.c_char_p, []),
+    'vqhip_codebook_bytes': (_i64, [_i64, _i32]),
+    'vqhip_workspace_bytes': (_i64, [_i64, _i64, _i32]),
+    'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    'vqhip_argmin': (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'vqhip_argmin_exact': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_distance': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'vqhip_col_argmin': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'vqhip_row_sqnorm': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    'vqhip_normalize_rows': (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),
+    'vqhip_gather_ste_loss': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'vqhip_hist': (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    'vqhip_scatter_add_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    'vqhip_vqkd_update': (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    'vqhip_cvq_update': (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp]),
+    'vqhip_gather_rows': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _vp]),
+    'vqhip_argmin_stats': (_i32, [_vp, _vp, _vp]),
+    'vqhip_profile_enable': (_i32, [_i32]),
+    'vqhip_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+}
+
+_lib = None
+
+
+class VqhipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libvqhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, 'csrc', 'build.sh')
+    res = subprocess.run(['bash', script], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise VqhipError(f'hipcc build of libvqhip.so failed:\n{res.stdout}\n{res.stderr}')
+    if verbose:
+        print(res.stdout.strip())
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load libvqhip.so and declare every entry point of include/vqhip.h; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VqhipError(
+                f'{LIB_PATH} not found: build it with vector_quantization_amd/csrc/build.sh '
+                '(or __graft_entry__.build()); there is no fallback path')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().vqhip_last_error()
+        raise VqhipError(f'{what} failed with code {rc}: {msg.decode() if msg else ""}')

@@ -1,0 +1,378 @@
+// libvqhip — host entry points (C ABI in include/vqhip.h).  gfx950 only.
+#include "vqhip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vqhip_kernels.h"
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *what, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), "%s%s%s", what, detail[0] ? ": " : "", detail);
+    return code;
+}
+
+#define VQ_CHECK_LAUNCH(name)                                            \
+    do {                                                                 \
+        hipError_t err__ = hipGetLastError();                            \
+        if (err__ != hipSuccess) return fail(VQHIP_ELAUNCH, name, hipGetErrorString(err__)); \
+    } while (0)
+
+#define VQ_HIP(call)                                                     \
+    do {                                                                 \
+        hipError_t err__ = (call);                                       \
+        if (err__ != hipSuccess) return fail(VQHIP_ELAUNCH, #call, hipGetErrorString(err__)); \
+    } while (0)
+
+// ---- optional per-launch timing of the proposal kernel (bench.py roofline) -------------------------------
+// Events are recorded on the caller's stream right around the coarse_kernel launch; vqhip_profile_collect
+// synchronises on them.  Disabled (zero overhead) unless vqhip_profile_enable(1) was called.
+#include <vector>
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+
+static void prof_begin(hipStream_t s) {
+    if (!g_prof_on) return;
+    if (g_prof_used == g_prof_events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return; }
+        g_prof_events.emplace_back(a, b);
+    }
+    (void)hipEventRecord(g_prof_events[g_prof_used].first, s);
+}
+static void prof_end(hipStream_t s) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_prof_events[g_prof_used].second, s);
+    ++g_prof_used;
+}
+
+static inline int waves_grid(int64_t rows, int waves_per_block) {
+    return (int)((rows + waves_per_block - 1) / waves_per_block);
+}
+
+// ---- proposal-pass dispatch ------------------------------------------------------------------------
+template <int NSTEP, int TM, int WAVES, int TPS>
+static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+                             int64_t Np, hipStream_t s) {
+    constexpr int BM = WAVES * TM * 32;
+    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    auto kern = coarse_kernel<NSTEP, TM, WAVES, TPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    int64_t ntb = (N + BM - 1) / BM;
+    prof_begin(s);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np);
+    prof_end(s);
+    VQ_CHECK_LAUNCH("coarse_kernel");
+    return VQHIP_OK;
+}
+
+static int pick_slices(int64_t ntb, int64_t nstages) {
+    int64_t want = ntb >= 32 ? 8 : (256 + ntb - 1) / ntb;
+    int ns = want > 8 ? 16 : (want > 4 ? 8 : (want > 2 ? 4 : (want > 1 ? 2 : 1)));
+    while (ns > 1 && ns > nstages) ns >>= 1;
+    return ns;
+}
+
+static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
+                         int *nslices_out, hipStream_t s) {
+    const int nstep = L.nstep;
+    // small batches use one token tile per wave so that more workgroups exist
+    const bool small = N <= 256 * 64;
+#define VQ_CFG(NS, TM, W, TPS)                                                                      \
+    {                                                                                               \
+        int64_t ntb = (N + (W) * (TM) * 32 - 1) / ((W) * (TM) * 32);                                \
+        int ns = pick_slices(ntb, L.nstages);                                                       \
+        *nslices_out = ns;                                                                          \
+        return launch_coarse_cfg<NS, TM, W, TPS>(ximg, N, frag, L.nstages, ns, rec, Np, s);         \
+    }
+    switch (nstep) {
+        case 1: if (small) VQ_CFG(1, 1, 8, 4) else VQ_CFG(1, 2, 8, 4)
+        case 2: if (small) VQ_CFG(2, 1, 8, 4) else VQ_CFG(2, 2, 8, 4)
+        case 4: if (small) VQ_CFG(4, 1, 8, 4) else VQ_CFG(4, 2, 8, 4)
+        case 8: if (small) VQ_CFG(8, 1, 8, 4) else VQ_CFG(8, 2, 8, 4)
+        case 16: if (small) VQ_CFG(16, 1, 8, 4) else VQ_CFG(16, 2, 8, 4)
+        case 32: VQ_CFG(32, 1, 8, 2)
+        default: break;
+    }
+#undef VQ_CFG
+    return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
+}
+
+static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, int64_t N, int64_t K, int D,
+                          int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
+    const int grid = 1024;
+    if (x_dtype == VQHIP_DTYPE_F32)
+        exact_kernel<0, 0><<<grid, 256, 0, s>>>(x, e, en, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    else
+        exact_kernel<1, 0><<<grid, 256, 0, s>>>(x, e, en, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    VQ_CHECK_LAUNCH("exact_kernel");
+    return VQHIP_OK;
+}
+
+extern "C" {
+
+int vqhip_version(void) { return VQHIP_VERSION; }
+const char *vqhip_last_error(void) { return g_err; }
+
+int64_t vqhip_codebook_bytes(int64_t K, int D) {
+    if (K <= 0 || D <= 0) return 0;
+    return vq_cb_layout(K, D).total;
+}
+
+int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D) {
+    if (N < 0 || K <= 0 || D <= 0) return 0;
+    return vq_ws_layout(N > 0 ? N : 1, K, D).total;
+}
+
+int vqhip_row_sqnorm(const void *v, int dtype, int64_t R, int D, float *out, void *stream) {
+    if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) row_sqnorm_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
+    else if (dtype == VQHIP_DTYPE_BF16) row_sqnorm_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
+    else return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: dtype");
+    VQ_CHECK_LAUNCH("row_sqnorm_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, float *out, void *stream) {
+    if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_normalize_rows: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) normalize_rows_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
+    else if (dtype == VQHIP_DTYPE_BF16) normalize_rows_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
+    else return fail(VQHIP_EINVAL, "vqhip_normalize_rows: dtype");
+    VQ_CHECK_LAUNCH("normalize_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
+    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS))
+        return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
+    if (K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: K too large");
+    hipStream_t s = (hipStream_t)stream;
+    VqCbLayout L = vq_cb_layout(K, D);
+    char *c = (char *)cb;
+    VQ_HIP(hipMemsetAsync(c + L.off_stats, 0, 256, s));
+    cb_stats_kernel<<<waves_grid(K, 4), 256, 0, s>>>(e, K, D, metric, c, L);
+    VQ_CHECK_LAUNCH("cb_stats_kernel");
+    if (vq_coarse_supported(D)) {
+        cb_resid_kernel<<<waves_grid(K, 4), 256, 0, s>>>(e, K, D, metric, c, L);
+        VQ_CHECK_LAUNCH("cb_resid_kernel");
+        int64_t pieces = L.nstages * (L.stage_bytes / 16);
+        cb_frag_kernel<<<(int)((pieces + 255) / 256), 256, 0, s>>>(e, K, D, metric, c, L);
+        VQ_CHECK_LAUNCH("cb_frag_kernel");
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
+                 int64_t *idx, int32_t *hist, void *ws, void *stream) {
+    if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
+    if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    VqCbLayout L = vq_cb_layout(K, D);
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    const char *c = (const char *)cb;
+    char *w = (char *)ws;
+    const int64_t Np = (N + 63) / 64 * 64;
+    int *counters = (int *)(w + W.off_counters);
+    float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *rec = (float *)(w + W.off_rec);
+    int *flag_list = (int *)(w + W.off_flag);
+    u64 *keys = (u64 *)(w + W.off_keys);
+    const float *en = (const float *)(c + L.off_en);
+    const float *e_exact = (metric == VQHIP_METRIC_COS) ? (const float *)(c + L.off_eexact) : e;
+
+    if (!vq_coarse_supported(D)) {
+        // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
+        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
+    }
+    VQ_HIP(hipMemsetAsync(counters, 0, 256, s));
+    int nslices = 1, rc;
+    char *ximg = w + W.off_ximg;
+    const int xgrid = (int)((N + 31) / 32);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2);
+    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2);
+    VQ_CHECK_LAUNCH("x_prep_kernel");
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
+    if (rc) return rc;
+    const int rgrid = (int)((N + 255) / 256);
+    if (x_dtype == VQHIP_DTYPE_F32)
+        refine_kernel<0><<<rgrid, 256, 0, s>>>(x, e_exact, c, L, N, D, metric, nslices, rec, xh2, rho2, Np, idx, hist,
+                                               flag_list, counters, keys);
+    else
+        refine_kernel<1><<<rgrid, 256, 0, s>>>(x, e_exact, c, L, N, D, metric, nslices, rec, xh2, rho2, Np, idx, hist,
+                                               flag_list, counters, keys);
+    VQ_CHECK_LAUNCH("refine_kernel");
+    rc = run_exact_rows(x, x_dtype, e_exact, en, N, K, D, metric, flag_list, counters, keys, s);
+    if (rc) return rc;
+    finalize_kernel<<<256, 256, 0, s>>>(keys, flag_list, counters, N, idx, nullptr, hist);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
+                       float *dmin, int32_t *hist, void *ws, void *stream) {
+    if (!x || !e || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: bad argument");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: x_dtype");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: N or K too large");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    char *w = (char *)ws;
+    u64 *keys = (u64 *)(w + W.off_keys);
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    fill_u64_kernel<<<256, 256, 0, s>>>(keys, N, ~0ull);
+    VQ_CHECK_LAUNCH("fill_u64_kernel");
+    int rc = run_exact_rows(x, x_dtype, e, en, N, K, D, metric, nullptr, nullptr, keys, s);
+    if (rc) return rc;
+    finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, N, idx, dmin, hist);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
+                     int64_t *col_idx, void *ws, void *stream) {
+    if (!x || !e || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_col_argmin: bad argument");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin: N or K too large");
+    hipStream_t s = (hipStream_t)stream;
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    char *w = (char *)ws;
+    u64 *keys = (u64 *)(w + W.off_keys);
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    fill_u64_kernel<<<256, 256, 0, s>>>(keys, K, ~0ull);
+    VQ_CHECK_LAUNCH("fill_u64_kernel");
+    if (x_dtype == VQHIP_DTYPE_F32)
+        exact_kernel<0, 1><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, keys, nullptr);
+    else if (x_dtype == VQHIP_DTYPE_BF16)
+        exact_kernel<1, 1><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, keys, nullptr);
+    else return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
+    VQ_CHECK_LAUNCH("exact_kernel<col>");
+    finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, K, col_idx, nullptr, nullptr);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, float *d, void *ws,
+                   void *stream) {
+    if (!x || !e || !d || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_distance: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    char *w = (char *)ws;
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    if (x_dtype == VQHIP_DTYPE_F32)
+        exact_kernel<0, 2><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, nullptr, d);
+    else if (x_dtype == VQHIP_DTYPE_BF16)
+        exact_kernel<1, 2><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, nullptr, d);
+    else return fail(VQHIP_EINVAL, "vqhip_distance: x_dtype");
+    VQ_CHECK_LAUNCH("exact_kernel<dist>");
+    return VQHIP_OK;
+}
+
+int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                          float *z_ste, double *sse, void *stream) {
+    if (!x || !e || !idx || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: bad argument");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((N + 3) / 4);
+    if (x_dtype == VQHIP_DTYPE_F32) gather_ste_loss_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_ste_loss_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
+    else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");
+    VQ_CHECK_LAUNCH("gather_ste_loss_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream) {
+    if (!idx || !hist || N < 0 || K <= 0) return fail(VQHIP_EINVAL, "vqhip_hist: bad argument");
+    if (N == 0) return VQHIP_OK;
+    int grid = (int)((N + 255) / 256); grid = grid > 2048 ? 2048 : grid;
+    hist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, N, K, hist);
+    VQ_CHECK_LAUNCH("hist_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_scatter_add_rows(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst, void *stream) {
+    if (!src || !idx || !dst || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_scatter_add_rows: bad argument");
+    if (N == 0) return VQHIP_OK;
+    scatter_add_rows_kernel<<<waves_grid(N, 4), 256, 0, (hipStream_t)stream>>>(src, idx, N, K, D, dst);
+    VQ_CHECK_LAUNCH("scatter_add_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out, void *stream) {
+    if (!x || !row_idx || !out || K < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_rows: bad argument");
+    if (K == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == VQHIP_DTYPE_F32) gather_rows_kernel<0><<<waves_grid(K, 4), 256, 0, s>>>(x, row_idx, K, D, out);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_rows_kernel<1><<<waves_grid(K, 4), 256, 0, s>>>(x, row_idx, K, D, out);
+    else return fail(VQHIP_EINVAL, "vqhip_gather_rows: x_dtype");
+    VQ_CHECK_LAUNCH("gather_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay, void *stream) {
+    if (!w || !hist || !sums || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_update: bad argument");
+    vqkd_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, hist, sums, K, D, decay);
+    VQ_CHECK_LAUNCH("vqkd_update_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K, int D,
+                     float ema_decay, float eps, void *stream) {
+    if (!w || !p || !hist || !anchors || K <= 0 || D <= 0 || numel <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_update: bad argument");
+    cvq_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, p, hist, numel, anchors, K, D, ema_decay, eps);
+    VQ_CHECK_LAUNCH("cvq_update_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
+    if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
+    VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VQHIP_OK;
+}
+
+int vqhip_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return VQHIP_OK;
+}
+
+int vqhip_profile_collect(double *ms_sum, int64_t *launches) {
+    if (!ms_sum || !launches) return fail(VQHIP_EINVAL, "vqhip_profile_collect: bad argument");
+    double total = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        VQ_HIP(hipEventSynchronize(g_prof_events[i].second));
+        float ms = 0.0f;
+        VQ_HIP(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+        total += ms;
+    }
+    *ms_sum = total;
+    *launches = (int64_t)g_prof_used;
+    g_prof_used = 0;
+    return VQHIP_OK;
+}
+
+}  // extern "C"

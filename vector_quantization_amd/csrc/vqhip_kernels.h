@@ -1,0 +1,806 @@
+// Device kernels of libvqhip (gfx950 / CDNA4 only — wave64, MFMA, LDS-DMA).
+//
+// Arithmetic contract: the result of every index-producing entry point is the argmin of the
+// fp32 definition evaluated with k-ordered fma chains — exactly what v_mfma_f32_32x32x2_f32 and the
+// scalar fmaf loops below compute, and what oracle/vq_oracle.c restates on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vqhip_layout.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+#define VQ_F16_MIN_NORMAL 6.103515625e-05f
+#define VQ_U 5.9604644775390625e-08f /* 2^-24 */
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+template <int DT>
+__device__ __forceinline__ float load_elem(const void *p, int64_t i) {
+    if (DT == 0) return ((const float *)p)[i];
+    return bf16_to_f32(((const uint16_t *)p)[i]);
+}
+
+// 8 consecutive elements starting at element offset i (i % 8 == 0, rows 16/32-byte aligned)
+template <int DT>
+__device__ __forceinline__ void load8(const void *p, int64_t i, float (&v)[8]) {
+    if (DT == 0) {
+        const float4 *q = (const float4 *)((const float *)p + i);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        uint4 a = *(const uint4 *)((const uint16_t *)p + i);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xFFFF0000u);
+    }
+}
+
+
+// raw 8-element vector loads for the proposal-pass prologue (kept as integers until all are in flight)
+template <int DT> struct RawVec;
+template <> struct RawVec<0> {
+    struct type { float4 a, b; };
+    static __device__ __forceinline__ type load(const void *p, int64_t i) {
+        const float4 *q = (const float4 *)((const float *)p + i);
+        type t; t.a = q[0]; t.b = q[1]; return t;
+    }
+    static __device__ __forceinline__ void unpack(const type &t, float (&v)[8]) {
+        v[0] = t.a.x; v[1] = t.a.y; v[2] = t.a.z; v[3] = t.a.w; v[4] = t.b.x; v[5] = t.b.y; v[6] = t.b.z; v[7] = t.b.w;
+    }
+};
+template <> struct RawVec<1> {
+    typedef uint4 type;
+    static __device__ __forceinline__ type load(const void *p, int64_t i) { return *(const uint4 *)((const uint16_t *)p + i); }
+    static __device__ __forceinline__ void unpack(const type &a, float (&v)[8]) {
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xFFFF0000u);
+    }
+};
+
+// single-instruction max (hipcc otherwise wraps fmaxf on MFMA results in canonicalising v_max pairs)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// fp32 -> fp16 (RNE) with subnormal results flushed to zero, so the MFMA never sees an fp16 subnormal
+__device__ __forceinline__ _Float16 to_f16_ftz(float v) {
+    _Float16 q = (_Float16)v;
+    float b = (float)q;
+    if (fabsf(b) < VQ_F16_MIN_NORMAL) q = (_Float16)0.0f;   // NaN compares false and stays NaN
+    return q;
+}
+
+__device__ __forceinline__ float wave_sum_tree(float p) {   // halving tree 32,16,...,1 (oracle order)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+__device__ __forceinline__ float wave_max(float p) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = fmaxf(p, __shfl_xor(p, off, 64));
+    return p;
+}
+
+// power-of-two scale that maps max|e| into [2^13, 2^14)
+__device__ __forceinline__ float cb_scale(const VqCbStats *st) {
+    float m = __uint_as_float(st->maxabs_bits);
+    if (!(m > 0.0f) || st->nonfinite) return 1.0f;
+    int ex;
+    (void)frexpf(m, &ex);            // m = f * 2^ex, f in [0.5,1)
+    int sh = 14 - ex;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    return ldexpf(1.0f, sh);
+}
+
+// C/D register -> row of the 32x32 MFMA tile (MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// row kernels: oracle-order |v|^2 and F.normalize
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void row_sqnorm_kernel(const void *v, int64_t R, int D, float *out) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    if (lane == 0) out[r] = p;
+}
+
+template <int DT>
+__global__ void normalize_rows_kernel(const void *v, int64_t R, int D, float eps, float *out) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p);
+    float den = (nrm < eps) ? eps : nrm;
+    for (int d = lane; d < D; d += 64) out[r * D + d] = load_elem<DT>(v, r * D + d) / den;
+}
+
+// ------------------------------------------------------------------------------------------------
+// codebook preparation
+// ------------------------------------------------------------------------------------------------
+// pass 1 (wave per code): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags
+__global__ void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    float *en = (float *)(cb + L.off_en);
+    float *ex = (float *)(cb + L.off_eexact);
+    float p = 0.0f, amax = 0.0f;
+    bool bad = false;
+    for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    float q2 = 0.0f;
+    if (metric == VQHIP_METRIC_COS) {
+        float nrm = sqrtf(p);
+        float den = (nrm < 1e-12f) ? 1e-12f : nrm;
+        for (int d = lane; d < D; d += 64) {
+            float a = e[k * D + d] / den;
+            ex[k * D + d] = a;
+            amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+        }
+        q2 = wave_sum_tree(q2);
+        if (lane == 0) en[k] = 0.0f;
+    } else {
+        for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); }
+        q2 = p;
+        if (lane == 0) en[k] = p;
+    }
+    amax = wave_max(amax);
+    bad = __any(bad) || !isfinite(q2);
+    if (lane == 0) {
+        if (bad) atomicOr(&st->nonfinite, 1u);
+        else {
+            atomicMax(&st->maxabs_bits, __float_as_uint(amax));
+            atomicMax(&st->e2max_bits, __float_as_uint(q2));
+            if (metric == VQHIP_METRIC_L2) atomicMax(&st->enmax_bits, __float_as_uint(p));
+        }
+    }
+}
+
+// pass 2 (wave per code): fp16 residual / image norms with the final scale
+__global__ void cb_resid_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    if (st->nonfinite) return;
+    const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
+    float se = cb_scale(st), inv = 1.0f / se;
+    float r2 = 0.0f, h2 = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float a = src[k * D + d];
+        float back = (float)to_f16_ftz(a * se) * inv;
+        float res = a - back;
+        r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+    }
+    r2 = wave_sum_tree(r2); h2 = wave_sum_tree(h2);
+    if (lane == 0) {
+        if (!isfinite(r2) || !isfinite(h2)) atomicOr(&st->nonfinite, 1u);
+        else { atomicMax(&st->r2max_bits, __float_as_uint(r2)); atomicMax(&st->eh2max_bits, __float_as_uint(h2)); }
+    }
+}
+
+// pass 3 (thread per 16-byte fragment piece): the MFMA-fragment-major fp16 image.
+// chunk (tile T, k-step s) holds, for lane l, codes T*32+(l&31), dims 16s + 8(l>>5) .. +8 — exactly the
+// A operand of v_mfma_f32_32x32x16_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
+__global__ void cb_frag_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t pieces_per_stage = L.stage_bytes / 16;
+    int64_t stage = gid / pieces_per_stage;
+    if (stage >= L.nstages) return;
+    int64_t piece = gid % pieces_per_stage;
+    int chunk = (int)(piece / 64), lane = (int)(piece % 64);
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
+    const float *en = (const float *)(cb + L.off_en);
+    float se = cb_scale(st);
+    char *dst = cb + L.off_frag + stage * L.stage_bytes + (int64_t)chunk * VQ_CHUNK_BYTES + lane * 16;
+    int nfrag = L.tps * L.nstep;
+    if (chunk < nfrag) {
+        int ti = chunk / L.nstep, s = chunk % L.nstep;
+        int64_t k = (stage * L.tps + ti) * VQ_TILE_CODES + (lane & 31);
+        int d0 = 16 * s + 8 * (lane >> 5);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = (k < K && d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+            o[j] = to_f16_ftz(a * se);
+        }
+        *(half8 *)dst = o;
+    } else {
+        // aux chunk: 4 floats per lane; lanes 0..(tps*8-1) carry -se*|e_k|^2/2 for the stage's codes
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = lane * 4 + j;
+            int64_t k = stage * L.tps * VQ_TILE_CODES + c;
+            float v = 0.0f;
+            if (c < L.tps * VQ_TILE_CODES) v = (k < K) ? (-0.5f * en[k]) * se : -INFINITY;
+            o[j] = v;
+        }
+        *(f32x4 *)dst = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token preparation: fp16 (flush-to-zero) fragment-major image of x, |xh|^2 and |x - xh|^2 per row
+// ------------------------------------------------------------------------------------------------
+// One 256-thread block per tile of 32 tokens.  Image chunk (tile, k-step s) holds for lane l the dims
+// 16s + 8(l>>5) .. +8 of token tile*32 + (l&31): the B operand of v_mfma_f32_32x32x16_f16.
+template <int DT>
+__global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
+                                                     char *__restrict__ ximg, float *__restrict__ xh2,
+                                                     float *__restrict__ rho2) {
+    __shared__ float red[2][8][32];
+    const int64_t tile = blockIdx.x;
+    const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t t = tile * 32 + r;
+    const bool tvalid = t < N;
+    const int64_t trow = tvalid ? t : (N - 1);
+    float s_h = 0.0f, s_r = 0.0f;
+    for (int piece = g; piece < nstep * 2; piece += 8) {
+        const int s = piece >> 1, h = piece & 1;
+        const int d0 = 16 * s + 8 * h;
+        half8 f;
+        if (tvalid && d0 < D) {
+            float v[8];
+            load8<DT>(x, trow * D + d0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 q = to_f16_ftz(v[j]);
+                float b = (float)q, res = v[j] - b;
+                s_h = fmaf(b, b, s_h); s_r = fmaf(res, res, s_r);
+                f[j] = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (_Float16)0.0f;
+        }
+        *(half8 *)(ximg + (tile * nstep + s) * (int64_t)VQ_CHUNK_BYTES + (h * 32 + r) * 16) = f;
+    }
+    red[0][g][r] = s_h; red[1][g][r] = s_r;
+    __syncthreads();
+    if (g == 0 && tvalid) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += red[0][i][r]; b += red[1][i][r]; }
+        xh2[t] = a; rho2[t] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 MFMA proposal pass
+// ------------------------------------------------------------------------------------------------
+struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
+
+__device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
+    if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }
+    else if (v > t.v2) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = v; t.c2 = c; }
+    else t.v3 = fmaxf(t.v3, v);
+}
+
+// One workgroup = WAVES waves x TM token tiles of 32 tokens held in registers as MFMA B fragments;
+// it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds) and
+// keeps, per lane and per slot (tile-in-stage), the best score with its tile/register and the runner-up
+// value.  Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (accumulator initialised with the aux value).
+template <int NSTEP, int TM, int WAVES, int TPS>
+__global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
+    const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
+    float *__restrict__ rec, int64_t Np) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int BM = WAVES * TM * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int sl = blockIdx.x % nslices;
+    const int64_t tb = blockIdx.x / nslices;
+    const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
+    const int64_t ntt = (N + 31) / 32;                   // token tiles in the fp16 token image
+
+    // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
+    half8 xf[TM][NSTEP];
+    int64_t tok[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        int64_t tt = tb * (BM / 32) + wave * TM + tm;
+        tok[tm] = tt * 32 + r;
+        tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
+        const char *src = ximg + tt * (int64_t)(NSTEP * VQ_CHUNK_BYTES) + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) xf[tm][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+    }
+
+    float b1[TM][TPS], b2[TM][TPS];
+    uint32_t t1[TM][TPS];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) { b1[tm][ti] = -INFINITY; b2[tm][ti] = -INFINITY; t1[tm][ti] = 0; }
+
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+
+    if (st0 < st1) issue_stage(st0, 0);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+
+    for (int64_t st = st0; st < st1; ++st) {
+        const int buf = (int)((st - st0) & 1);
+        if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+        const char *base = lds + buf * STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x16 acc[TM];
+            // accumulator init = -se*|e|^2/2 of this lane's 16 code rows (rows 8g+4h+{0..3} per register group g)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    acc[tm][4 * g + 0] = a4[0]; acc[tm][4 * g + 1] = a4[1];
+                    acc[tm][4 * g + 2] = a4[2]; acc[tm][4 * g + 3] = a4[3];
+                }
+            }
+            // A fragments one k-step ahead of the MFMAs that consume them
+            half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                half8 a_nxt = a_cur;
+                if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], acc[tm], 0, 0, 0);
+                a_cur = a_nxt;
+            }
+            const uint32_t tg = (uint32_t)(st * TPS + ti);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const uint32_t old = __float_as_uint(b1[tm][ti]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float v = __uint_as_float((__float_as_uint(acc[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
+                    b2[tm][ti] = __builtin_amdgcn_fmed3f(b1[tm][ti], b2[tm][ti], v);
+                    b1[tm][ti] = vmax(b1[tm][ti], v);
+                }
+                t1[tm][ti] = (__float_as_uint(b1[tm][ti]) != old) ? tg : t1[tm][ti];
+            }
+        }
+        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+    }
+
+    // ---- merge slots, then the two lane halves; lanes 0..31 write one record per (token, slice) ----
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        Top2 t; t.v1 = t.v2 = t.v3 = -INFINITY; t.c1 = t.c2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+            uint32_t bits = __float_as_uint(b1[tm][ti]);
+            uint32_t code = t1[tm][ti] * 32u + (uint32_t)mfma_row((int)(bits & 15u), h);
+            if (b1[tm][ti] > -INFINITY) top_insert(t, b1[tm][ti], code);
+            t.v3 = fmaxf(t.v3, b2[tm][ti]);
+        }
+        Top2 o;
+        o.v1 = __shfl_xor(t.v1, 32, 64); o.v2 = __shfl_xor(t.v2, 32, 64); o.v3 = __shfl_xor(t.v3, 32, 64);
+        o.c1 = __shfl_xor(t.c1, 32, 64); o.c2 = __shfl_xor(t.c2, 32, 64);
+        if (o.c1 != 0xFFFFFFFFu) top_insert(t, o.v1, o.c1);
+        if (o.c2 != 0xFFFFFFFFu) top_insert(t, o.v2, o.c2);
+        t.v3 = fmaxf(t.v3, o.v3);
+        if (h == 0 && tok[tm] < N) {
+            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tok[tm];
+            rp[0] = t.v1; rp[Np] = __uint_as_float(t.c1); rp[2 * Np] = t.v2;
+            rp[3 * Np] = __uint_as_float(t.c2); rp[4 * Np] = t.v3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scalar evaluation (refine)
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ float sqnorm_thread(const void *x, int64_t off, int D) {   // oracle order, one thread
+    float p[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) p[j] = 0.0f;
+    for (int base = 0; base < D; base += 64) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            if (base + j < D) { float a = load_elem<DT>(x, off + base + j); p[j] = fmaf(a, a, p[j]); }
+    }
+#pragma unroll
+    for (int off2 = 32; off2 >= 1; off2 >>= 1)
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < off2) p[j] = p[j] + p[j + off2];
+    return p[0];
+}
+
+template <int DT>
+__device__ float oracle_distance(const void *x, int64_t xoff, const float *erow, int D, int metric, float xn, float en) {
+    float c = 0.0f;
+    if (metric == VQHIP_METRIC_L2) {
+        for (int d = 0; d < D; ++d) c = fmaf(-2.0f * load_elem<DT>(x, xoff + d), erow[d], c);
+        float t = (c + xn) + en;
+        t = (t < 0.0f) ? 0.0f : t;
+        return sqrtf(t);
+    }
+    for (int d = 0; d < D; ++d) c = fmaf(load_elem<DT>(x, xoff + d), erow[d], c);
+    return 1.0f - c;
+}
+
+// torch.argmin order on (distance, index): NaN first, then smaller distance, then smaller index
+__device__ __forceinline__ u64 dist_key(float d, uint32_t k) {
+    if (isnan(d)) return (u64)k;
+    if (d == 0.0f) d = 0.0f;                 // -0 and +0 tie (lowest index wins), as in torch.argmin
+    uint32_t b = __float_as_uint(d);
+    // distances are >= 0 for L2; COS distances may be slightly negative: make the map monotone for both signs
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((u64)b + 1ull) << 32 | (u64)k;      // b+1 <= 2^32 : fits in the upper 33 bits
+}
+
+// thread per token: merge slice records under the rigorous margin, settle or flag
+template <int DT>
+__global__ void refine_kernel(const void *x, const float *e_exact, const char *cb, VqCbLayout L, int64_t N, int D,
+                              int metric, int nslices, const float *rec, const float *xh2, const float *rho2,
+                              int64_t Np, int64_t *idx, int32_t *hist, int *flag_list, int *counters, u64 *keys) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float *en = (const float *)(cb + L.off_en);
+    bool flagged = st->nonfinite != 0;
+    float X2 = xh2[n], R2 = rho2[n];
+    if (!isfinite(X2) || !isfinite(R2)) flagged = true;
+    const float infl = 1.0f + 1e-5f;
+    float se = cb_scale(st);
+    float Xh = sqrtf(X2) * infl, rho = sqrtf(R2) * infl, Xn = Xh + rho;
+    float Emax = sqrtf(__uint_as_float(st->e2max_bits)) * infl;
+    float Rmax = sqrtf(__uint_as_float(st->r2max_bits)) * infl;
+    float Ehmax = sqrtf(__uint_as_float(st->eh2max_bits)) * infl;
+    float ENmax = __uint_as_float(st->enmax_bits);
+    float Df = (float)L.Dp;
+    float m;
+    if (metric == VQHIP_METRIC_L2) {
+        // oracle rounding slop S (in squared-distance units) and proposal error B (in score units)
+        float mag = Xn * Xn + ENmax + 2.0f * Xn * Emax;
+        float S = 2.0f * (1.01f * Df * VQ_U * 2.0f * Xn * Emax + 2.1f * VQ_U * mag) + 4.0f * VQ_U * mag;
+        float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax + 0.5f * ENmax);
+        m = (2.0f * B + 0.5f * S);
+        if (!(mag < 1e30f)) flagged = true;
+    } else {
+        float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax);
+        m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
+    }
+    m = m * se * infl + 1e-37f;
+    if (!isfinite(m)) flagged = true;
+
+    float gbest = -INFINITY;
+    for (int s = 0; s < nslices; ++s) gbest = fmaxf(gbest, rec[((int64_t)s * VQ_REC_FIELDS + 0) * Np + n]);
+    if (!(gbest > -INFINITY)) flagged = true;
+    const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
+    int nc = 0;
+    uint32_t best = 0xFFFFFFFFu;
+    if (!flagged) {
+        for (int s = 0; s < nslices; ++s) {
+            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+            float v1 = rp[0], v2 = rp[2 * Np], v3 = rp[4 * Np];
+            if (v3 >= thr) flagged = true;
+            if (v1 >= thr) { ++nc; best = __float_as_uint(rp[Np]); }
+            if (v2 >= thr) ++nc;
+        }
+    }
+    if (flagged || nc == 0) {
+        int pos = atomicAdd(&counters[0], 1);
+        flag_list[pos] = (int)n;
+        keys[n] = ~0ull;
+        return;
+    }
+    if (nc > 1) {
+        atomicAdd(&counters[1], 1);
+        float xn = (metric == VQHIP_METRIC_L2) ? sqnorm_thread<DT>(x, n * D, D) : 0.0f;
+        u64 bk = ~0ull;
+        for (int s = 0; s < nslices; ++s) {
+            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (rp[2 * f * Np] >= thr) {
+                    uint32_t k = __float_as_uint(rp[(2 * f + 1) * Np]);
+                    float d = oracle_distance<DT>(x, n * D, e_exact + (int64_t)k * D, D, metric, xn, en[k]);
+                    u64 key = dist_key(d, k);
+                    bk = key < bk ? key : bk;
+                }
+            }
+        }
+        best = (uint32_t)(bk & 0xFFFFFFFFull);
+    }
+    idx[n] = (int64_t)best;
+    if (hist) atomicAdd(&hist[best], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32 MFMA pass (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain)
+// ------------------------------------------------------------------------------------------------
+// MODE 0: row argmin via 64-bit atomicMin keys[row]; MODE 1: column argmin keys[code]; MODE 2: store d[N,K]
+// Work item = (tile of 32 rows, chunk of 4*CT*32 codes); persistent grid-stride loop over items.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                    const float *__restrict__ en_in, int64_t N, int64_t K, int D,
+                                                    int metric, const int *__restrict__ row_list,
+                                                    const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
+                                                    float *__restrict__ dout) {
+    constexpr int CT = 4;                       // code tiles per wave
+    constexpr int DB = 256;                     // dims per register block
+    constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    const int64_t ntiles = (nrows + 31) / 32;
+    const int64_t nchunks = (K + CHUNK - 1) / CHUNK;
+    const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < ntiles * nchunks; item += gridDim.x) {
+        const int64_t tile = item / nchunks, chunk = item % nchunks;
+        const int64_t slot = tile * 32 + j;
+        const bool rvalid = slot < nrows;
+        const int64_t row = rvalid ? (row_list ? (int64_t)row_list[slot] : slot) : 0;
+        const int64_t kbase = chunk * CHUNK + (int64_t)wave * CT * 32;
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        float xn = 0.0f;   // oracle |x|^2 of this lane's row (wave-cooperative tree, 32 rows sequentially is too slow:
+                           // each lane computes its own row with the thread-order emulation only when needed below)
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {      // 4 consecutive dims per load
+                int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (rvalid && d < D) {
+                    if (DT == 0) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)((const float *)x + row * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            v0 = load_elem<DT>(x, row * D + d);
+                            if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                            if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                            if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                        }
+                    } else {
+                        v0 = load_elem<DT>(x, row * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int64_t k = kbase + c * 32 + j;         // this lane's A row (code)
+                const bool kvalid = k < K;
+                const float *erow = e + (kvalid ? k : 0) * D;
+#pragma unroll
+                for (int s4 = 0; s4 < DB / 4; ++s4) {
+                    int d = db + 4 * s4;
+                    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (d < D) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)(erow + d);
+                            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
+                        } else {
+                            a0 = erow[d];
+                            if (d + 1 < D) a1 = erow[d + 1];
+                            if (d + 2 < D) a2 = erow[d + 2];
+                            if (d + 3 < D) a3 = erow[d + 3];
+                        }
+                        if (!kvalid) { a0 = a1 = a2 = a3 = 0.0f; }
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1 : a0, xfr[2 * s4], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a3 : a2, xfr[2 * s4 + 1], acc[c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (metric == VQHIP_METRIC_L2) xn = rvalid ? sqnorm_thread<DT>(x, row * D, D) : 0.0f;
+
+        // epilogue: C[code row][token col j]
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (metric == VQHIP_METRIC_L2) {
+                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = 1.0f - acc[c][q];
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    // column argmin: reduce over the 32 token lanes of this half, one atomic per code
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+}
+
+// decode keys -> idx (+hist, +dmin).  rows = flagged list (device count) or all N
+__global__ void finalize_kernel(const u64 *keys, const int *row_list, const int *nrows_dev, int64_t N, int64_t *idx,
+                                float *dmin, int32_t *hist) {
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = row_list ? (int64_t)row_list[i] : i;
+        u64 key = keys[row];
+        uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
+        idx[row] = (int64_t)k;
+        if (hist) atomicAdd(&hist[k], 1);
+        if (dmin) {
+            u64 hi = key >> 32;
+            float d;
+            if (hi == 0) d = __uint_as_float(0x7FC00000u);
+            else {
+                uint32_t b = (uint32_t)(hi - 1ull);
+                b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+                d = __uint_as_float(b);
+            }
+            dmin[row] = d;
+        }
+    }
+}
+
+__global__ void fill_u64_kernel(u64 *p, int64_t n, u64 v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode / STE / loss partial sums, histogram, scatter-add, gathers, codebook updates
+// ------------------------------------------------------------------------------------------------
+// wave per token row: z = e[idx], z_ste = x + (z - x), sse += (z-x)^2 (double, one atomic per block)
+template <int DT>
+__global__ void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                                       float *zste, double *sse) {
+    __shared__ double red[4];
+    int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    if (n < N) {
+        const float *er = e + idx[n] * D;
+        for (int d = lane; d < D; d += 64) {
+            float xv = load_elem<DT>(x, n * D + d), zv = er[d];
+            float df = zv - xv;
+            if (z) z[n * D + d] = zv;
+            if (zste) zste[n * D + d] = xv + df;
+            s += (double)(df * df);
+        }
+    }
+    if (sse) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+__global__ void hist_kernel(const int64_t *idx, int64_t N, int64_t K, int32_t *hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k = idx[i];
+        if (k >= 0 && k < K) atomicAdd(&hist[k], 1);
+    }
+}
+
+// wave per source row; lanes sweep the row so each atomic wave-instruction adds 256 contiguous bytes
+__global__ void scatter_add_rows_kernel(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst) {
+    int64_t n = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    int64_t k = idx[n];
+    if (k < 0 || k >= K) return;
+    for (int d = lane; d < D; d += 64) atomicAdd(&dst[k * D + d], src[n * D + d]);
+}
+
+template <int DT>
+__global__ void gather_rows_kernel(const void *x, const int64_t *row_idx, int64_t K, int D, float *out) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int64_t n = row_idx[k];
+    for (int d = lane; d < D; d += 64) out[k * D + d] = load_elem<DT>(x, n * D + d);
+}
+
+// VQ-KD codebook update, wave per code (callbacks.py:66-70,126-128,73-75)
+__global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int64_t occ = hist[k];
+    float cnt = (float)(occ > 0 ? occ : 1);
+    // c = where(occurred, sums / max(count,1), w); then normalize
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        p = fmaf(c, c, p);
+    }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p), den = (nrm < 1e-12f) ? 1e-12f : nrm;
+    float om = 1.0f - decay;
+    float q = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        c = c / den;
+        float v = w[k * D + d] * decay + c * om;       // todd.utils.ema
+        q = fmaf(v, v, q);
+    }
+    q = wave_sum_tree(q);
+    float nrm2 = sqrtf(q), den2 = (nrm2 < 1e-12f) ? 1e-12f : nrm2;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        c = c / den;
+        float v = w[k * D + d] * decay + c * om;
+        w[k * D + d] = v / den2;
+    }
+}
+
+// CVQ-VAE update, wave per code (quantizer_callback.py:94-102)
+__global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K,
+                                  int D, float ema_decay, float eps) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    float freq = (float)hist[k] / (float)numel;
+    float pk = p[k] * ema_decay + freq * (1.0f - ema_decay);
+    float decay = 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
+    float om = 1.0f - decay;
+    for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors[k * D + d] * om;
+    if (lane == 0) p[k] = pk;
+}

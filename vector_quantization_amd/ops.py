@@ -1,0 +1,236 @@
+"""Tensor-level front end of libvqhip: torch tensors in, torch tensors out, every byte of arithmetic in
+the HIP library.  torch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import METRIC_COS, METRIC_L2, check
+
+METRICS = {'L2': METRIC_L2, 'Cosine': METRIC_COS, METRIC_L2: METRIC_L2, METRIC_COS: METRIC_COS}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VqhipError('vector_quantization_amd ops need tensors on an MI355X device (no CPU path)')
+
+
+def _latents(x: torch.Tensor):
+    """Dense row-major [N, D] view of the latents in a dtype the library reads (fp32 or bf16)."""
+    if x.dim() != 2:
+        raise ValueError(f'expected [N, D] latents, got {tuple(x.shape)}')
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    x = x.contiguous()
+    if x.data_ptr() % 16:
+        x = x.clone()
+    return x, (_lib.DTYPE_F32 if x.dtype == torch.float32 else _lib.DTYPE_BF16)
+
+
+def _codebook(e: torch.Tensor) -> torch.Tensor:
+    if e.dim() != 2:
+        raise ValueError(f'expected [K, D] codebook, got {tuple(e.shape)}')
+    e = e.detach()
+    if e.dtype != torch.float32:
+        e = e.float()
+    e = e.contiguous()
+    if e.data_ptr() % 16:
+        e = e.clone()
+    return e
+
+
+def _bytes(n: int, device) -> torch.Tensor:
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+@dataclass
+class PreparedCodebook:
+    """Device image produced by vqhip_codebook_prepare (fp16 MFMA fragments, |e|^2, error bounds)."""
+    image: torch.Tensor
+    weight: torch.Tensor          # the fp32 codebook the image was made from (kept alive for the re-rank)
+    K: int
+    D: int
+    metric: int
+
+
+def prepare_codebook(e: torch.Tensor, metric='L2') -> PreparedCodebook:
+    _require_cuda(e)
+    e = _codebook(e)
+    K, D = e.shape
+    m = METRICS[metric]
+    L = _lib.lib()
+    image = _bytes(L.vqhip_codebook_bytes(K, D), e.device)
+    check(L.vqhip_codebook_prepare(_ptr(e), K, D, m, _ptr(image), _stream()), 'vqhip_codebook_prepare')
+    return PreparedCodebook(image, e, K, D, m)
+
+
+def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] = None,
+           return_stats: bool = False):
+    """idx[n] = argmin_k distance(x_n, e_k) — fused fp16 proposal + exact fp32 re-rank.
+
+    For the cosine metric x must already be normalised (``normalize_rows``)."""
+    _require_cuda(x)
+    x, dt = _latents(x)
+    N, D = x.shape
+    if D != cb.D:
+        raise ValueError(f'latent dim {D} != codebook dim {cb.D}')
+    L = _lib.lib()
+    idx = torch.empty(N, dtype=torch.int64, device=x.device)
+    ws = _bytes(L.vqhip_workspace_bytes(N, cb.K, D), x.device)
+    if hist is not None:
+        assert hist.dtype == torch.int32 and hist.numel() == cb.K and hist.is_contiguous()
+    check(L.vqhip_argmin(_ptr(x), dt, _ptr(cb.weight), _ptr(cb.image), N, cb.K, D, cb.metric, _ptr(idx),
+                         _ptr(hist), _ptr(ws), _stream()), 'vqhip_argmin')
+    if return_stats:
+        st = torch.zeros(4, dtype=torch.int32, device=x.device)
+        if N > 0:
+            check(L.vqhip_argmin_stats(_ptr(ws), _ptr(st), _stream()), 'vqhip_argmin_stats')
+        return idx, st
+    return idx
+
+
+def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None,
+                 return_min: bool = False):
+    """Same contract as ``argmin`` evaluated entirely with fp32 MFMA (x, e normalised by the caller for cosine)."""
+    _require_cuda(x, e)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    L = _lib.lib()
+    idx = torch.empty(N, dtype=torch.int64, device=x.device)
+    dmin = torch.empty(N, dtype=torch.float32, device=x.device) if return_min else None
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
+    check(L.vqhip_argmin_exact(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(idx), _ptr(dmin), _ptr(hist),
+                               _ptr(ws), _stream()), 'vqhip_argmin_exact')
+    return (idx, dmin) if return_min else idx
+
+
+def distance(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
+    """Materialised d[N, K] (memo['distance']); x, e normalised by the caller for cosine."""
+    _require_cuda(x, e)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    L = _lib.lib()
+    d = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
+    check(L.vqhip_distance(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(d), _ptr(ws), _stream()),
+          'vqhip_distance')
+    return d
+
+
+def col_argmin(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
+    """NearestAnchor indices: for every code the nearest token (lowest token on ties)."""
+    _require_cuda(x, e)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    L = _lib.lib()
+    out = torch.empty(K, dtype=torch.int64, device=x.device)
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
+    check(L.vqhip_col_argmin(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(out), _ptr(ws), _stream()),
+          'vqhip_col_argmin')
+    return out
+
+
+def row_sqnorm(v: torch.Tensor) -> torch.Tensor:
+    _require_cuda(v)
+    v, dt = _latents(v)
+    out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+    check(_lib.lib().vqhip_row_sqnorm(_ptr(v), dt, v.shape[0], v.shape[1], _ptr(out), _stream()), 'vqhip_row_sqnorm')
+    return out
+
+
+def normalize_rows(v: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """F.normalize(v, dim=1) as fp32."""
+    _require_cuda(v)
+    v, dt = _latents(v)
+    out = torch.empty(v.shape, dtype=torch.float32, device=v.device)
+    check(_lib.lib().vqhip_normalize_rows(_ptr(v), dt, v.shape[0], v.shape[1], eps, _ptr(out), _stream()),
+          'vqhip_normalize_rows')
+    return out
+
+
+def gather_ste_loss(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: bool = True,
+                    need_ste: bool = True, need_sse: bool = True):
+    """(z = e[idx], z_ste = x + (z - x), sse = sum (z-x)^2 as a float64[1] tensor); unwanted outputs are None."""
+    _require_cuda(x, e, idx)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    idx = idx.reshape(-1).contiguous()
+    assert idx.dtype == torch.int64 and idx.numel() == x.shape[0]
+    N, D = x.shape
+    z = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_z else None
+    zs = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_ste else None
+    sse = torch.zeros(1, dtype=torch.float64, device=x.device) if need_sse else None
+    check(_lib.lib().vqhip_gather_ste_loss(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(z), _ptr(zs), _ptr(sse),
+                                           _stream()), 'vqhip_gather_ste_loss')
+    return z, zs, sse
+
+
+def hist(idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_cuda(idx)
+    idx = idx.reshape(-1).contiguous()
+    assert idx.dtype == torch.int64
+    if out is None:
+        out = torch.zeros(K, dtype=torch.int32, device=idx.device)
+    check(_lib.lib().vqhip_hist(_ptr(idx), idx.numel(), K, _ptr(out), _stream()), 'vqhip_hist')
+    return out
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _require_cuda(src, idx)
+    src = src.float().contiguous()
+    idx = idx.reshape(-1).contiguous()
+    if out is None:
+        out = torch.zeros(K, src.shape[1], dtype=torch.float32, device=src.device)
+    check(_lib.lib().vqhip_scatter_add_rows(_ptr(src), _ptr(idx), src.shape[0], K, src.shape[1], _ptr(out), _stream()),
+          'vqhip_scatter_add_rows')
+    return out
+
+
+def gather_rows(x: torch.Tensor, row_idx: torch.Tensor) -> torch.Tensor:
+    _require_cuda(x, row_idx)
+    x, dt = _latents(x)
+    row_idx = row_idx.reshape(-1).contiguous()
+    out = torch.empty(row_idx.numel(), x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.lib().vqhip_gather_rows(_ptr(x), dt, _ptr(row_idx), row_idx.numel(), x.shape[1], _ptr(out), _stream()),
+          'vqhip_gather_rows')
+    return out
+
+
+def vqkd_update_(w: torch.Tensor, hist64: torch.Tensor, sums: torch.Tensor, decay: float) -> torch.Tensor:
+    """In-place VQ-KD codebook update on a contiguous fp32 [K, D] tensor."""
+    _require_cuda(w, hist64, sums)
+    assert w.dtype == torch.float32 and w.is_contiguous() and hist64.dtype == torch.int64
+    K, D = w.shape
+    check(_lib.lib().vqhip_vqkd_update(_ptr(w), _ptr(hist64.contiguous()), _ptr(sums.contiguous()), K, D, decay,
+                                       _stream()), 'vqhip_vqkd_update')
+    return w
+
+
+def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: torch.Tensor, numel: int, anchors: torch.Tensor,
+                ema_decay: float, eps: float) -> None:
+    """In-place CVQ-VAE probability + codebook update."""
+    _require_cuda(w, p, hist64, anchors)
+    assert w.dtype == torch.float32 and w.is_contiguous() and p.dtype == torch.float32 and p.is_contiguous()
+    K, D = w.shape
+    check(_lib.lib().vqhip_cvq_update(_ptr(w), _ptr(p), _ptr(hist64.contiguous()), int(numel),
+                                      _ptr(anchors.contiguous()), K, D, ema_decay, eps, _stream()), 'vqhip_cvq_update')
