@@ -175,6 +175,7 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
 
 int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
                  int64_t *idx, int32_t *hist, void *ws, void *stream) {
+    if (N == 0) return VQHIP_OK;
     if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
@@ -224,6 +225,7 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
 
 int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
                        float *dmin, int32_t *hist, void *ws, void *stream) {
+    if (N == 0) return VQHIP_OK;
     if (!x || !e || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: bad argument");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: x_dtype");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: N or K too large");

@@ -236,7 +236,9 @@ __global__ void cb_frag_kernel(const float *e, int64_t K, int D, int metric, cha
             int c = lane * 4 + j;
             int64_t k = stage * L.tps * VQ_TILE_CODES + c;
             float v = 0.0f;
-            if (c < L.tps * VQ_TILE_CODES) v = (k < K) ? (-0.5f * en[k]) * se : -INFINITY;
+            // padded codes get a large FINITE negative score: -inf with the register index or-ed into its low
+            // mantissa bits would be a signalling NaN and poison v_max_f32
+            if (c < L.tps * VQ_TILE_CODES) v = (k < K) ? (-0.5f * en[k]) * se : -3.0e38f;
             o[j] = v;
         }
         *(f32x4 *)dst = o;
