@@ -105,13 +105,20 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
 }
 
-static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, int64_t N, int64_t K, int D,
+static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
                           int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
     const int grid = 1024;
-    if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 0><<<grid, 256, 0, s>>>(x, e, en, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
-    else
-        exact_kernel<1, 0><<<grid, 256, 0, s>>>(x, e, en, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    if (row_list) {   // a few flagged rows against the whole codebook: small work items
+        if (x_dtype == VQHIP_DTYPE_F32)
+            exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+        else
+            exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    } else {
+        if (x_dtype == VQHIP_DTYPE_F32)
+            exact_kernel<0, 0, 4><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+        else
+            exact_kernel<1, 0, 4><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    }
     VQ_CHECK_LAUNCH("exact_kernel");
     return VQHIP_OK;
 }
@@ -161,10 +168,10 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
     VqCbLayout L = vq_cb_layout(K, D);
     char *c = (char *)cb;
     VQ_HIP(hipMemsetAsync(c + L.off_stats, 0, 256, s));
-    cb_stats_kernel<<<waves_grid(K, 4), 256, 0, s>>>(e, K, D, metric, c, L);
+    cb_stats_kernel<<<(int)(waves_grid(K, 4) > 512 ? 512 : waves_grid(K, 4)), 256, 0, s>>>(e, K, D, metric, c, L);
     VQ_CHECK_LAUNCH("cb_stats_kernel");
     if (vq_coarse_supported(D)) {
-        cb_resid_kernel<<<waves_grid(K, 4), 256, 0, s>>>(e, K, D, metric, c, L);
+        cb_resid_kernel<<<(int)(waves_grid(K, 4) > 512 ? 512 : waves_grid(K, 4)), 256, 0, s>>>(e, K, D, metric, c, L);
         VQ_CHECK_LAUNCH("cb_resid_kernel");
         int64_t pieces = L.nstages * (L.stage_bytes / 16);
         cb_frag_kernel<<<(int)((pieces + 255) / 256), 256, 0, s>>>(e, K, D, metric, c, L);
@@ -209,14 +216,34 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
     if (rc) return rc;
     const int rgrid = (int)((N + 255) / 256);
-    if (x_dtype == VQHIP_DTYPE_F32)
-        refine_kernel<0><<<rgrid, 256, 0, s>>>(x, e_exact, c, L, N, D, metric, nslices, rec, xh2, rho2, Np, idx, hist,
-                                               flag_list, counters, keys);
-    else
-        refine_kernel<1><<<rgrid, 256, 0, s>>>(x, e_exact, c, L, N, D, metric, nslices, rec, xh2, rho2, Np, idx, hist,
-                                               flag_list, counters, keys);
-    VQ_CHECK_LAUNCH("refine_kernel");
-    rc = run_exact_rows(x, x_dtype, e_exact, en, N, K, D, metric, flag_list, counters, keys, s);
+    int *multi_list = (int *)(w + W.off_multi);
+    refine_decide_kernel<<<rgrid, 256, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, flag_list,
+                                               multi_list, counters, keys);
+    VQ_CHECK_LAUNCH("refine_decide_kernel");
+    {
+        // re-rank: one wave per queued row; LDS per wave = (1 + 2*VQ_MAX_SLICES) rows of D floats
+        int wpb = 4;
+        size_t per_wave = (size_t)(VQ_RR_BATCH + 1) * ((D + 3) & ~3) * sizeof(float);
+        while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
+        if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
+        size_t lds = per_wave * wpb;
+        auto kern = (x_dtype == VQHIP_DTYPE_F32) ? refine_rerank_kernel<0> : refine_rerank_kernel<1>;
+        static size_t lds_set[2] = {0, 0};
+        if (lds > lds_set[x_dtype]) {
+            VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set[x_dtype] = lds;
+        }
+        kern<<<1024, wpb * 64, lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np, idx, hist, multi_list,
+                                        counters);
+        VQ_CHECK_LAUNCH("refine_rerank_kernel");
+    }
+    float *xn = xh2;     // xh2 is dead after the decision kernels: reuse it for the oracle-order |x|^2 of flagged rows
+    if (metric == VQHIP_METRIC_L2) {
+        if (x_dtype == VQHIP_DTYPE_F32) row_sqnorm_list_kernel<0><<<256, 256, 0, s>>>(x, D, flag_list, counters, xn);
+        else row_sqnorm_list_kernel<1><<<256, 256, 0, s>>>(x, D, flag_list, counters, xn);
+        VQ_CHECK_LAUNCH("row_sqnorm_list_kernel");
+    }
+    rc = run_exact_rows(x, x_dtype, e_exact, en, xn, N, K, D, metric, flag_list, counters, keys, s);
     if (rc) return rc;
     finalize_kernel<<<256, 256, 0, s>>>(keys, flag_list, counters, N, idx, nullptr, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
@@ -241,7 +268,12 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
     }
     fill_u64_kernel<<<256, 256, 0, s>>>(keys, N, ~0ull);
     VQ_CHECK_LAUNCH("fill_u64_kernel");
-    int rc = run_exact_rows(x, x_dtype, e, en, N, K, D, metric, nullptr, nullptr, keys, s);
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
+    int rc = run_exact_rows(x, x_dtype, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, s);
     if (rc) return rc;
     finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, N, idx, dmin, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
@@ -261,12 +293,17 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
         int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
         if (rc) return rc;
     }
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
     fill_u64_kernel<<<256, 256, 0, s>>>(keys, K, ~0ull);
     VQ_CHECK_LAUNCH("fill_u64_kernel");
     if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 1><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, keys, nullptr);
+        exact_kernel<0, 1, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, nullptr);
     else if (x_dtype == VQHIP_DTYPE_BF16)
-        exact_kernel<1, 1><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, keys, nullptr);
+        exact_kernel<1, 1, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, nullptr);
     else return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
     VQ_CHECK_LAUNCH("exact_kernel<col>");
     finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, K, col_idx, nullptr, nullptr);
@@ -285,10 +322,15 @@ int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_
         int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
         if (rc) return rc;
     }
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
     if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 2><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, nullptr, d);
+        exact_kernel<0, 2, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, nullptr, d);
     else if (x_dtype == VQHIP_DTYPE_BF16)
-        exact_kernel<1, 2><<<1024, 256, 0, s>>>(x, e, en, N, K, D, metric, nullptr, nullptr, nullptr, d);
+        exact_kernel<1, 2, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, nullptr, d);
     else return fail(VQHIP_EINVAL, "vqhip_distance: x_dtype");
     VQ_CHECK_LAUNCH("exact_kernel<dist>");
     return VQHIP_OK;
@@ -300,6 +342,7 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = (int)((N + 3) / 4);
+    grid = grid > 1024 ? 1024 : grid;
     if (x_dtype == VQHIP_DTYPE_F32) gather_ste_loss_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
     else if (x_dtype == VQHIP_DTYPE_BF16) gather_ste_loss_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
     else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");

@@ -105,6 +105,13 @@ __device__ __forceinline__ float cb_scale(const VqCbStats *st) {
     return ldexpf(1.0f, sh);
 }
 
+
+// atomicMax on a hot word: read first (L2 hit), issue the atomic only when it would raise the value —
+// same-address atomics serialise at ~11 ns each, and after the first few waves the filter drops them all
+__device__ __forceinline__ void atomic_max_filtered(uint32_t *p, uint32_t v) {
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
+
 // C/D register -> row of the 32x32 MFMA tile (MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -138,66 +145,87 @@ __global__ void normalize_rows_kernel(const void *v, int64_t R, int D, float eps
 // ------------------------------------------------------------------------------------------------
 // codebook preparation
 // ------------------------------------------------------------------------------------------------
-// pass 1 (wave per code): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags
-__global__ void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
-    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (k >= K) return;
+__device__ __forceinline__ float block_max4(float v, float *red) {    // max over the 4 waves of a 256-thread block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// pass 1 (wave per code, grid-stride): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
+// Running maxima stay in registers; one filtered atomic set per block at the end (hot-word atomics serialise).
+__global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
     VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
     float *en = (float *)(cb + L.off_en);
     float *ex = (float *)(cb + L.off_eexact);
-    float p = 0.0f, amax = 0.0f;
+    float m_abs = 0.0f, m_e2 = 0.0f, m_en = 0.0f;
     bool bad = false;
-    for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; p = fmaf(a, a, p); }
-    p = wave_sum_tree(p);
-    float q2 = 0.0f;
-    if (metric == VQHIP_METRIC_COS) {
-        float nrm = sqrtf(p);
-        float den = (nrm < 1e-12f) ? 1e-12f : nrm;
-        for (int d = lane; d < D; d += 64) {
-            float a = e[k * D + d] / den;
-            ex[k * D + d] = a;
-            amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * 4) {
+        float p = 0.0f, amax = 0.0f;
+        for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; p = fmaf(a, a, p); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); }
+        p = wave_sum_tree(p);
+        float q2 = p;
+        if (metric == VQHIP_METRIC_COS) {
+            float nrm = sqrtf(p);
+            float den = (nrm < 1e-12f) ? 1e-12f : nrm;
+            amax = 0.0f; q2 = 0.0f;
+            for (int d = lane; d < D; d += 64) {
+                float a = e[k * D + d] / den;
+                ex[k * D + d] = a;
+                amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+            }
+            q2 = wave_sum_tree(q2);
+            if (lane == 0) en[k] = 0.0f;
+        } else {
+            if (lane == 0) en[k] = p;
+            m_en = fmaxf(m_en, p);
         }
-        q2 = wave_sum_tree(q2);
-        if (lane == 0) en[k] = 0.0f;
-    } else {
-        for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); }
-        q2 = p;
-        if (lane == 0) en[k] = p;
+        bad |= !isfinite(q2);
+        m_abs = fmaxf(m_abs, amax); m_e2 = fmaxf(m_e2, q2);
     }
-    amax = wave_max(amax);
-    bad = __any(bad) || !isfinite(q2);
-    if (lane == 0) {
-        if (bad) atomicOr(&st->nonfinite, 1u);
+    m_abs = wave_max(m_abs);
+    bad = __any(bad);
+    m_abs = block_max4(m_abs, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
+    float badf = block_max4(bad ? 1.0f : 0.0f, red);
+    if (threadIdx.x == 0) {
+        if (badf > 0.0f) atomicOr(&st->nonfinite, 1u);
         else {
-            atomicMax(&st->maxabs_bits, __float_as_uint(amax));
-            atomicMax(&st->e2max_bits, __float_as_uint(q2));
-            if (metric == VQHIP_METRIC_L2) atomicMax(&st->enmax_bits, __float_as_uint(p));
+            atomic_max_filtered(&st->maxabs_bits, __float_as_uint(m_abs));
+            atomic_max_filtered(&st->e2max_bits, __float_as_uint(m_e2));
+            if (metric == VQHIP_METRIC_L2) atomic_max_filtered(&st->enmax_bits, __float_as_uint(m_en));
         }
     }
 }
 
-// pass 2 (wave per code): fp16 residual / image norms with the final scale
-__global__ void cb_resid_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
-    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (k >= K) return;
-    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
-    if (st->nonfinite) return;
+// pass 2 (wave per code, grid-stride): fp16 residual / image norms with the final scale
+__global__ __launch_bounds__(256) void cb_resid_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);   // (no early exit on st->nonfinite: block barriers below)
     const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
-    float se = cb_scale(st), inv = 1.0f / se;
-    float r2 = 0.0f, h2 = 0.0f;
-    for (int d = lane; d < D; d += 64) {
-        float a = src[k * D + d];
-        float back = (float)to_f16_ftz(a * se) * inv;
-        float res = a - back;
-        r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+    const float se = cb_scale(st), inv = 1.0f / se;
+    float m_r2 = 0.0f, m_h2 = 0.0f;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * 4) {
+        float r2 = 0.0f, h2 = 0.0f;
+        for (int d = lane; d < D; d += 64) {
+            float a = src[k * D + d];
+            float back = (float)to_f16_ftz(a * se) * inv;
+            float res = a - back;
+            r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+        }
+        r2 = wave_sum_tree(r2); h2 = wave_sum_tree(h2);
+        bad |= !isfinite(r2) || !isfinite(h2);
+        m_r2 = fmaxf(m_r2, r2); m_h2 = fmaxf(m_h2, h2);
     }
-    r2 = wave_sum_tree(r2); h2 = wave_sum_tree(h2);
-    if (lane == 0) {
-        if (!isfinite(r2) || !isfinite(h2)) atomicOr(&st->nonfinite, 1u);
-        else { atomicMax(&st->r2max_bits, __float_as_uint(r2)); atomicMax(&st->eh2max_bits, __float_as_uint(h2)); }
+    m_r2 = block_max4(m_r2, red); m_h2 = block_max4(m_h2, red);
+    float badf = block_max4(bad ? 1.0f : 0.0f, red);
+    if (threadIdx.x == 0) {
+        if (badf > 0.0f) atomicOr(&st->nonfinite, 1u);
+        else { atomic_max_filtered(&st->r2max_bits, __float_as_uint(m_r2)); atomic_max_filtered(&st->eh2max_bits, __float_as_uint(m_h2)); }
     }
 }
 
@@ -467,18 +495,10 @@ __device__ __forceinline__ u64 dist_key(float d, uint32_t k) {
     return ((u64)b + 1ull) << 32 | (u64)k;      // b+1 <= 2^32 : fits in the upper 33 bits
 }
 
-// thread per token: merge slice records under the rigorous margin, settle or flag
-template <int DT>
-__global__ void refine_kernel(const void *x, const float *e_exact, const char *cb, VqCbLayout L, int64_t N, int D,
-                              int metric, int nslices, const float *rec, const float *xh2, const float *rho2,
-                              int64_t Np, int64_t *idx, int32_t *hist, int *flag_list, int *counters, u64 *keys) {
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
-    const float *en = (const float *)(cb + L.off_en);
-    bool flagged = st->nonfinite != 0;
-    float X2 = xh2[n], R2 = rho2[n];
-    if (!isfinite(X2) || !isfinite(R2)) flagged = true;
+// Rigorous per-row margin (in scaled score units) between the proposal score and the fp32 definition.
+// Returns a negative value when the bound cannot be formed (non-finite data): the row is then flagged.
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2) {
+    if (st->nonfinite != 0 || !isfinite(X2) || !isfinite(R2)) return -1.0f;
     const float infl = 1.0f + 1e-5f;
     float se = cb_scale(st);
     float Xh = sqrtf(X2) * infl, rho = sqrtf(R2) * infl, Xn = Xh + rho;
@@ -486,63 +506,172 @@ __global__ void refine_kernel(const void *x, const float *e_exact, const char *c
     float Rmax = sqrtf(__uint_as_float(st->r2max_bits)) * infl;
     float Ehmax = sqrtf(__uint_as_float(st->eh2max_bits)) * infl;
     float ENmax = __uint_as_float(st->enmax_bits);
-    float Df = (float)L.Dp;
+    float Df = (float)Dp;
     float m;
     if (metric == VQHIP_METRIC_L2) {
-        // oracle rounding slop S (in squared-distance units) and proposal error B (in score units)
+        // S: rounding slop of the fp32 definition itself (squared-distance units): the D-term fma chain, the two
+        // additions and the sqrt tie window.  B: |proposal score - real score| <= fp16 residuals (Cauchy-Schwarz)
+        // + fp32 MFMA accumulation + the 4 low mantissa bits that carry the register index.
         float mag = Xn * Xn + ENmax + 2.0f * Xn * Emax;
+        if (!(mag < 1e30f)) return -1.0f;
         float S = 2.0f * (1.01f * Df * VQ_U * 2.0f * Xn * Emax + 2.1f * VQ_U * mag) + 4.0f * VQ_U * mag;
         float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax + 0.5f * ENmax);
-        m = (2.0f * B + 0.5f * S);
-        if (!(mag < 1e30f)) flagged = true;
+        m = 2.0f * B + 0.5f * S;
     } else {
         float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax);
         m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
     }
     m = m * se * infl + 1e-37f;
-    if (!isfinite(m)) flagged = true;
+    return isfinite(m) ? m : -1.0f;
+}
 
+// thread per token: merge the slice records under the margin; settle single-candidate rows, queue the rest
+__global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
+                                     const float *xh2, const float *rho2, int64_t Np, int64_t *idx, int32_t *hist,
+                                     int *flag_list, int *multi_list, int *counters, u64 *keys) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+    bool flagged = !(m > 0.0f);
+    float v1[VQ_MAX_SLICES], v2[VQ_MAX_SLICES], v3[VQ_MAX_SLICES], c1[VQ_MAX_SLICES];
+#pragma unroll
+    for (int s = 0; s < VQ_MAX_SLICES; ++s) {
+        const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+        const bool on = s < nslices;
+        v1[s] = on ? rp[0] : -INFINITY; c1[s] = on ? rp[Np] : 0.0f;
+        v2[s] = on ? rp[2 * Np] : -INFINITY; v3[s] = on ? rp[4 * Np] : -INFINITY;
+    }
     float gbest = -INFINITY;
-    for (int s = 0; s < nslices; ++s) gbest = fmaxf(gbest, rec[((int64_t)s * VQ_REC_FIELDS + 0) * Np + n]);
+#pragma unroll
+    for (int s = 0; s < VQ_MAX_SLICES; ++s) gbest = fmaxf(gbest, v1[s]);
     if (!(gbest > -INFINITY)) flagged = true;
     const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
     int nc = 0;
     uint32_t best = 0xFFFFFFFFu;
-    if (!flagged) {
-        for (int s = 0; s < nslices; ++s) {
-            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
-            float v1 = rp[0], v2 = rp[2 * Np], v3 = rp[4 * Np];
-            if (v3 >= thr) flagged = true;
-            if (v1 >= thr) { ++nc; best = __float_as_uint(rp[Np]); }
-            if (v2 >= thr) ++nc;
-        }
+#pragma unroll
+    for (int s = 0; s < VQ_MAX_SLICES; ++s) {
+        if (v3[s] >= thr) flagged = true;
+        if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
+        if (v2[s] >= thr) ++nc;
     }
     if (flagged || nc == 0) {
         int pos = atomicAdd(&counters[0], 1);
         flag_list[pos] = (int)n;
         keys[n] = ~0ull;
-        return;
+    } else if (nc > 1) {
+        int pos = atomicAdd(&counters[1], 1);
+        multi_list[pos] = (int)n;
+    } else {
+        idx[n] = (int64_t)best;
+        if (hist) atomicAdd(&hist[best], 1);
     }
-    if (nc > 1) {
-        atomicAdd(&counters[1], 1);
-        float xn = (metric == VQHIP_METRIC_L2) ? sqnorm_thread<DT>(x, n * D, D) : 0.0f;
-        u64 bk = ~0ull;
-        for (int s = 0; s < nslices; ++s) {
-            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                if (rp[2 * f * Np] >= thr) {
-                    uint32_t k = __float_as_uint(rp[(2 * f + 1) * Np]);
-                    float d = oracle_distance<DT>(x, n * D, e_exact + (int64_t)k * D, D, metric, xn, en[k]);
-                    u64 key = dist_key(d, k);
-                    bk = key < bk ? key : bk;
-                }
-            }
+}
+
+// wave per queued row (persistent): exact fp32 evaluation of its candidates.  The row and (up to VQ_RR_BATCH at
+// a time) candidate code rows are staged in LDS with coalesced loads; lane j then runs the fma chain of the j-th
+// candidate in d order.
+#define VQ_RR_BATCH 8
+template <int DT>
+__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const float *e_exact, const char *cb,
+                                                            VqCbLayout L, int D, int metric, int nslices,
+                                                            const float *rec, const float *xh2, const float *rho2,
+                                                            int64_t Np, int64_t *idx, int32_t *hist,
+                                                            const int *multi_list, const int *counters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int Dq = (D + 3) & ~3;                                  // rows padded to 16 bytes
+    float *xs = (float *)lds + (size_t)wave * (VQ_RR_BATCH + 1) * Dq;   // [Dq] row, then [BATCH][Dq] candidate rows
+    float *es = xs + Dq;
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float *en = (const float *)(cb + L.off_en);
+    const int nrows = counters[1];
+    for (int item = blockIdx.x * nwaves + wave; item < nrows; item += gridDim.x * nwaves) {
+        const int64_t n = multi_list[item];
+        const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+        // lane i < 2*nslices owns candidate slot (slice i/2, field i%2)
+        float v = -INFINITY; uint32_t code = 0xFFFFFFFFu;
+        if (lane < 2 * nslices) {
+            const float *rp = rec + (int64_t)(lane >> 1) * VQ_REC_FIELDS * Np + n;
+            v = rp[(2 * (lane & 1)) * Np];
+            code = __float_as_uint(rp[(2 * (lane & 1) + 1) * Np]);
         }
-        best = (uint32_t)(bk & 0xFFFFFFFFull);
+        const float gbest = wave_max((lane & 1) ? -INFINITY : v);
+        const bool cand = (lane < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
+        u64 cmask = __ballot(cand);
+        const int ncand = __popcll(cmask);
+        // stage x (oracle-order |x|^2 on the way)
+        float p = 0.0f;
+        for (int d = lane; d < Dq; d += 64) {
+            float a = d < D ? load_elem<DT>(x, n * D + d) : 0.0f;
+            xs[d] = a; p = fmaf(a, a, p);
+        }
+        const float xn = wave_sum_tree(p);
+        u64 key = ~0ull;
+        for (int b0 = 0; b0 < ncand; b0 += VQ_RR_BATCH) {
+            // j-th candidate of this batch = (b0+j)-th set bit of cmask
+            uint32_t mycode = 0xFFFFFFFFu;
+            u64 mm = cmask;
+            for (int j = 0; j < VQ_RR_BATCH && mm; ++j) {
+                const int src = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const uint32_t k = __shfl(code, src, 64);
+                if (lane == j) mycode = k;
+                const float *er = e_exact + (int64_t)k * D;
+                for (int d = lane; d < Dq; d += 64) es[j * Dq + d] = d < D ? er[d] : 0.0f;
+            }
+            cmask = mm;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mycode != 0xFFFFFFFFu) {
+                const float4 *xr = (const float4 *)xs;
+                const float4 *er = (const float4 *)(es + lane * Dq);
+                float c = 0.0f;
+                const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+#pragma unroll 4
+                for (int q = 0; q < Dq / 4; ++q) {
+                    float4 a = xr[q], bb = er[q];
+                    c = fmaf(sx * a.x, bb.x, c); c = fmaf(sx * a.y, bb.y, c);
+                    c = fmaf(sx * a.z, bb.z, c); c = fmaf(sx * a.w, bb.w, c);
+                }
+                float dist;
+                if (metric == VQHIP_METRIC_L2) {
+                    float t = (c + xn) + en[mycode];
+                    t = (t < 0.0f) ? 0.0f : t;
+                    dist = sqrtf(t);
+                } else {
+                    dist = 1.0f - c;
+                }
+                u64 kk = dist_key(dist, mycode);
+                key = kk < key ? kk : key;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { u64 o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
+        if (lane == 0) {
+            const uint32_t best = (uint32_t)(key & 0xFFFFFFFFull);
+            idx[n] = (int64_t)best;
+            if (hist) atomicAdd(&hist[best], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    idx[n] = (int64_t)best;
-    if (hist) atomicAdd(&hist[best], 1);
+}
+
+// oracle-order |x|^2 for the rows of a device-side list (wave per row, persistent)
+template <int DT>
+__global__ __launch_bounds__(256) void row_sqnorm_list_kernel(const void *x, int D, const int *row_list, const int *nrows_dev,
+                                                              float *xn_out) {
+    const int lane = threadIdx.x & 63;
+    const int nrows = *nrows_dev;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nrows; i += gridDim.x * 4) {
+        const int64_t r = row_list[i];
+        float p = 0.0f;
+        for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(x, r * D + d); p = fmaf(a, a, p); }
+        p = wave_sum_tree(p);
+        if (lane == 0) xn_out[r] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,13 +679,15 @@ __global__ void refine_kernel(const void *x, const float *e_exact, const char *c
 // ------------------------------------------------------------------------------------------------
 // MODE 0: row argmin via 64-bit atomicMin keys[row]; MODE 1: column argmin keys[code]; MODE 2: store d[N,K]
 // Work item = (tile of 32 rows, chunk of 4*CT*32 codes); persistent grid-stride loop over items.
-template <int DT, int MODE>
+template <int DT, int MODE, int CT>
 __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
-                                                    const float *__restrict__ en_in, int64_t N, int64_t K, int D,
+                                                    const float *__restrict__ en_in,
+                                                    const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
                                                     int metric, const int *__restrict__ row_list,
                                                     const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
                                                     float *__restrict__ dout) {
-    constexpr int CT = 4;                       // code tiles per wave
+    // CT = code tiles (32 codes) per wave: 4 for whole-batch passes, 1 when only a few flagged rows need the
+    // whole codebook (more, smaller work items)
     constexpr int DB = 256;                     // dims per register block
     constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -579,8 +710,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
 
-        float xn = 0.0f;   // oracle |x|^2 of this lane's row (wave-cooperative tree, 32 rows sequentially is too slow:
-                           // each lane computes its own row with the thread-order emulation only when needed below)
+        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? xn_in[row] : 0.0f;   // oracle-order |x|^2, precomputed
         for (int db = 0; db < D; db += DB) {
             // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
             float xfr[DB / 2];
@@ -599,6 +729,10 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                             if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
                             if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
                         }
+                    } else if (d + 3 < D && (D % 4) == 0) {
+                        uint2 t = *(const uint2 *)((const uint16_t *)x + row * D + d);
+                        v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                        v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
                     } else {
                         v0 = load_elem<DT>(x, row * D + d);
                         if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
@@ -635,7 +769,6 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                 }
             }
         }
-        if (metric == VQHIP_METRIC_L2) xn = rvalid ? sqnorm_thread<DT>(x, row * D, D) : 0.0f;
 
         // epilogue: C[code row][token col j]
         u64 best = ~0ull;
@@ -707,22 +840,42 @@ __global__ void fill_u64_kernel(u64 *p, int64_t n, u64 v) {
 // ------------------------------------------------------------------------------------------------
 // decode / STE / loss partial sums, histogram, scatter-add, gathers, codebook updates
 // ------------------------------------------------------------------------------------------------
-// wave per token row: z = e[idx], z_ste = x + (z - x), sse += (z-x)^2 (double, one atomic per block)
+// wave per token row, 4 elements (16 B) per lane and step, grid-stride over rows:
+// z = e[idx], z_ste = x + (z - x), sse += (z-x)^2 (fp32 within a lane's 4 elements, double across; one atomic per block)
 template <int DT>
-__global__ void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N, int D, float *z,
-                                       float *zste, double *sse) {
+__global__ __launch_bounds__(256) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
+                                                              int D, float *z, float *zste, double *sse) {
     __shared__ double red[4];
-    int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0;
-    if (n < N) {
+    const bool vec = (D % 4) == 0;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
         const float *er = e + idx[n] * D;
-        for (int d = lane; d < D; d += 64) {
-            float xv = load_elem<DT>(x, n * D + d), zv = er[d];
-            float df = zv - xv;
-            if (z) z[n * D + d] = zv;
-            if (zste) zste[n * D + d] = xv + df;
-            s += (double)(df * df);
+        if (vec) {
+            for (int d = lane * 4; d < D; d += 256) {
+                float4 zv = *(const float4 *)(er + d);
+                float xv[4];
+                if (DT == 0) {
+                    float4 t = *(const float4 *)((const float *)x + n * D + d);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                } else {
+                    uint2 t = *(const uint2 *)((const uint16_t *)x + n * D + d);
+                    xv[0] = __uint_as_float(t.x << 16); xv[1] = __uint_as_float(t.x & 0xFFFF0000u);
+                    xv[2] = __uint_as_float(t.y << 16); xv[3] = __uint_as_float(t.y & 0xFFFF0000u);
+                }
+                float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
+                if (z) *(float4 *)(z + n * D + d) = zv;
+                if (zste) *(float4 *)(zste + n * D + d) = make_float4(xv[0] + d0, xv[1] + d1, xv[2] + d2, xv[3] + d3);
+                s += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                float xv = load_elem<DT>(x, n * D + d), zv = er[d];
+                float df = zv - xv;
+                if (z) z[n * D + d] = zv;
+                if (zste) zste[n * D + d] = xv + df;
+                s += (double)(df * df);
+            }
         }
     }
     if (sse) {
@@ -730,7 +883,7 @@ __global__ void gather_ste_loss_kernel(const void *x, const float *e, const int6
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
 
