@@ -120,6 +120,9 @@ def main():
     for _ in range(args.warmup):
         step()
     L = _lib.lib()
+    for key, name in ((0, 'VQHIP_TUNE_PIPE'), (1, 'VQHIP_TUNE_PRIO'), (2, 'VQHIP_TUNE_SLICES')):   # A/B knobs (results unchanged)
+        if name in os.environ:
+            L.vqhip_set_tuning(key, int(os.environ[name]))
     barrier()
     L.vqhip_profile_enable(1)
     t0 = time.perf_counter()

@@ -54,12 +54,14 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 }
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
-template <int NSTEP, int TM, int WAVES, int TPS>
-static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+static int g_tune_pipe = 1, g_tune_prio = 0, g_tune_slices = 0;   // proposal-kernel variant knobs (vqhip_set_tuning)
+
+template <int NSTEP, int TM, int WAVES, int TPS, int PIPE, int PRIO>
+static int launch_coarse_var(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, hipStream_t s) {
     constexpr int BM = WAVES * TM * 32;
     constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TM, WAVES, TPS>;
+    auto kern = coarse_kernel<NSTEP, TM, WAVES, TPS, PIPE, PRIO>;
     static bool attr_set = false;
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -73,9 +75,27 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     return VQHIP_OK;
 }
 
+template <int NSTEP, int TM, int WAVES, int TPS>
+static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+                             int64_t Np, hipStream_t s) {
+    if (g_tune_pipe) {
+        if (g_tune_prio) return launch_coarse_var<NSTEP, TM, WAVES, TPS, 1, 1>(ximg, N, frag, nstages, nslices, rec, Np, s);
+        return launch_coarse_var<NSTEP, TM, WAVES, TPS, 1, 0>(ximg, N, frag, nstages, nslices, rec, Np, s);
+    }
+    if (g_tune_prio) return launch_coarse_var<NSTEP, TM, WAVES, TPS, 0, 1>(ximg, N, frag, nstages, nslices, rec, Np, s);
+    return launch_coarse_var<NSTEP, TM, WAVES, TPS, 0, 0>(ximg, N, frag, nstages, nslices, rec, Np, s);
+}
+
 static int pick_slices(int64_t ntb, int64_t nstages) {
-    int64_t want = ntb >= 32 ? 8 : (256 + ntb - 1) / ntb;
-    int ns = want > 8 ? 16 : (want > 4 ? 8 : (want > 2 ? 4 : (want > 1 ? 2 : 1)));
+    if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
+    // Enough slices to put a workgroup on every CU.  Fewer, longer workgroups are faster for the proposal kernel
+    // itself (N=65536: 2 slices 1304 TF, 8 slices 1254 TF) but every slice also adds candidate groups, and fewer
+    // groups send more rows to the whole-codebook fp32 pass (measured 156 / 80 / 53 us at 2 / 4 / 8 slices), so
+    // large batches stay at 8 slices (one per XCD L2) for now.
+    int64_t want = (256 + ntb - 1) / ntb;
+    if (want < 8) want = 8;
+    int ns = 1;
+    while (ns < want && ns < VQ_MAX_SLICES) ns <<= 1;
     while (ns > 1 && ns > nstages) ns >>= 1;
     return ns;
 }
@@ -396,6 +416,14 @@ int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, con
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
     if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
     VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VQHIP_OK;
+}
+
+int vqhip_set_tuning(int key, int value) {
+    if (key == 0) g_tune_pipe = value;
+    else if (key == 1) g_tune_prio = value;
+    else if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
+    else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;
 }
 

@@ -334,7 +334,7 @@ __device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
 // it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds) and
 // keeps, per lane and per slot (tile-in-stage), the best score with its tile/register and the runner-up
 // value.  Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (accumulator initialised with the aux value).
-template <int NSTEP, int TM, int WAVES, int TPS>
+template <int NSTEP, int TM, int WAVES, int TPS, int PIPE, int PRIO>
 __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np) {
@@ -381,49 +381,131 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     if (st0 < st1) issue_stage(st0, 0);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
 
+    if (PRIO) {   // static priority for the younger half of an 8-wave workgroup (breaks MFMA/VALU lockstep of SIMD partners)
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= (WAVES / 2) * 64) __builtin_amdgcn_s_setprio(1);
+    }
+    if (PIPE == 0) {
     for (int64_t st = st0; st < st1; ++st) {
-        const int buf = (int)((st - st0) & 1);
-        if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
-        const char *base = lds + buf * STAGE_BYTES;
-        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+            const int buf = (int)((st - st0) & 1);
+            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+            const char *base = lds + buf * STAGE_BYTES;
+            const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll
-        for (int ti = 0; ti < TPS; ++ti) {
-            f32x16 acc[TM];
-            // accumulator init = -se*|e|^2/2 of this lane's 16 code rows (rows 8g+4h+{0..3} per register group g)
+            for (int ti = 0; ti < TPS; ++ti) {
+                f32x16 acc[TM];
+                // accumulator init = -se*|e|^2/2 of this lane's 16 code rows (rows 8g+4h+{0..3} per register group g)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tm][4 * g + 0] = a4[0]; acc[tm][4 * g + 1] = a4[1];
+                        acc[tm][4 * g + 2] = a4[2]; acc[tm][4 * g + 3] = a4[3];
+                    }
+                }
+                // A fragments one k-step ahead of the MFMAs that consume them
+                half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    half8 a_nxt = a_cur;
+                    if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], acc[tm], 0, 0, 0);
+                    a_cur = a_nxt;
+                }
+                const uint32_t tg = (uint32_t)(st * TPS + ti);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    acc[tm][4 * g + 0] = a4[0]; acc[tm][4 * g + 1] = a4[1];
-                    acc[tm][4 * g + 2] = a4[2]; acc[tm][4 * g + 3] = a4[3];
+                    const uint32_t old = __float_as_uint(b1[tm][ti]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float v = __uint_as_float((__float_as_uint(acc[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
+                        b2[tm][ti] = __builtin_amdgcn_fmed3f(b1[tm][ti], b2[tm][ti], v);
+                        b1[tm][ti] = vmax(b1[tm][ti], v);
+                    }
+                    t1[tm][ti] = (__float_as_uint(b1[tm][ti]) != old) ? tg : t1[tm][ti];
                 }
             }
-            // A fragments one k-step ahead of the MFMAs that consume them
-            half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
+            __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+        }
+
+    } else {
+        // Software-pipelined form: the epilogue (top-2 tracking) of tile t-1 is spread over the MFMA steps of tile t, so
+        // that its VALU work issues in the shadow of this wave's own MFMAs.  Two accumulator sets ping-pong by tile parity.
+        static_assert(TPS % 2 == 0, "ping-pong needs an even number of tiles per stage");
+        f32x16 accA[TM], accB[TM];
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                half8 a_nxt = a_cur;
-                if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accB[tm][q] = -3.0e38f;     // "previous tile" of the very first tile: never wins
+        constexpr int EPS = (16 + NSTEP - 1) / NSTEP;                // accumulator registers retired per k-step
+        for (int64_t st = st0; st < st1; ++st) {
+            const int buf = (int)((st - st0) & 1);
+            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+            const char *base = lds + buf * STAGE_BYTES;
+            const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti) {
+                f32x16 (&cur)[TM] = (ti & 1) ? accB : accA;
+                f32x16 (&prv)[TM] = (ti & 1) ? accA : accB;
+                constexpr int PS_DUMMY = 0; (void)PS_DUMMY;
+                const int ps = (ti + TPS - 1) % TPS;                  // slot of the previous tile
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        cur[tm][4 * g + 0] = a4[0]; cur[tm][4 * g + 1] = a4[1];
+                        cur[tm][4 * g + 2] = a4[2]; cur[tm][4 * g + 3] = a4[3];
+                    }
+                }
+                uint32_t old[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) old[tm] = __float_as_uint(b1[tm][ps]);
+                half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    half8 a_nxt = a_cur;
+                    if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        cur[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], cur[tm], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int i = 0; i < EPS; ++i) {
+                            const int q = s * EPS + i;
+                            if (q < 16 && (NSTEP <= 16 || (s % (NSTEP / 16)) == 0)) {
+                                const int qq = NSTEP <= 16 ? q : s / (NSTEP / 16);
+                                float v = __uint_as_float((__float_as_uint(prv[tm][qq]) & 0xFFFFFFF0u) | (uint32_t)qq);
+                                b2[tm][ps] = __builtin_amdgcn_fmed3f(b1[tm][ps], b2[tm][ps], v);
+                                b1[tm][ps] = vmax(b1[tm][ps], v);
+                            }
+                        }
+                    a_cur = a_nxt;
+                }
+                const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], acc[tm], 0, 0, 0);
-                a_cur = a_nxt;
+                    t1[tm][ps] = (__float_as_uint(b1[tm][ps]) != old[tm]) ? tgp : t1[tm][ps];
             }
-            const uint32_t tg = (uint32_t)(st * TPS + ti);
+            __syncthreads();
+        }
+        // drain: epilogue of the last tile (slot TPS-1, held in accB since TPS is even)
+        if (st1 > st0) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const uint32_t old = __float_as_uint(b1[tm][ti]);
+                const uint32_t old = __float_as_uint(b1[tm][TPS - 1]);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    float v = __uint_as_float((__float_as_uint(acc[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
-                    b2[tm][ti] = __builtin_amdgcn_fmed3f(b1[tm][ti], b2[tm][ti], v);
-                    b1[tm][ti] = vmax(b1[tm][ti], v);
+                    float v = __uint_as_float((__float_as_uint(accB[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
+                    b2[tm][TPS - 1] = __builtin_amdgcn_fmed3f(b1[tm][TPS - 1], b2[tm][TPS - 1], v);
+                    b1[tm][TPS - 1] = vmax(b1[tm][TPS - 1], v);
                 }
-                t1[tm][ti] = (__float_as_uint(b1[tm][ti]) != old) ? tg : t1[tm][ti];
+                t1[tm][TPS - 1] = (__float_as_uint(b1[tm][TPS - 1]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[tm][TPS - 1];
             }
         }
-        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
     }
 
     // ---- merge slots, then the two lane halves; lanes 0..31 write one record per (token, slice) ----
