@@ -103,17 +103,41 @@ int vqhip_scatter_add_rows(const float *src, const int64_t *idx, int64_t N, int6
 /* ---- codebook updates ------------------------------------------------------------------------------- */
 /* VQKDCallback._kmeans tail + after_encode (callbacks.py:66-70,126-128,73-75):
  *   c = where(hist>0, sums/max(hist,1), w); c = normalize(c); c = w*decay + c*(1-decay); w = normalize(c)
- * hist int64[K] / sums[K,D] are the (all-reduced) statistics.  In place on w. */
+ * hist int64[K] / sums[K,D] are the (all-reduced) statistics.  In place on w.  centroid_only != 0 stops after the
+ * first line (VQKDCallback._kmeans as used by the k-means lazy init, callbacks.py:104-107). */
 int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay,
-                      void *stream);
+                      int centroid_only, void *stream);
 /* CVQVAECallback.after_encode (quantizer_callback.py:94-102):
  *   p = p*ema_decay + (hist/numel)*(1-ema_decay);  decay_k = 1 - exp(-p_k*K*10/(1-ema_decay) - eps)
- *   w_k = w_k*decay_k + anchors_k*(1-decay_k)      — in place on p[K] and w[K,D]. */
-int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K,
-                     int D, float ema_decay, float eps, void *stream);
+ *   w_k = w_k*decay_k + anchors_k*(1-decay_k)      — in place on p[K] and w[K,D].
+ * numel_dev (nullable DEVICE int64) overrides numel: the all-reduced token count can stay on the device.
+ * stage: 1 = update p only (the anchor sampler runs between the two halves, quantizer_callback.py:94-96),
+ *        2 = update w only from the current p, 3 = both. */
+int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
+                     const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage, void *stream);
 /* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
 int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
                       void *stream);
+
+/* ---- elementwise pieces of the backward / unfused path ------------------------------------------------
+ * vqhip_diff: sse[0] += sum (a-b)^2 in double (MSELoss forward, losses.py:50,62) and/or out = (a-b)*scale
+ *             (its backward); a, b may each be fp32 or bf16; out / sse nullable (not both).
+ * vqhip_ste:  out = x + (z - x)                                      (utils/ste.py:10)
+ * vqhip_normalize_rows_bwd: gradient of F.normalize(v, dim=1, eps) given the output gradient g. */
+int vqhip_diff(const void *a, int a_dtype, const void *b, int b_dtype, int64_t n, float scale,
+               const float *scale_dev /* nullable DEVICE scalar multiplied into scale */, float *out, double *sse,
+               void *stream);
+/* Fused backward of the quantizer forward (embedding_dense_backward + both MSE gradients + STE):
+ *   z = W[idx], z_ste = x + sg(z - x), m_cb = mse(z, sg x) (losses.py:50), m_cm = mse(sg z, x) (losses.py:62)
+ *   grad_x = g_zste + g_cm*(2/ND)*(x - z);   grad_w[idx] += g_cb*(2/ND)*(z - x)  (fp32 atomics)
+ * g_cb, g_cm: DEVICE scalars (upstream gradients of the two MSE values, nullable = 0); g_zste, grad_x, grad_w
+ * nullable (grad_w must be zero-initialised by the caller). */
+int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
+                      const float *g_zste, const float *g_cb, const float *g_cm, float *grad_x, float *grad_w,
+                      void *stream);
+int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream);
+int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv,
+                             void *stream);
 
 /* ---- diagnostics ------------------------------------------------------------------------------------
  * Copies the counters of the last vqhip_argmin on `ws` to out[4] (DEVICE int32): rows sent to the

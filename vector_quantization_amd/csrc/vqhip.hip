@@ -398,17 +398,19 @@ int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_
     return VQHIP_OK;
 }
 
-int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay, void *stream) {
+int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay, int centroid_only,
+                      void *stream) {
     if (!w || !hist || !sums || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_update: bad argument");
-    vqkd_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, hist, sums, K, D, decay);
+    vqkd_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, hist, sums, K, D, decay, centroid_only);
     VQ_CHECK_LAUNCH("vqkd_update_kernel");
     return VQHIP_OK;
 }
 
-int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K, int D,
-                     float ema_decay, float eps, void *stream) {
-    if (!w || !p || !hist || !anchors || K <= 0 || D <= 0 || numel <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_update: bad argument");
-    cvq_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, p, hist, numel, anchors, K, D, ema_decay, eps);
+int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev, const float *anchors,
+                     int64_t K, int D, float ema_decay, float eps, int stage, void *stream) {
+    if (!w || !p || K <= 0 || D <= 0 || stage < 1 || stage > 3 || ((stage & 1) && (!hist || (numel <= 0 && !numel_dev))) ||
+        ((stage & 2) && !anchors)) return fail(VQHIP_EINVAL, "vqhip_cvq_update: bad argument");
+    cvq_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, p, hist, numel, numel_dev, anchors, K, D, ema_decay, eps, stage);
     VQ_CHECK_LAUNCH("cvq_update_kernel");
     return VQHIP_OK;
 }
@@ -416,6 +418,59 @@ int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, con
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
     if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
     VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VQHIP_OK;
+}
+
+int vqhip_diff(const void *a, int a_dtype, const void *b, int b_dtype, int64_t n, float scale, const float *scale_dev,
+               float *out, double *sse, void *stream) {
+    if (!a || !b || n < 0 || (!out && !sse)) return fail(VQHIP_EINVAL, "vqhip_diff: bad argument");
+    if (n == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((n + 255) / 256); grid = grid > 2048 ? 2048 : grid;
+    if (a_dtype == 0 && b_dtype == 0) diff_kernel<0, 0><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 0 && b_dtype == 1) diff_kernel<0, 1><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 1 && b_dtype == 0) diff_kernel<1, 0><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 1 && b_dtype == 1) diff_kernel<1, 1><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else return fail(VQHIP_EINVAL, "vqhip_diff: dtype");
+    VQ_CHECK_LAUNCH("diff_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, const float *g_zste,
+                      const float *g_cb, const float *g_cm, float *grad_x, float *grad_w, void *stream) {
+    if (!x || !e || !idx || N < 0 || D <= 0 || (!grad_x && !grad_w)) return fail(VQHIP_EINVAL, "vqhip_vq_backward: bad argument");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((N + 3) / 4); grid = grid > 2048 ? 2048 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32)
+        vq_backward_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+    else if (x_dtype == VQHIP_DTYPE_BF16)
+        vq_backward_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+    else return fail(VQHIP_EINVAL, "vqhip_vq_backward: x_dtype");
+    VQ_CHECK_LAUNCH("vq_backward_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream) {
+    if (!x || !z || !out || n < 0) return fail(VQHIP_EINVAL, "vqhip_ste: bad argument");
+    if (n == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((n + 255) / 256); grid = grid > 4096 ? 4096 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32) ste_kernel<0><<<grid, 256, 0, s>>>(x, z, n, out);
+    else if (x_dtype == VQHIP_DTYPE_BF16) ste_kernel<1><<<grid, 256, 0, s>>>(x, z, n, out);
+    else return fail(VQHIP_EINVAL, "vqhip_ste: dtype");
+    VQ_CHECK_LAUNCH("ste_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv, void *stream) {
+    if (!v || !g || !gv || R < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_normalize_rows_bwd: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) normalize_bwd_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, g, R, D, eps, gv);
+    else if (dtype == VQHIP_DTYPE_BF16) normalize_bwd_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, g, R, D, eps, gv);
+    else return fail(VQHIP_EINVAL, "vqhip_normalize_rows_bwd: dtype");
+    VQ_CHECK_LAUNCH("normalize_bwd_kernel");
     return VQHIP_OK;
 }
 

@@ -996,12 +996,18 @@ __global__ void gather_rows_kernel(const void *x, const int64_t *row_idx, int64_
 }
 
 // VQ-KD codebook update, wave per code (callbacks.py:66-70,126-128,73-75)
-__global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay) {
+__global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay,
+                                   int centroid_only) {
     int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (k >= K) return;
     int64_t occ = hist[k];
     float cnt = (float)(occ > 0 ? occ : 1);
+    if (centroid_only) {   // VQKDCallback._kmeans alone (callbacks.py:66-70): where(occurred, sums/count, w)
+        if (occ > 0)
+            for (int d = lane; d < D; d += 64) w[k * D + d] = sums[k * D + d] / cnt;
+        return;
+    }
     // c = where(occurred, sums / max(count,1), w); then normalize
     float p = 0.0f;
     for (int d = lane; d < D; d += 64) {
@@ -1029,15 +1035,98 @@ __global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *s
 }
 
 // CVQ-VAE update, wave per code (quantizer_callback.py:94-102)
-__global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64_t numel, const float *anchors, int64_t K,
-                                  int D, float ema_decay, float eps) {
+__global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
+                                  const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage) {
     int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (k >= K) return;
-    float freq = (float)hist[k] / (float)numel;
-    float pk = p[k] * ema_decay + freq * (1.0f - ema_decay);
-    float decay = 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
-    float om = 1.0f - decay;
-    for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors[k * D + d] * om;
-    if (lane == 0) p[k] = pk;
+    // stage bit 0: p = ema(p, hist/numel); stage bit 1: w = ema(w, anchors, decay(p))
+    float pk = p[k];
+    if (stage & 1) {
+        if (numel_dev) numel = *numel_dev;      // all-reduced token count left on the device (no host sync)
+        float freq = (float)hist[k] / (float)numel;
+        pk = pk * ema_decay + freq * (1.0f - ema_decay);
+    }
+    if (stage & 2) {
+        float decay = 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
+        float om = 1.0f - decay;
+        for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors[k * D + d] * om;
+    }
+    if (lane == 0 && (stage & 1)) p[k] = pk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise pieces of the autograd path (losses.py:50,62; utils/ste.py:10; F.normalize backward)
+// ------------------------------------------------------------------------------------------------
+// sse += sum (a-b)^2 (double accumulation across lanes/blocks), optional out = (a-b)*scale
+template <int DTA, int DTB>
+__global__ __launch_bounds__(256) void diff_kernel(const void *a, const void *b, int64_t n, float scale,
+                                                   const float *scale_dev, float *out, double *sse) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    if (scale_dev) scale *= *scale_dev;          // upstream scalar gradient left on the device
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float df = load_elem<DTA>(a, i) - load_elem<DTB>(b, i);
+        if (out) out[i] = df * scale;
+        s += (double)(df * df);
+    }
+    if (sse) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// out = x + (z - x)
+template <int DT>
+__global__ void ste_kernel(const void *x, const float *z, int64_t n, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float xv = load_elem<DT>(x, i);
+        out[i] = xv + (z[i] - xv);
+    }
+}
+
+// backward of y = v / max(|v|, eps) per row: gv = (g - y*(y.g)) / max(|v|, eps)   (rows with |v| < eps: g / eps)
+template <int DT>
+__global__ void normalize_bwd_kernel(const void *v, const float *g, int64_t R, int D, float eps, float *gv) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p);
+    bool clamped = nrm < eps;
+    float den = clamped ? eps : nrm;
+    float dot = 0.0f;
+    for (int d = lane; d < D; d += 64) dot = fmaf(load_elem<DT>(v, r * D + d) / den, g[r * D + d], dot);
+    dot = wave_sum_tree(dot);
+    for (int d = lane; d < D; d += 64) {
+        float y = load_elem<DT>(v, r * D + d) / den;
+        gv[r * D + d] = clamped ? g[r * D + d] / den : (g[r * D + d] - y * dot) / den;
+    }
+}
+
+// fused backward of the quantizer forward, z = W[idx], z_ste = x + sg(z - x), m_cb = mse(z, sg x), m_cm = mse(sg z, x):
+//   grad_x = g_zste + g_cm*(2/ND)*(x - z)        grad_W[idx] += g_cb*(2/ND)*(z - x)
+// wave per token row; g_cb / g_cm are device scalars (upstream gradients of the two MSE values), nullable = 0.
+template <int DT>
+__global__ __launch_bounds__(256) void vq_backward_kernel(const void *x, const float *e, const int64_t *idx, int64_t N, int D,
+                                                          const float *g_zste, const float *g_cb, const float *g_cm,
+                                                          float *grad_x, float *grad_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float s = 2.0f / ((float)N * (float)D);
+    const float kx = (g_cm ? *g_cm : 0.0f) * s, kw = (g_cb ? *g_cb : 0.0f) * s;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int64_t k = idx[n];
+        for (int d = lane; d < D; d += 64) {
+            float xv = load_elem<DT>(x, n * D + d), zv = e[k * D + d];
+            float df = zv - xv;
+            if (grad_x) grad_x[n * D + d] = (g_zste ? g_zste[n * D + d] : 0.0f) - kx * df;
+            if (grad_w && kw != 0.0f) atomicAdd(&grad_w[k * D + d], kw * df);
+        }
+    }
 }

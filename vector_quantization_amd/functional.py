@@ -1,0 +1,125 @@
+"""Autograd-aware building blocks of the quantizer path.  Forward and backward arithmetic runs in libvqhip;
+torch.autograd.Function is only the glue that hooks the HIP kernels into PyTorch's graph."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def _as2d(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1])
+
+
+class _Embedding(Function):
+    """z = W[idx] (nn.Embedding, vq/algorithms/vq/quantizers.py:107); backward = dense scatter-add into W."""
+
+    @staticmethod
+    def forward(ctx, weight: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        flat = idx.reshape(-1)
+        ctx.save_for_backward(flat)
+        ctx.shape = weight.shape
+        z = ops.gather_rows(weight, flat)
+        return z.view(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        K, D = ctx.shape
+        gw = ops.scatter_add_rows(_as2d(g), flat, K) if ctx.needs_input_grad[0] else None
+        return gw, None
+
+
+def embedding(weight: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return _Embedding.apply(weight, idx)
+
+
+class _MSE(Function):
+    """mean((a-b)^2) (todd MSELoss, mean reduction; vq/algorithms/vq/losses.py:50,62)."""
+
+    @staticmethod
+    def forward(ctx, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(a, b)
+        sse = ops.sse(a, b)
+        return (sse / a.numel()).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = ops.diff_scale(a, b, 2.0 / a.numel(), g).to(a.dtype)
+        if ctx.needs_input_grad[1]:
+            gb = ops.diff_scale(b, a, 2.0 / a.numel(), g).to(b.dtype)
+        return ga, gb
+
+
+def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _MSE.apply(a, b)
+
+
+class _Normalize(Function):
+    """F.normalize(v, dim=1, eps=1e-12) in the oracle's summation order."""
+
+    @staticmethod
+    def forward(ctx, v: torch.Tensor, eps: float) -> torch.Tensor:
+        ctx.save_for_backward(v)
+        ctx.eps = eps
+        return ops.normalize_rows(_as2d(v), eps).view(v.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        gv = ops.normalize_rows_bwd(_as2d(v), _as2d(g), ctx.eps).view(v.shape).to(v.dtype)
+        return gv, None
+
+
+def normalize(v: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    return _Normalize.apply(v, eps)
+
+
+class _STE(Function):
+    """x + (z - x).detach() (vq/tasks/image_tokenization/models/quantizers/utils/ste.py:9-10)."""
+
+    @staticmethod
+    def forward(ctx, z: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        ctx.xdtype = x.dtype
+        return ops.ste(x, z)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g.to(ctx.xdtype)
+
+
+def ste(z: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    return _STE.apply(z, x)
+
+
+class _FusedDecodeLoss(Function):
+    """decode + straight-through + both MSE terms in one pass:
+        z = W[idx];  z_ste = x + sg(z - x);  m_cb = mse(z, sg x);  m_cm = mse(sg z, x)   (same value, two graph nodes)
+    Backward is one fused kernel (vqhip_vq_backward): m_cb's gradient flows to W, m_cm's and z_ste's to x."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor):
+        _, z_ste, sse = ops.gather_ste_loss(x, weight, idx, need_z=False, need_ste=True, need_sse=True)
+        ctx.save_for_backward(x, weight, idx)
+        m = (sse / x.numel()).float().reshape(())
+        return z_ste.view(x.shape), m, m.clone()
+
+    @staticmethod
+    def backward(ctx, g_zste, g_cb, g_cm):
+        x, weight, idx = ctx.saved_tensors
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx, gw = ops.vq_backward(x, weight, idx, g_zste, g_cb, g_cm, need_x, need_w)
+        if gx is not None:
+            gx = gx.view(x.shape).to(x.dtype)
+        return gx, gw, None
+
+
+def fused_decode_loss(x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor):
+    """Returns (z_ste, m_cb, m_cm): the straight-through output and the codebook / commitment MSE values."""
+    return _FusedDecodeLoss.apply(x, weight, idx)

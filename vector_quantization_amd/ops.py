@@ -216,21 +216,104 @@ def gather_rows(x: torch.Tensor, row_idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vqkd_update_(w: torch.Tensor, hist64: torch.Tensor, sums: torch.Tensor, decay: float) -> torch.Tensor:
-    """In-place VQ-KD codebook update on a contiguous fp32 [K, D] tensor."""
+def vqkd_update_(w: torch.Tensor, hist64: torch.Tensor, sums: torch.Tensor, decay: float, mode: str = 'full') -> torch.Tensor:
+    """In-place VQ-KD codebook update on a contiguous fp32 [K, D] tensor (mode 'centroid': k-means centroids only)."""
     _require_cuda(w, hist64, sums)
     assert w.dtype == torch.float32 and w.is_contiguous() and hist64.dtype == torch.int64
     K, D = w.shape
     check(_lib.lib().vqhip_vqkd_update(_ptr(w), _ptr(hist64.contiguous()), _ptr(sums.contiguous()), K, D, decay,
-                                       _stream()), 'vqhip_vqkd_update')
+                                       1 if mode == 'centroid' else 0, _stream()), 'vqhip_vqkd_update')
     return w
 
 
-def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: torch.Tensor, numel: int, anchors: torch.Tensor,
-                ema_decay: float, eps: float) -> None:
-    """In-place CVQ-VAE probability + codebook update."""
-    _require_cuda(w, p, hist64, anchors)
+def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: Optional[torch.Tensor], numel, anchors: Optional[torch.Tensor],
+                ema_decay: float, eps: float, stage: int = 3) -> None:
+    """In-place CVQ-VAE update; stage 1 = probability only, 2 = codebook only (from the current p), 3 = both.
+    ``numel`` is an int or a device int64 scalar tensor."""
+    _require_cuda(w, p)
     assert w.dtype == torch.float32 and w.is_contiguous() and p.dtype == torch.float32 and p.is_contiguous()
     K, D = w.shape
-    check(_lib.lib().vqhip_cvq_update(_ptr(w), _ptr(p), _ptr(hist64.contiguous()), int(numel),
-                                      _ptr(anchors.contiguous()), K, D, ema_decay, eps, _stream()), 'vqhip_cvq_update')
+    numel_dev = numel if isinstance(numel, torch.Tensor) else None
+    if numel_dev is not None:
+        numel_dev = numel_dev.to(torch.int64).reshape(1)
+        assert numel_dev.is_cuda
+    hist64 = None if hist64 is None else hist64.contiguous()
+    anchors = None if anchors is None else anchors.contiguous()
+    check(_lib.lib().vqhip_cvq_update(_ptr(w), _ptr(p), _ptr(hist64), 0 if (numel_dev is not None or numel is None)
+                                      else int(numel), _ptr(numel_dev), _ptr(anchors), K, D, ema_decay, eps, stage,
+                                      _stream()), 'vqhip_cvq_update')
+
+
+def _any(t: torch.Tensor):
+    """Flat contiguous fp32/bf16 view + dtype code for the elementwise kernels."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    t = t.contiguous()
+    return t, (_lib.DTYPE_F32 if t.dtype == torch.float32 else _lib.DTYPE_BF16)
+
+
+def sse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """sum((a-b)^2) as a float64[1] device tensor."""
+    _require_cuda(a, b)
+    a, da = _any(a)
+    b, db = _any(b)
+    assert a.numel() == b.numel()
+    out = torch.zeros(1, dtype=torch.float64, device=a.device)
+    check(_lib.lib().vqhip_diff(_ptr(a), da, _ptr(b), db, a.numel(), 1.0, None, None, _ptr(out), _stream()),
+          'vqhip_diff')
+    return out
+
+
+def diff_scale(a: torch.Tensor, b: torch.Tensor, scale: float, scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(a - b) * scale [* scale_dev] as fp32 (the MSE backward; scale_dev = upstream scalar gradient on the device)."""
+    _require_cuda(a, b)
+    shape = a.shape
+    a, da = _any(a)
+    b, db = _any(b)
+    out = torch.empty(a.numel(), dtype=torch.float32, device=a.device)
+    if scale_dev is not None:
+        scale_dev = scale_dev.detach().float().reshape(1).contiguous()
+    check(_lib.lib().vqhip_diff(_ptr(a), da, _ptr(b), db, a.numel(), float(scale), _ptr(scale_dev), _ptr(out), None,
+                                _stream()), 'vqhip_diff')
+    return out.view(shape)
+
+
+def ste(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """x + (z - x) as fp32."""
+    _require_cuda(x, z)
+    shape = z.shape
+    x, dx = _any(x)
+    z = z.float().contiguous()
+    out = torch.empty(z.numel(), dtype=torch.float32, device=z.device)
+    check(_lib.lib().vqhip_ste(_ptr(x), dx, _ptr(z), z.numel(), _ptr(out), _stream()), 'vqhip_ste')
+    return out.view(shape)
+
+
+def normalize_rows_bwd(v: torch.Tensor, g: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    _require_cuda(v, g)
+    v, dt = _latents(v)
+    g = g.float().contiguous()
+    out = torch.empty(v.shape, dtype=torch.float32, device=v.device)
+    check(_lib.lib().vqhip_normalize_rows_bwd(_ptr(v), dt, _ptr(g), v.shape[0], v.shape[1], eps, _ptr(out), _stream()),
+          'vqhip_normalize_rows_bwd')
+    return out
+
+
+def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Optional[torch.Tensor],
+                g_cb: Optional[torch.Tensor], g_cm: Optional[torch.Tensor], need_x: bool, need_w: bool):
+    """Fused backward of the quantizer forward; returns (grad_x fp32 or None, grad_w fp32 [K, D] or None)."""
+    _require_cuda(x, e, idx)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    idx = idx.reshape(-1).contiguous()
+    N, D = x.shape
+    gx = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_x else None
+    gw = torch.zeros(e.shape, dtype=torch.float32, device=x.device) if need_w else None
+    if gx is None and gw is None:
+        return None, None
+    if g_zste is not None:
+        g_zste = g_zste.float().contiguous()
+    scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cb, g_cm)]
+    check(_lib.lib().vqhip_vq_backward(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
+                                       _ptr(gx), _ptr(gw), _stream()), 'vqhip_vq_backward')
+    return gx, gw

@@ -1,0 +1,16 @@
+from .anchors import BaseAnchor, CachedAnchor, MultinomialAnchor, NearestAnchor
+from .base import BaseQuantizer, ModuleDict, build_module_dict, get_memo
+from .callbacks import (BaseCallback, ComposedCallback, CVQVAECallback, LazyInitWeightsMixin, NormalizeCallback,
+                        QuantizerHolderMixin, UpdateMixin, VQKDCallback)
+from .distances import BaseDistance, CosineDistance, L2Distance, LazyDistance, as_distance_tensor
+from .losses import BaseLoss, CodebookLoss, CommitmentLoss, EntropyLoss, VQGANLoss
+from .statistics import QuantStatistics
+from .vector_quantizer import VectorQuantizer, VQGANQuantizer, VQKDQuantizer
+
+__all__ = [
+    'BaseAnchor', 'CachedAnchor', 'MultinomialAnchor', 'NearestAnchor', 'BaseQuantizer', 'ModuleDict',
+    'build_module_dict', 'get_memo', 'BaseCallback', 'ComposedCallback', 'CVQVAECallback', 'LazyInitWeightsMixin',
+    'NormalizeCallback', 'QuantizerHolderMixin', 'UpdateMixin', 'VQKDCallback', 'BaseDistance', 'CosineDistance',
+    'L2Distance', 'LazyDistance', 'as_distance_tensor', 'BaseLoss', 'CodebookLoss', 'CommitmentLoss', 'EntropyLoss',
+    'VQGANLoss', 'QuantStatistics', 'VectorQuantizer', 'VQGANQuantizer', 'VQKDQuantizer',
+]

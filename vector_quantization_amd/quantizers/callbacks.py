@@ -1,0 +1,328 @@
+"""Quantizer callbacks — mirror of
+  vq/tasks/image_tokenization/models/quantizers/callbacks/{base,composed,lazy_init_weights}.py,
+  .../quantizers/utils/quantizer_holder.py:15-27,
+  vq/algorithms/vq/callbacks/{normalize,update}.py,
+  vq/algorithms/vqkd/quantizers/callbacks.py:26-129 and vq/algorithms/cvqvae/quantizer_callback.py:25-105.
+Hook names, order and side effects follow the reference; the arithmetic runs in libvqhip."""
+from __future__ import annotations
+
+import random
+from abc import abstractmethod
+from typing import TYPE_CHECKING, Iterable, Mapping
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
+from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
+from ..utils import EMA, PriorityQueue, Store, all_reduce_statistics, get_rank, get_world_size, is_sync
+from .base import BaseQuantizer, Memo
+from .statistics import QuantStatistics
+
+if TYPE_CHECKING:
+    from .vector_quantizer import VectorQuantizer
+
+
+class QuantizerHolderMixin:
+    """todd.utils.HolderMixin[BaseQuantizer]: a non-Module holder bound to its quantizer."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__()
+        self._instance = None
+
+    def bind(self, instance: BaseQuantizer) -> None:
+        self._instance = instance
+
+    @property
+    def quantizer(self) -> BaseQuantizer:
+        return self._instance
+
+    @property
+    def vector_quantizer(self) -> 'VectorQuantizer':
+        from .vector_quantizer import VectorQuantizer
+        assert isinstance(self.quantizer, VectorQuantizer)
+        return self.quantizer
+
+
+class BaseCallback(QuantizerHolderMixin):
+
+    def before_init_weights(self, config: Config) -> None:
+        pass
+
+    def after_init_weights(self, config: Config, recursive: bool) -> bool:
+        return recursive
+
+    def before_encode(self, x: torch.Tensor, memo: Memo) -> torch.Tensor:
+        return x
+
+    def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        return quant
+
+    def before_decode(self, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        return quant
+
+    def after_decode(self, z: torch.Tensor, memo: Memo) -> torch.Tensor:
+        return z
+
+    def before_loss(self, z: torch.Tensor, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor]:
+        return z, x
+
+    def after_loss(self, loss: torch.Tensor, memo: Memo) -> torch.Tensor:
+        return loss
+
+
+_DECODE_LOSS_HOOKS = ('before_decode', 'after_decode', 'before_loss', 'after_loss')
+
+
+@VQITQuantizerCallbackRegistry.register_()
+class ComposedCallback(BuildPreHookMixin, BaseCallback):
+
+    def __init__(self, *args, priorities: Iterable[Mapping[str, int]], callbacks: Iterable[BaseCallback], **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._priority_queue = PriorityQueue(priorities, callbacks)
+
+    @classmethod
+    def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config = super().build_pre_hook(config, registry, item)
+        callbacks = [Config(c) if isinstance(c, dict) else c for c in config.callbacks]
+        config.priorities = [c.pop('priority', dict()) if isinstance(c, dict) else dict() for c in callbacks]
+        config.callbacks = [registry.build_or_return(c) for c in callbacks]
+        return config
+
+    @property
+    def callbacks(self) -> list:
+        return self._priority_queue('bind')
+
+    def overrides_decode_or_loss(self) -> bool:
+        """True when some callback customises a decode/loss hook (the fused decode+loss path must then be skipped)."""
+        for cb in self.callbacks:
+            for name in _DECODE_LOSS_HOOKS:
+                if getattr(type(cb), name) is not getattr(BaseCallback, name):
+                    return True
+        return False
+
+    def bind(self, *args, **kwargs) -> None:
+        super().bind(*args, **kwargs)
+        for callback in self._priority_queue('bind'):
+            callback.bind(*args, **kwargs)
+
+    def before_init_weights(self, *args, **kwargs) -> None:
+        super().before_init_weights(*args, **kwargs)
+        for callback in self._priority_queue('before_init_weights'):
+            callback.before_init_weights(*args, **kwargs)
+
+    def after_init_weights(self, config: Config, recursive: bool) -> bool:
+        recursive = super().after_init_weights(config, recursive)
+        for callback in self._priority_queue('after_init_weights'):
+            recursive = callback.after_init_weights(config, recursive)
+        return recursive
+
+    def before_encode(self, x: torch.Tensor, memo: Memo) -> torch.Tensor:
+        x = super().before_encode(x, memo)
+        for callback in self._priority_queue('before_encode'):
+            x = callback.before_encode(x, memo)
+        return x
+
+    def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        quant = super().after_encode(x, quant, memo)
+        for callback in self._priority_queue('after_encode'):
+            quant = callback.after_encode(x, quant, memo)
+        return quant
+
+    def before_decode(self, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        quant = super().before_decode(quant, memo)
+        for callback in self._priority_queue('before_decode'):
+            quant = callback.before_decode(quant, memo)
+        return quant
+
+    def after_decode(self, z: torch.Tensor, memo: Memo) -> torch.Tensor:
+        z = super().after_decode(z, memo)
+        for callback in self._priority_queue('after_decode'):
+            z = callback.after_decode(z, memo)
+        return z
+
+    def before_loss(self, z: torch.Tensor, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor]:
+        z, x = super().before_loss(z, x, memo)
+        for callback in self._priority_queue('before_loss'):
+            z, x = callback.before_loss(z, x, memo)
+        return z, x
+
+    def after_loss(self, loss: torch.Tensor, memo: Memo) -> torch.Tensor:
+        loss = super().after_loss(loss, memo)
+        for callback in self._priority_queue('after_loss'):
+            loss = callback.after_loss(loss, memo)
+        return loss
+
+
+class LazyInitWeightsMixin(BaseCallback):
+
+    @abstractmethod
+    def lazy_init_weights(self, config: Config, x: torch.Tensor, memo: Memo) -> None:
+        pass
+
+    def before_init_weights(self, config: Config) -> None:
+        super().before_init_weights(config)
+        lazy_init_weights = config.pop('lazy_init_weights', Config())
+
+        def forward_pre_hook(module: BaseQuantizer, args: tuple[torch.Tensor, Memo]) -> None:
+            x, memo = args
+            self.lazy_init_weights(lazy_init_weights, x, memo)
+            handle.remove()
+
+        handle = self.quantizer.register_forward_pre_hook(forward_pre_hook)
+
+
+class UpdateMixin(BuildPreHookMixin, BaseCallback):
+
+    def __init__(self, *args, ema: EMA | None = None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        if ema is not None:
+            self._ema = ema
+
+    @classmethod
+    def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config = super().build_pre_hook(config, registry, item)
+        if (ema := config.get('ema')) is not None:
+            config.ema = EMA(**ema)
+        return config
+
+    @property
+    def with_ema(self) -> bool:
+        return hasattr(self, '_ema')
+
+    def _update_embedding(self, e: torch.Tensor) -> None:
+        if Store.DRY_RUN:
+            assert is_sync(e)
+        self.vector_quantizer.embedding.weight.data = e      # rebinds the storage, like callbacks/update.py:56
+
+
+@VQITQuantizerCallbackRegistry.register_()
+class NormalizeCallback(UpdateMixin, BaseCallback):
+
+    def before_encode(self, x: torch.Tensor, memo: Memo) -> torch.Tensor:
+        x = super().before_encode(x, memo)
+        from .. import functional as VF
+        x = VF.normalize(x)                                   # F.normalize(x): differentiable w.r.t. the encoder
+        e = self.vector_quantizer.embedding.weight
+        e = ops.normalize_rows(e.detach())
+        self._update_embedding(e)
+        return x
+
+
+def distributed_cat(x: torch.Tensor) -> torch.Tensor:
+    """vqkd/quantizers/callbacks.py:26-35: gather the first batch on rank 0."""
+    if get_world_size() <= 1:
+        return x
+    if get_rank() > 0:
+        dist.gather(x)
+        return x.new_empty(0)
+    gather_list = [torch.zeros_like(x) for _ in range(get_world_size())]
+    dist.gather(x, gather_list)
+    return torch.cat(gather_list)
+
+
+@VQITQuantizerCallbackRegistry.register_()
+class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
+
+    def _statistics(self, x: torch.Tensor, quant: torch.Tensor, sync: bool):
+        """Histogram + per-code sums of the assigned (already normalised) latents, all-reduced when syncing."""
+        K = self.vector_quantizer.codebook_size
+        hist = ops.hist(quant, K).to(torch.int64)
+        sums = ops.scatter_add_rows(x, quant, K)
+        if sync and get_world_size() > 1:
+            hist, _, sums = all_reduce_statistics(hist, quant.numel(), sums)
+        return hist, sums
+
+    def _kmeans(self, x: torch.Tensor, quant: torch.Tensor, sync: bool) -> torch.Tensor:
+        """callbacks.py:44-71 — centroids, old row kept where a code received no token."""
+        e = self.vector_quantizer.embeddings
+        hist, sums = self._statistics(x, quant, sync)
+        ops.vqkd_update_(e, hist, sums, 0.0, mode='centroid')
+        return e
+
+    def _update_embedding(self, e: torch.Tensor) -> None:
+        e = ops.normalize_rows(e)
+        return super()._update_embedding(e)
+
+    def lazy_init_weights(self, config: Config, x: torch.Tensor, memo: Memo) -> None:
+        if not self.quantizer.training:
+            return
+        x = distributed_cat(x.detach())
+        e = self.vector_quantizer.embeddings
+        iters = config.get('iters', 10)
+        if get_rank() > 0:
+            e = torch.empty_like(e)
+        elif x.shape[0] < e.shape[0]:
+            e[:x.shape[0]] = x
+        else:
+            x = ops.normalize_rows(x)
+            # (the reference offloads to the CPU when N*K > 2^30 because it materialises d[N, K]; the fused
+            #  argmin never forms the matrix, so the Lloyd iterations stay on the device)
+            indices = random.sample(range(x.shape[0]), e.shape[0])
+            e = ops.gather_rows(x, torch.as_tensor(indices, device=x.device))
+            for _ in range(iters):
+                self._update_embedding(e)
+                quant, _ = self.vector_quantizer._encode(x, Config())
+                e = self._kmeans(x, quant, False)
+        if get_world_size() > 1:
+            dist.broadcast(e, 0)
+        self._update_embedding(e)
+
+    def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        quant = super().after_encode(x, quant, memo)
+        if not self.quantizer.training:
+            return quant
+        x = ops.normalize_rows(x.detach())                     # callbacks.py:124
+        hist, sums = self._statistics(x, quant, True)          # :125 (hist + sums, two collectives at most)
+        e = self.vector_quantizer.embeddings                   # clone: the update writes a fresh tensor
+        ops.vqkd_update_(e, hist, sums, self._ema.decay)       # :66-70,126-127 and the final normalise (:73-75)
+        UpdateMixin._update_embedding(self, e)
+        return quant
+
+
+@VQITQuantizerCallbackRegistry.register_()
+class CVQVAECallback(UpdateMixin, BaseCallback):
+
+    def __init__(self, *args, anchor, eps: float = 1e-3, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._anchor = anchor
+        self._eps = eps
+
+    @classmethod
+    def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config = super().build_pre_hook(config, registry, item)
+        config.anchor = AnchorRegistry.build_or_return(config.anchor)
+        return config
+
+    def before_init_weights(self, config: Config) -> None:
+        super().before_init_weights(config)
+        if not self.quantizer.training:
+            return
+        p = torch.zeros(self.quantizer.codebook_size, device=self.vector_quantizer.embedding.weight.device)
+        self._update_probability(p)
+
+    @property
+    def probability(self) -> torch.Tensor:
+        return self.quantizer.get_buffer('_probability')
+
+    def _update_probability(self, value: torch.Tensor) -> None:
+        self.quantizer.register_buffer('_probability', value)
+
+    def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
+        quant = super().after_encode(x, quant, memo)
+        if not self.quantizer.training:
+            return quant
+        K = self.quantizer.codebook_size
+        e = self.quantizer.embeddings
+        d = memo['encode']['distance']
+        stats = QuantStatistics(quant=quant, codebook_size=K, sync=True, hist=memo['encode'].get('hist'))
+        hist, numel = stats.bin_count(), stats._statistics()[1]
+        p = self.probability.to(device=e.device, dtype=torch.float32).clone()
+        ops.cvq_update_(e, p, hist, numel, None, self._ema.decay, self._eps, stage=1)      # p = ema(p, hist/numel)
+        self._update_probability(p)
+        anchors, memo = self._anchor(x.detach(), e, d, quant, p, memo=memo)
+        # decay = 1 - exp(-p*K*10/(1-ema.decay) - eps); e = e*decay + anchors*(1-decay)
+        ops.cvq_update_(e, p, None, None, anchors, self._ema.decay, self._eps, stage=2)
+        self._update_embedding(e)
+        return quant

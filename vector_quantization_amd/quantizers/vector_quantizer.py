@@ -1,0 +1,174 @@
+"""VectorQuantizer / VQGANQuantizer / VQKDQuantizer — mirror of vq/algorithms/vq/quantizers.py:19-117,
+vq/algorithms/vqgan/quantizer.py:11-21 and vq/algorithms/vqkd/quantizers/base.py:11-15."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import functional as VF
+from .. import ops
+from ..config import Config, Item, RegistryMeta
+from ..registries import InitRegistry, ModelRegistry, VQITQuantizerDistanceRegistry, VQITQuantizerRegistry
+from .base import BaseQuantizer, Memo, get_memo
+from .distances import BaseDistance, LazyDistance
+from .losses import CodebookLoss, CommitmentLoss, VQGANLoss
+
+
+@InitRegistry.register_('uniform_')
+def _uniform_init(a: float = 0.0, b: float = 1.0):
+    return lambda w: nn.init.uniform_(w, a, b)
+
+
+@InitRegistry.register_('normal_')
+def _normal_init(mean: float = 0.0, std: float = 1.0):
+    return lambda w: nn.init.normal_(w, mean, std)
+
+
+@VQITQuantizerRegistry.register_()
+class VectorQuantizer(BaseQuantizer):
+
+    def __init__(self, *args, embedding: nn.Embedding, distance: BaseDistance, fused: bool = True,
+                 cache_codebook: bool = False, **kwargs) -> None:
+        """``fused`` / ``cache_codebook`` are extensions (defaults keep the reference semantics):
+        fused          — decode + STE + plain MSE losses in one kernel when no callback customises decode/loss;
+        cache_codebook — reuse the prepared codebook image while ``weight`` is bit-for-bit unchanged
+                         (opt-in for frozen-codebook tokenisation; callers that mutate the weight must call
+                         ``invalidate_codebook()``)."""
+        super().__init__(*args, **kwargs)
+        self._embedding = embedding
+        self._distance = distance
+        self._fused = fused
+        self._cache_codebook = cache_codebook
+        self._prepared: Optional[ops.PreparedCodebook] = None
+        self._prepared_key = None
+
+    @classmethod
+    def embedding_build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config.embedding = ModelRegistry.build_or_return(config.embedding)
+        return config
+
+    @classmethod
+    def distance_build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config.distance = VQITQuantizerDistanceRegistry.build_or_return(config.distance)
+        return config
+
+    @classmethod
+    def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
+        config = super().build_pre_hook(config, registry, item)
+        config = cls.embedding_build_pre_hook(config, registry, item)
+        config = cls.distance_build_pre_hook(config, registry, item)
+        return config
+
+    @property
+    def embedding(self) -> nn.Embedding:
+        return self._embedding
+
+    @property
+    def distance(self) -> BaseDistance:
+        return self._distance
+
+    @property
+    def embedding_dim(self) -> int:
+        return self._embedding.embedding_dim
+
+    @property
+    def codebook_size(self) -> int:
+        return self._embedding.num_embeddings
+
+    @property
+    def embeddings(self) -> torch.Tensor:
+        return self._embedding.weight.detach().clone()
+
+    def _init_weights(self, config: Config) -> bool:
+        config = Config(config)
+        if 'type' not in config:            # nothing configured: keep nn.Embedding's own initialisation
+            return False
+        func = InitRegistry.resolve(config.pop('type'))(**config)
+        with torch.no_grad():
+            func(self._embedding.weight)
+        self.invalidate_codebook()
+        return False
+
+    # ---- encode: fused distance + argmin -------------------------------------------------------------------------
+    def invalidate_codebook(self) -> None:
+        self._prepared = None
+        self._prepared_key = None
+
+    def _prepare(self, w: torch.Tensor) -> ops.PreparedCodebook:
+        if not self._cache_codebook:
+            return self._distance.prepare(w)
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        if self._prepared is None or self._prepared_key != key:
+            self._prepared = self._distance.prepare(w)
+            self._prepared_key = key
+        return self._prepared
+
+    def _encode(self, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, Memo]:
+        """quantizers.py:92-100.  The reference clones the weight, materialises d[N, K] and takes argmin; here the
+        weight is read in place, memo['distance'] is lazy, and the code-hit histogram falls out of the epilogue."""
+        w = self._embedding.weight.detach()
+        shape = x.shape[:-1]
+        x2 = x.detach().reshape(-1, x.shape[-1])
+        hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
+        quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w))
+        memo['distance'] = LazyDistance(self._distance, x2, w)
+        memo['hist'] = hist
+        return quant.reshape(shape), memo
+
+    def _decode(self, quant: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, Memo]:
+        z = VF.embedding(self._embedding.weight, quant)
+        return z, memo
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def _fusable(self) -> bool:
+        if not self._fused or self._callbacks.overrides_decode_or_loss():
+            return False
+        if type(self)._decode is not VectorQuantizer._decode or type(self)._loss is not BaseQuantizer._loss:
+            return False
+        for loss in self._losses.values():
+            if not (isinstance(loss, (VQGANLoss, CodebookLoss, CommitmentLoss)) and loss.plain):
+                return False
+        return True
+
+    def forward(self, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:
+        """quantizers.py:110-117 (BaseQuantizer.forward, then ste(z, memo['x'])).  When nothing customises
+        decode/loss the gather, the STE expression and the MSE sums are one kernel with one fused backward."""
+        if not self._fusable() or x.dim() != 2:
+            z, loss, memo = super().forward(x, memo)
+            z = VF.ste(z, memo['x'])
+            return z, loss, memo
+        x, quant, memo = self.encode(x, memo)
+        memo.update(x=x, quant=quant)
+        z_ste, m_cb, m_cm = VF.fused_decode_loss(x, self._embedding.weight, quant)
+        memo['decode'] = get_memo(memo, 'decode')
+        losses = {}
+        for name, loss in self._losses.items():
+            if isinstance(loss, VQGANLoss):
+                losses[name] = m_cb + loss.beta * m_cm
+            elif isinstance(loss, CodebookLoss):
+                losses[name] = m_cb
+            else:
+                losses[name] = m_cm
+        loss_memo = get_memo(memo, 'loss')
+        loss_memo.update(losses)
+        memo['loss'] = loss_memo
+        loss = sum(losses.values(), x.new_zeros([], dtype=torch.float32))
+        return z_ste, loss, memo
+
+
+@VQITQuantizerRegistry.register_()
+class VQGANQuantizer(VectorQuantizer):
+
+    def _init_weights(self, config: Config) -> bool:
+        if Config(config) == Config(type='vqgan'):
+            config = Config(type='uniform_', a=-1.0 / self.codebook_size, b=1.0 / self.codebook_size)
+        return super()._init_weights(config)
+
+
+@VQITQuantizerRegistry.register_()
+class VQKDQuantizer(VectorQuantizer):
+
+    def _init_weights(self, config: Config) -> bool:
+        return False

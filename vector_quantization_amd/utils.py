@@ -1,0 +1,105 @@
+"""Small host-side helpers standing in for the todd utilities the path uses:
+EMA / ema, PriorityQueue, Store flags, rank helpers, is_sync, and the packed statistics all-reduce."""
+from __future__ import annotations
+
+import os
+from typing import Generic, Iterable, Mapping, Optional, TypeVar
+
+import torch
+import torch.distributed as dist
+
+T = TypeVar('T')
+
+
+# ---- todd.utils.ema / EMA (definition fixed in SURVEY.md §8c: a*decay + b*(1-decay), default decay 0.99) ----
+
+def ema(a: torch.Tensor, b: torch.Tensor, decay) -> torch.Tensor:
+    return a * decay + b * (1 - decay)
+
+
+class EMA:
+    def __init__(self, *args, decay: float = 0.99, **kwargs) -> None:
+        self._decay = float(decay)
+
+    @property
+    def decay(self) -> float:
+        return self._decay
+
+    def __call__(self, a: Optional[torch.Tensor], b: torch.Tensor) -> torch.Tensor:
+        if a is None:
+            return b
+        return ema(a, b, self._decay)
+
+
+# ---- todd.runners.utils.PriorityQueue: per-hook ordering of callbacks (ascending priority, stable) ----
+
+class PriorityQueue(Generic[T]):
+    def __init__(self, priorities: Iterable[Mapping[str, int]], items: Iterable[T]) -> None:
+        self._priorities = [dict(p) for p in priorities]
+        self._items = list(items)
+        assert len(self._priorities) == len(self._items)
+
+    def __call__(self, key: str) -> list:
+        order = sorted(range(len(self._items)), key=lambda i: (self._priorities[i].get(key, 0), i))
+        return [self._items[i] for i in order]
+
+    def __len__(self) -> int:
+        return len(self._items)
+
+
+# ---- todd.Store flags (vq/utils/stores.py:8-10): environment-backed booleans ----
+
+class _Store:
+    @property
+    def DRY_RUN(self) -> bool:  # noqa: N802
+        return bool(os.environ.get('DRY_RUN'))
+
+
+Store = _Store()
+
+
+# ---- rank helpers (todd.patches.torch.get_rank / get_world_size) ----
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_sync(t: torch.Tensor) -> bool:
+    """True when ``t`` is bit-identical on every rank (todd.utils.is_sync; the reference's only
+    distributed-correctness assert: callbacks/update.py:54-55, cvqvae/anchors.py:52-53,62-63)."""
+    if get_world_size() <= 1:
+        return True
+    flat = t.detach().contiguous().view(torch.uint8).reshape(-1) if t.dtype != torch.bool else t.reshape(-1)
+    lo, hi = flat.clone().to(torch.int32), flat.clone().to(torch.int32)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+# ---- one exchange step of the codebook update ----
+
+def all_reduce_statistics(hist: torch.Tensor, numel: Optional[int] = None, sums: Optional[torch.Tensor] = None):
+    """SUM-all-reduce the per-step codebook statistics with at most two collectives:
+    int64 [K+1] = histogram ‖ token count (exact), and fp32 [K*D] = per-code sums (centroids / anchors).
+    Replaces the reference's separate all_reduce calls (vq/algorithms/vq/utils.py:35 twice,
+    vqkd/quantizers/callbacks.py:63-64, cvqvae/anchors.py:65-67).  No-op for a single rank.
+    Returns (hist int64[K], numel, sums); numel is a python int for one rank and a device int64 scalar tensor after
+    an all-reduce (no host synchronisation)."""
+    K = hist.numel()
+    if numel is None:
+        numel = int(hist.sum().item()) if get_world_size() <= 1 else None
+    if get_world_size() <= 1:
+        return hist.to(torch.int64), numel, sums
+    packed = torch.empty(K + 1, dtype=torch.int64, device=hist.device)
+    packed[:K] = hist
+    packed[K] = numel if numel is not None else hist.sum()
+    dist.all_reduce(packed)
+    if sums is not None:
+        if not sums.is_contiguous():
+            sums = sums.contiguous()
+        dist.all_reduce(sums)
+    return packed[:K], packed[K], sums
