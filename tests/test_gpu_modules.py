@@ -53,7 +53,7 @@ def test_vqgan_forward_backward(fused):
     N, K, D = 1024, 1024, 256
     x, w = synth.make_inputs('normal', 3407, N, K, D)
     q = build(vqgan_cfg(K, D, fused=fused), train=True, init=dict(type='vqgan'))
-    assert float(q.embedding.weight.abs().max()) <= 1.0 / K + 1e-9           # VQGANQuantizer init: U(-1/K, 1/K)
+    assert float(q.embedding.weight.detach().abs().max()) <= 1.0 / K + 1e-9           # VQGANQuantizer init: U(-1/K, 1/K)
     set_weight(q, w)
     xd = torch.from_numpy(x).cuda().requires_grad_(True)
     memo = {}
@@ -90,7 +90,7 @@ def test_bf16_latents_under_autocast_semantics():
     assert x2 is xd and torch.equal(quant, memo['quant'])
     zz, _ = q.decode(quant.reshape(2, 16, 16), {})
     assert zz.shape == (2, 16, 16, D)
-    np.testing.assert_array_equal(zz.reshape(-1, D).cpu().numpy(), w[gz['quant'].astype(np.int64)])
+    np.testing.assert_array_equal(zz.detach().reshape(-1, D).cpu().numpy(), w[gz['quant'].astype(np.int64)])
 
 
 def test_normalize_callback_llamagen_shape():
