@@ -1,0 +1,91 @@
+"""Host-side logic that needs no GPU: config / registry shim, building the reference's quantizer configs, hook
+ordering, state-dict layout, and the guarantee that the product refuses to run without the HIP path."""
+import pytest
+import torch
+
+from vector_quantization_amd import (Config, ModelRegistry, VQITQuantizerCallbackRegistry, VQITQuantizerLossRegistry,
+                                     VQITQuantizerRegistry, _lib, build_quantizer)
+from vector_quantization_amd import quantizers as Q
+
+EMB = 'torch_nn_modules_sparse_Embedding'
+
+
+def test_config_and_registry():
+    c = Config(a=dict(b=[dict(c=1)]), d=2)
+    assert c.a.b[0].c == 1 and c.get_config('missing') == {} and c.get_config('a').b[0].c == 1
+    c.e = dict(f=3)
+    assert isinstance(c.e, Config) and c.e.f == 3
+    emb = ModelRegistry.build(dict(type=EMB, num_embeddings=7, embedding_dim=3))
+    assert isinstance(emb, torch.nn.Embedding) and emb.weight.shape == (7, 3)
+    assert VQITQuantizerRegistry.resolve('VectorQuantizer') is Q.VectorQuantizer
+    assert VQITQuantizerRegistry.resolve('VQITQuantizerRegistry.VQGANQuantizer') is Q.VQGANQuantizer
+    assert VQITQuantizerLossRegistry.resolve('VQGANLoss') is Q.VQGANLoss
+    assert VQITQuantizerCallbackRegistry.resolve('CVQVAECallback') is Q.CVQVAECallback
+    with pytest.raises(KeyError):
+        VQITQuantizerRegistry.resolve('NoSuchQuantizer')
+    with pytest.raises(KeyError):                              # same name twice without force
+        VQITQuantizerRegistry.register_()(Q.VectorQuantizer)
+
+
+def _vqgan(K=64, D=16, **extra):
+    return build_quantizer(dict(type='VQGANQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D),
+                                distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss')),
+                                **extra))
+
+
+def test_build_reference_configs_and_state_dict():
+    q = _vqgan()
+    assert isinstance(q, Q.VQGANQuantizer) and q.codebook_size == 64 and q.embedding_dim == 16
+    assert isinstance(q.distance, Q.L2Distance) and isinstance(q.embedding, torch.nn.Embedding)
+    assert q._fusable()
+    q.init_weights(Config(type='vqgan'))
+    assert float(q.embedding.weight.detach().abs().max()) <= 1 / 64
+    assert q.embeddings.data_ptr() != q.embedding.weight.data_ptr()         # .embeddings is a clone
+    kd = build_quantizer(dict(type='VQKDQuantizer', embedding=dict(type=EMB, num_embeddings=32, embedding_dim=8),
+                              distance=dict(type='CosineDistance'), callbacks=[dict(type='VQKDCallback', ema=dict())],
+                              losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True)))))
+    assert not kd._fusable()                                                # norm=True MSE → general path
+    assert kd._callbacks.callbacks[0].with_ema and kd._callbacks.callbacks[0]._ema.decay == 0.99
+    assert set(kd.state_dict()) == {'_embedding.weight', '_losses.commitment_loss._weight._steps',
+                                    '_losses.commitment_loss._mse._weight._steps'}
+    kd.train()
+    kd.init_weights(Config())
+    assert len(kd._forward_pre_hooks) == 1                                  # k-means lazy init armed
+    cvq = _vqgan(callbacks=[dict(type='CVQVAECallback', ema=dict(decay=0.9), anchor=dict(type='NearestAnchor'))])
+    cvq.train()
+    cvq.init_weights(Config(type='vqgan'))
+    assert '_probability' in cvq.state_dict() and cvq.get_buffer('_probability').shape == (64,)
+    assert isinstance(cvq._callbacks.callbacks[0]._anchor, Q.NearestAnchor)
+
+
+def test_callback_priority_order():
+    calls = []
+
+    class Rec(Q.BaseCallback):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def before_encode(self, x, memo):
+            calls.append(self.name)
+            return x
+
+    cc = Q.ComposedCallback(priorities=[dict(before_encode=5), dict(), dict(before_encode=-3)],
+                            callbacks=[Rec('a'), Rec('b'), Rec('c')])
+    cc.before_encode(torch.zeros(1), {})
+    assert calls == ['c', 'b', 'a']
+    assert not cc.overrides_decode_or_loss()
+
+    class Dec(Q.BaseCallback):
+        def after_decode(self, z, memo):
+            return z
+
+    assert Q.ComposedCallback(priorities=[dict()], callbacks=[Dec()]).overrides_decode_or_loss()
+
+
+def test_no_cpu_fallback():
+    q = _vqgan()
+    with pytest.raises(_lib.VqhipError):
+        q(torch.zeros(4, 16), {})
+    with pytest.raises(_lib.VqhipError):
+        q.decode(torch.zeros(4, dtype=torch.long), {})
