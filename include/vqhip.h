@@ -140,8 +140,9 @@ int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R
                              void *stream);
 
 /* ---- diagnostics ------------------------------------------------------------------------------------
- * Copies the counters of the last vqhip_argmin on `ws` to out[4] (DEVICE int32): rows sent to the
- * whole-codebook fp32 pass, rows with more than one candidate (re-ranked exactly), reserved x2. */
+ * Copies the counters of the last vqhip_argmin on `ws` to out[4] (DEVICE int32): rows given a second proposal
+ * pass, rows with more than one identified candidate (re-ranked exactly), rows sent to the whole-codebook fp32
+ * pass, reserved. */
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream);
 
 /* Per-launch timing of the proposal (distance+argmin) kernel with HIP events recorded on the caller's stream

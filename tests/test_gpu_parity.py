@@ -94,7 +94,7 @@ def test_encode_matches_oracle_and_golden(ops, path):
     assert abs(mse - ref) <= 1e-5 * max(1.0, abs(ref))
     if spec['loss'] == 'vqgan' and not spec['normalize'] and spec['kind'] in EXACT_KINDS and not tiny:
         assert abs(1.25 * mse - float(z['loss'])) <= 1e-5 * max(1.0, abs(float(z['loss'])))
-    print(f"{spec['name']}: flagged={int(st[0])} multi={int(st[1])} of {spec['N']}")
+    print(f"{spec['name']}: rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])} of {spec['N']}")
 
 
 def test_bf16_latents_same_as_fp32_values(ops):
@@ -230,7 +230,7 @@ def test_full_size_properties(ops):
     rows = torch.arange(0, N, 257, device='cuda')
     xs = x[rows].float().cpu().numpy()
     np.testing.assert_array_equal(idx[rows].cpu().numpy(), co.l2_argmin(xs, w.cpu().numpy()))
-    print(f'full size: flagged={int(st[0])} multi={int(st[1])} of {N}')
+    print(f'full size: rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])} of {N}')
 
 
 def test_empty_and_ragged(ops):

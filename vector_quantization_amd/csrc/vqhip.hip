@@ -88,12 +88,11 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
 
 static int pick_slices(int64_t ntb, int64_t nstages) {
     if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
-    // Enough slices to put a workgroup on every CU.  Fewer, longer workgroups are faster for the proposal kernel
-    // itself (N=65536: 2 slices 1304 TF, 8 slices 1254 TF) but every slice also adds candidate groups, and fewer
-    // groups send more rows to the whole-codebook fp32 pass (measured 156 / 80 / 53 us at 2 / 4 / 8 slices), so
-    // large batches stay at 8 slices (one per XCD L2) for now.
+    // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
+    // record write-back (N=65536: 2 slices 1304 TF, 8 slices 1254 TF), re-read the token image fewer times and write
+    // fewer records.  (Rows whose candidates cannot all be identified get a second proposal pass, so the number of
+    // candidate groups no longer matters for speed.)
     int64_t want = (256 + ntb - 1) / ntb;
-    if (want < 8) want = 8;
     int ns = 1;
     while (ns < want && ns < VQ_MAX_SLICES) ns <<= 1;
     while (ns > 1 && ns > nstages) ns >>= 1;
@@ -236,36 +235,68 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
     if (rc) return rc;
     const int rgrid = (int)((N + 255) / 256);
-    int *multi_list = (int *)(w + W.off_multi);
-    refine_decide_kernel<<<rgrid, 256, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, flag_list,
-                                               multi_list, counters, keys);
+    int *rescan_list = flag_list;
+    int *multi_list = (int *)(w + W.off_multi), *exact_list = (int *)(w + W.off_exact);
+    float *thr = (float *)(w + W.off_thr);
+    int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
+    refine_decide_kernel<<<rgrid, 256, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, rescan_list,
+                                               multi_list, exact_list, counters, keys, thr, rescan_cnt);
     VQ_CHECK_LAUNCH("refine_decide_kernel");
+    // re-rank kernels: one wave per queued row; LDS per wave = (1 + VQ_RR_BATCH) rows of D floats
+    int wpb = 4;
+    size_t per_wave = (size_t)(VQ_RR_BATCH + 1) * ((D + 3) & ~3) * sizeof(float);
+    while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
+    const size_t rr_lds = per_wave * wpb;
     {
-        // re-rank: one wave per queued row; LDS per wave = (1 + 2*VQ_MAX_SLICES) rows of D floats
-        int wpb = 4;
-        size_t per_wave = (size_t)(VQ_RR_BATCH + 1) * ((D + 3) & ~3) * sizeof(float);
-        while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
-        if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
-        size_t lds = per_wave * wpb;
-        auto kern = (x_dtype == VQHIP_DTYPE_F32) ? refine_rerank_kernel<0> : refine_rerank_kernel<1>;
-        static size_t lds_set[2] = {0, 0};
-        if (lds > lds_set[x_dtype]) {
-            VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set[x_dtype] = lds;
-        }
-        kern<<<1024, wpb * 64, lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np, idx, hist, multi_list,
-                                        counters);
-        VQ_CHECK_LAUNCH("refine_rerank_kernel");
+        static size_t lds_set[4] = {0, 0, 0, 0};
+        const void *kerns[4] = {(const void *)refine_rerank_kernel<0, 0>, (const void *)refine_rerank_kernel<1, 0>,
+                                (const void *)refine_rerank_kernel<0, 1>, (const void *)refine_rerank_kernel<1, 1>};
+        for (int i = 0; i < 4; ++i)
+            if (rr_lds > lds_set[i]) {
+                VQ_HIP(hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_lds));
+                lds_set[i] = rr_lds;
+            }
     }
-    float *xn = xh2;     // xh2 is dead after the decision kernels: reuse it for the oracle-order |x|^2 of flagged rows
+    if (x_dtype == VQHIP_DTYPE_F32)
+        refine_rerank_kernel<0, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
+                                                                  nullptr, nullptr);
+    else
+        refine_rerank_kernel<1, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
+                                                                  nullptr, nullptr);
+    VQ_CHECK_LAUNCH("refine_rerank_kernel");
+    // second-chance proposals for rows with a possibly unidentified candidate, then their exact re-rank
+    {
+        const char *frag = c + L.off_frag;
+        switch (L.nstep) {
+#define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
+            VQ_RESCAN(1, 4) VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
+#undef VQ_RESCAN
+            default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
+        }
+        VQ_CHECK_LAUNCH("rescan_kernel");
+    }
+    if (x_dtype == VQHIP_DTYPE_F32)
+        refine_rerank_kernel<0, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
+                                                                 exact_list, keys);
+    else
+        refine_rerank_kernel<1, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
+                                                                 exact_list, keys);
+    VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");
+    // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
+    float *xn = xh2;     // xh2 is dead after the decision kernels: reuse it for the oracle-order |x|^2 of these rows
     if (metric == VQHIP_METRIC_L2) {
-        if (x_dtype == VQHIP_DTYPE_F32) row_sqnorm_list_kernel<0><<<256, 256, 0, s>>>(x, D, flag_list, counters, xn);
-        else row_sqnorm_list_kernel<1><<<256, 256, 0, s>>>(x, D, flag_list, counters, xn);
+        if (x_dtype == VQHIP_DTYPE_F32) row_sqnorm_list_kernel<0><<<256, 256, 0, s>>>(x, D, exact_list, counters + 2, xn);
+        else row_sqnorm_list_kernel<1><<<256, 256, 0, s>>>(x, D, exact_list, counters + 2, xn);
         VQ_CHECK_LAUNCH("row_sqnorm_list_kernel");
     }
-    rc = run_exact_rows(x, x_dtype, e_exact, en, xn, N, K, D, metric, flag_list, counters, keys, s);
+    rc = run_exact_rows(x, x_dtype, e_exact, en, xn, N, K, D, metric, exact_list, counters + 2, keys, s);
     if (rc) return rc;
-    finalize_kernel<<<256, 256, 0, s>>>(keys, flag_list, counters, N, idx, nullptr, hist);
+    finalize_kernel<<<256, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
     return VQHIP_OK;
 }

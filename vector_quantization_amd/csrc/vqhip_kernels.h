@@ -607,15 +607,23 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
     return isfinite(m) ? m : -1.0f;
 }
 
-// thread per token: merge the slice records under the margin; settle single-candidate rows, queue the rest
+#define VQ_RESCAN_CAP 32     // candidate slots per rescanned row
+
+// thread per token: merge the slice records under the margin.  Outcomes:
+//   one candidate                         -> idx written here
+//   several identified candidates         -> multi_list   (exact re-rank of those candidates)
+//   an unidentified candidate may exist   -> rescan_list  (second proposal pass that emits every score >= thr)
+//   no usable bound (non-finite data)     -> exact_list   (whole-codebook fp32 pass)
+// counters: [0] rescan rows, [1] multi rows, [2] exact rows
 __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
                                      const float *xh2, const float *rho2, int64_t Np, int64_t *idx, int32_t *hist,
-                                     int *flag_list, int *multi_list, int *counters, u64 *keys) {
+                                     int *rescan_list, int *multi_list, int *exact_list, int *counters, u64 *keys,
+                                     float *thr_out, int *rescan_cnt) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
-    bool flagged = !(m > 0.0f);
+    bool invalid = !(m > 0.0f);
     float v1[VQ_MAX_SLICES], v2[VQ_MAX_SLICES], v3[VQ_MAX_SLICES], c1[VQ_MAX_SLICES];
 #pragma unroll
     for (int s = 0; s < VQ_MAX_SLICES; ++s) {
@@ -627,20 +635,26 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     float gbest = -INFINITY;
 #pragma unroll
     for (int s = 0; s < VQ_MAX_SLICES; ++s) gbest = fmaxf(gbest, v1[s]);
-    if (!(gbest > -INFINITY)) flagged = true;
+    if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
     const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
     int nc = 0;
+    bool unidentified = false;
     uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
     for (int s = 0; s < VQ_MAX_SLICES; ++s) {
-        if (v3[s] >= thr) flagged = true;
+        if (v3[s] >= thr) unidentified = true;
         if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
         if (v2[s] >= thr) ++nc;
     }
-    if (flagged || nc == 0) {
-        int pos = atomicAdd(&counters[0], 1);
-        flag_list[pos] = (int)n;
+    if (invalid || nc == 0) {
+        int pos = atomicAdd(&counters[2], 1);
+        exact_list[pos] = (int)n;
         keys[n] = ~0ull;
+    } else if (unidentified) {
+        int pos = atomicAdd(&counters[0], 1);
+        rescan_list[pos] = (int)n;
+        rescan_cnt[pos] = 0;
+        thr_out[n] = thr;
     } else if (nc > 1) {
         int pos = atomicAdd(&counters[1], 1);
         multi_list[pos] = (int)n;
@@ -650,16 +664,74 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     }
 }
 
+// Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
+// operands, same instruction sequence), but every score >= the row's threshold is appended to the row's candidate
+// list.  One wave per (tile of 32 queued rows, codebook stage); fragments come straight from the L2-resident images.
+template <int NSTEP, int TPS>
+__global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
+                                                     int64_t nstages, const int *__restrict__ rescan_list,
+                                                     const int *__restrict__ counters, const float *__restrict__ thr,
+                                                     int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+    constexpr int NCH = TPS * NSTEP + 1;
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nrows = counters[0];
+    const int64_t ntiles = (nrows + 31) / 32;
+    const int64_t nitems = ntiles * nstages;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
+        const int64_t ft = item / nstages, st = item % nstages;
+        const int slot = (int)(ft * 32 + r);
+        const bool valid = slot < nrows;
+        const int64_t t = rescan_list[valid ? slot : 0];
+        const float mythr = valid ? thr[t] : INFINITY;
+        half8 xf[NSTEP];
+        const char *xsrc = ximg + (t >> 5) * (int64_t)(NSTEP * VQ_CHUNK_BYTES) + (h * 32 + (int)(t & 31)) * 16;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) xf[s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
+        const char *base = frag + st * (int64_t)STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+#pragma unroll 1
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
+                acc[4 * g + 0] = a4[0]; acc[4 * g + 1] = a4[1]; acc[4 * g + 2] = a4[2]; acc[4 * g + 3] = a4[3];
+            }
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                half8 a = *(const half8 *)(base + (ti * NSTEP + s) * VQ_CHUNK_BYTES + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[s], acc, 0, 0, 0);
+            }
+            uint32_t hits = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hits |= (acc[q] >= mythr) ? (1u << q) : 0u;
+            if (__any(hits != 0)) {
+                while (hits) {
+                    const int q = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + mfma_row(q, h));
+                    const int pos = atomicAdd(&rescan_cnt[slot], 1);
+                    if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)slot * VQ_RESCAN_CAP + pos] = (int)code;
+                }
+            }
+        }
+    }
+}
+
 // wave per queued row (persistent): exact fp32 evaluation of its candidates.  The row and (up to VQ_RR_BATCH at
 // a time) candidate code rows are staged in LDS with coalesced loads; lane j then runs the fma chain of the j-th
 // candidate in d order.
 #define VQ_RR_BATCH 8
-template <int DT>
+template <int DT, int SRC>
 __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const float *e_exact, const char *cb,
                                                             VqCbLayout L, int D, int metric, int nslices,
                                                             const float *rec, const float *xh2, const float *rho2,
                                                             int64_t Np, int64_t *idx, int32_t *hist,
-                                                            const int *multi_list, const int *counters) {
+                                                            const int *multi_list, int *counters,
+                                                            const int *rescan_cnt, const int *cand_list, int *exact_list,
+                                                            u64 *keys) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
@@ -668,19 +740,36 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const
     float *es = xs + Dq;
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float *en = (const float *)(cb + L.off_en);
-    const int nrows = counters[1];
+    const int nrows = counters[SRC == 0 ? 1 : 0];
     for (int item = blockIdx.x * nwaves + wave; item < nrows; item += gridDim.x * nwaves) {
         const int64_t n = multi_list[item];
-        const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
-        // lane i < 2*nslices owns candidate slot (slice i/2, field i%2)
-        float v = -INFINITY; uint32_t code = 0xFFFFFFFFu;
-        if (lane < 2 * nslices) {
-            const float *rp = rec + (int64_t)(lane >> 1) * VQ_REC_FIELDS * Np + n;
-            v = rp[(2 * (lane & 1)) * Np];
-            code = __float_as_uint(rp[(2 * (lane & 1) + 1) * Np]);
+        bool cand;
+        uint32_t code = 0xFFFFFFFFu;
+        if (SRC == 0) {
+            // lane i < 2*nslices owns candidate slot (slice i/2, field i%2) of the proposal records
+            const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+            float v = -INFINITY;
+            if (lane < 2 * nslices) {
+                const float *rp = rec + (int64_t)(lane >> 1) * VQ_REC_FIELDS * Np + n;
+                v = rp[(2 * (lane & 1)) * Np];
+                code = __float_as_uint(rp[(2 * (lane & 1) + 1) * Np]);
+            }
+            const float gbest = wave_max((lane & 1) ? -INFINITY : v);
+            cand = (lane < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
+        } else {
+            // rescanned row: lane j owns the j-th emitted candidate; an overflowing list goes to the fp32 pass
+            const int cnt = rescan_cnt[item];
+            if (cnt > VQ_RESCAN_CAP || cnt <= 0) {
+                if (lane == 0) {
+                    int pos = atomicAdd(&counters[2], 1);
+                    exact_list[pos] = (int)n;
+                    keys[n] = ~0ull;
+                }
+                continue;
+            }
+            cand = lane < cnt;
+            if (cand) code = (uint32_t)cand_list[(int64_t)item * VQ_RESCAN_CAP + lane];
         }
-        const float gbest = wave_max((lane & 1) ? -INFINITY : v);
-        const bool cand = (lane < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
         u64 cmask = __ballot(cand);
         const int ncand = __popcll(cmask);
         // stage x (oracle-order |x|^2 on the way)

@@ -62,10 +62,10 @@ struct VqCbStats {
 
 struct VqWsLayout {
     int64_t N;
-    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_keys, off_en, off_ximg, total;
+    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_ximg, total;
 };
 
-// counters: [0] flagged rows, [1] rows with >1 candidate, [2] rows (N), [3] reserved
+// counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
 VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     VqWsLayout W;
     W.N = N;
@@ -77,8 +77,12 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_rho2 = W.off_xh2 + Np * 4;
     W.off_rec = W.off_rho2 + Np * 4;
     W.off_flag = W.off_rec + (int64_t)VQ_MAX_SLICES * VQ_REC_FIELDS * Np * 4;
-    W.off_multi = W.off_flag + Np * 4;
-    W.off_keys = (W.off_multi + Np * 4 + 255) / 256 * 256;
+    W.off_multi = W.off_flag + Np * 4;       // off_flag: rescan list
+    W.off_exact = W.off_multi + Np * 4;
+    W.off_thr = W.off_exact + Np * 4;
+    W.off_rcnt = W.off_thr + Np * 4;
+    W.off_rlist = W.off_rcnt + Np * 4;       // [Np][32] candidate codes of rescanned rows
+    W.off_keys = (W.off_rlist + Np * 4 * 32 + 255) / 256 * 256;
     W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
     W.off_ximg = (W.off_en + (K + 63) / 64 * 64 * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
     W.total = W.off_ximg + (vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0);
