@@ -70,7 +70,7 @@ def test_vqgan_forward_backward(fused):
     np.testing.assert_allclose(xd.grad.cpu().numpy(), rgx, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), rgw, rtol=1e-4, atol=1e-7)
     # histogram from the fused epilogue and lazy distance
-    np.testing.assert_array_equal(memo['encode']['hist'].cpu().numpy().astype(np.int64), co.bincount(quant, K))
+    assert 'hist' not in memo['encode']                                   # plain VQGAN forward: no histogram pass
     d = memo['encode']['distance'].materialize()
     np.testing.assert_array_equal(d.cpu().numpy(), co.l2_dist(x, w))
 
@@ -153,6 +153,8 @@ def test_vqkd_kmeans_lazy_init_runs():
     z, loss, memo = q(torch.from_numpy(x).cuda(), {})
     w = q.embedding.weight.detach()
     np.testing.assert_allclose(w.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    np.testing.assert_array_equal(memo['encode']['hist'].cpu().numpy().astype(np.int64),
+                                  co.bincount(memo['quant'].cpu().numpy(), K))   # fused epilogue histogram (training callbacks)
     used = int((memo['encode']['hist'] > 0).sum())
     assert used > K // 2, f'k-means init left {K - used} dead codes'
     assert len(q._forward_pre_hooks) == 0       # the one-shot hook removed itself

@@ -126,7 +126,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
 
 static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
                           int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
-    const int grid = 1024;
+    const int grid = row_list ? 256 : 1024;
     if (row_list) {   // a few flagged rows against the whole codebook: small work items
         if (x_dtype == VQHIP_DTYPE_F32)
             exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
@@ -186,15 +186,11 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     char *c = (char *)cb;
-    VQ_HIP(hipMemsetAsync(c + L.off_stats, 0, 256, s));
-    cb_stats_kernel<<<(int)(waves_grid(K, 4) > 512 ? 512 : waves_grid(K, 4)), 256, 0, s>>>(e, K, D, metric, c, L);
+    cb_stats_kernel<<<(int)((K + 15) / 16), 256, 0, s>>>(e, K, D, metric, c, L);
     VQ_CHECK_LAUNCH("cb_stats_kernel");
     if (vq_coarse_supported(D)) {
-        cb_resid_kernel<<<(int)(waves_grid(K, 4) > 512 ? 512 : waves_grid(K, 4)), 256, 0, s>>>(e, K, D, metric, c, L);
-        VQ_CHECK_LAUNCH("cb_resid_kernel");
-        int64_t pieces = L.nstages * (L.stage_bytes / 16);
-        cb_frag_kernel<<<(int)((pieces + 255) / 256), 256, 0, s>>>(e, K, D, metric, c, L);
-        VQ_CHECK_LAUNCH("cb_frag_kernel");
+        cb_image_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(e, K, D, metric, c, L);
+        VQ_CHECK_LAUNCH("cb_image_kernel");
     }
     return VQHIP_OK;
 }
@@ -225,12 +221,11 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
         // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
         return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
     }
-    VQ_HIP(hipMemsetAsync(counters, 0, 256, s));
     int nslices = 1, rc;
     char *ximg = w + W.off_ximg;
     const int xgrid = (int)((N + 31) / 32);
-    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2);
-    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
     VQ_CHECK_LAUNCH("x_prep_kernel");
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
     if (rc) return rc;
@@ -288,15 +283,9 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
                                                                  exact_list, keys);
     VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
-    float *xn = xh2;     // xh2 is dead after the decision kernels: reuse it for the oracle-order |x|^2 of these rows
-    if (metric == VQHIP_METRIC_L2) {
-        if (x_dtype == VQHIP_DTYPE_F32) row_sqnorm_list_kernel<0><<<256, 256, 0, s>>>(x, D, exact_list, counters + 2, xn);
-        else row_sqnorm_list_kernel<1><<<256, 256, 0, s>>>(x, D, exact_list, counters + 2, xn);
-        VQ_CHECK_LAUNCH("row_sqnorm_list_kernel");
-    }
-    rc = run_exact_rows(x, x_dtype, e_exact, en, xn, N, K, D, metric, exact_list, counters + 2, keys, s);
+    rc = run_exact_rows(x, x_dtype, e_exact, en, nullptr, N, K, D, metric, exact_list, counters + 2, keys, s);
     if (rc) return rc;
-    finalize_kernel<<<256, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
+    finalize_kernel<<<16, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
     return VQHIP_OK;
 }

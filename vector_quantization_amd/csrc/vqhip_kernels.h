@@ -153,123 +153,164 @@ __device__ __forceinline__ float block_max4(float v, float *red) {    // max ove
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// pass 1 (wave per code, grid-stride): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
-// Running maxima stay in registers; one filtered atomic set per block at the end (hot-word atomics serialise).
+// pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
+// The four rows of a wave are loaded together and reduced with interleaved shuffle trees; maxima are reduced per
+// block and written as one partial per block (same-line atomics from ~1000 concurrent blocks cost ~25 us).
 __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
     __shared__ float red[4];
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
     float *en = (float *)(cb + L.off_en);
     float *ex = (float *)(cb + L.off_eexact);
-    float m_abs = 0.0f, m_e2 = 0.0f, m_en = 0.0f;
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    float p[4] = {0, 0, 0, 0}, amax = 0.0f;
     bool bad = false;
-    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * 4) {
-        float p = 0.0f, amax = 0.0f;
-        for (int d = lane; d < D; d += 64) { float a = e[k * D + d]; p = fmaf(a, a, p); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); }
-        p = wave_sum_tree(p);
-        float q2 = p;
-        if (metric == VQHIP_METRIC_COS) {
-            float nrm = sqrtf(p);
+    for (int d = lane; d < D; d += 64) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = (k0 + c < K) ? e[(k0 + c) * D + d] : 0.0f;
+            p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = p[c] + __shfl_xor(p[c], off, 64);
+    float m_e2 = 0.0f, m_en = 0.0f;
+    if (metric == VQHIP_METRIC_COS) {
+        amax = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + c >= K) continue;
+            float nrm = sqrtf(p[c]);
             float den = (nrm < 1e-12f) ? 1e-12f : nrm;
-            amax = 0.0f; q2 = 0.0f;
+            float q2 = 0.0f;
             for (int d = lane; d < D; d += 64) {
-                float a = e[k * D + d] / den;
-                ex[k * D + d] = a;
+                float a = e[(k0 + c) * D + d] / den;
+                ex[(k0 + c) * D + d] = a;
                 amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
             }
             q2 = wave_sum_tree(q2);
-            if (lane == 0) en[k] = 0.0f;
-        } else {
-            if (lane == 0) en[k] = p;
-            m_en = fmaxf(m_en, p);
+            bad |= !isfinite(q2);
+            m_e2 = fmaxf(m_e2, q2);
+            if (lane == 0) en[k0 + c] = 0.0f;
         }
-        bad |= !isfinite(q2);
-        m_abs = fmaxf(m_abs, amax); m_e2 = fmaxf(m_e2, q2);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + c >= K) continue;
+            if (lane == 0) en[k0 + c] = p[c];
+            bad |= !isfinite(p[c]);
+            m_e2 = fmaxf(m_e2, p[c]); m_en = fmaxf(m_en, p[c]);
+        }
     }
-    m_abs = wave_max(m_abs);
+    amax = wave_max(amax);
     bad = __any(bad);
-    m_abs = block_max4(m_abs, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
+    amax = block_max4(amax, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
     float badf = block_max4(bad ? 1.0f : 0.0f, red);
-    if (threadIdx.x == 0) {
-        if (badf > 0.0f) atomicOr(&st->nonfinite, 1u);
-        else {
-            atomic_max_filtered(&st->maxabs_bits, __float_as_uint(m_abs));
-            atomic_max_filtered(&st->e2max_bits, __float_as_uint(m_e2));
-            if (metric == VQHIP_METRIC_L2) atomic_max_filtered(&st->enmax_bits, __float_as_uint(m_en));
-        }
-    }
+    // per-block partial result; reduced by every block of cb_image_kernel (no hot-word atomics, no memset)
+    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part1))[blockIdx.x] = f32x4{amax, m_e2, m_en, badf};
+    (void)st;
 }
 
-// pass 2 (wave per code, grid-stride): fp16 residual / image norms with the final scale
-__global__ __launch_bounds__(256) void cb_resid_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
-    __shared__ float red[4];
-    const int lane = threadIdx.x & 63;
-    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);   // (no early exit on st->nonfinite: block barriers below)
-    const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
-    const float se = cb_scale(st), inv = 1.0f / se;
-    float m_r2 = 0.0f, m_h2 = 0.0f;
-    bool bad = false;
-    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * 4) {
-        float r2 = 0.0f, h2 = 0.0f;
-        for (int d = lane; d < D; d += 64) {
-            float a = src[k * D + d];
-            float back = (float)to_f16_ftz(a * se) * inv;
-            float res = a - back;
-            r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
-        }
-        r2 = wave_sum_tree(r2); h2 = wave_sum_tree(h2);
-        bad |= !isfinite(r2) || !isfinite(h2);
-        m_r2 = fmaxf(m_r2, r2); m_h2 = fmaxf(m_h2, h2);
-    }
-    m_r2 = block_max4(m_r2, red); m_h2 = block_max4(m_h2, red);
-    float badf = block_max4(bad ? 1.0f : 0.0f, red);
-    if (threadIdx.x == 0) {
-        if (badf > 0.0f) atomicOr(&st->nonfinite, 1u);
-        else { atomic_max_filtered(&st->r2max_bits, __float_as_uint(m_r2)); atomic_max_filtered(&st->eh2max_bits, __float_as_uint(m_h2)); }
-    }
-}
-
-// pass 3 (thread per 16-byte fragment piece): the MFMA-fragment-major fp16 image.
-// chunk (tile T, k-step s) holds, for lane l, codes T*32+(l&31), dims 16s + 8(l>>5) .. +8 — exactly the
-// A operand of v_mfma_f32_32x32x16_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
-__global__ void cb_frag_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
-    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t pieces_per_stage = L.stage_bytes / 16;
-    int64_t stage = gid / pieces_per_stage;
-    if (stage >= L.nstages) return;
-    int64_t piece = gid % pieces_per_stage;
-    int chunk = (int)(piece / 64), lane = (int)(piece % 64);
-    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+// pass 2 (one 256-thread block per tile of 32 codes): the MFMA-fragment-major fp16 image, the aux chunk, and the fp16
+// residual / image norms with the final scale.
+// chunk (tile T, k-step s) holds, for lane l, codes T*32+(l&31), dims 16s + 8(l>>5) .. +8 — exactly the A operand of
+// v_mfma_f32_32x32x16_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
+__global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    __shared__ float red[2][8][32];
+    __shared__ float red4[4];
+    const int64_t tile = blockIdx.x;
+    const int64_t stage = tile / L.tps;
+    const int ti = (int)(tile % L.tps);
+    const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
     const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
     const float *en = (const float *)(cb + L.off_en);
-    float se = cb_scale(st);
-    char *dst = cb + L.off_frag + stage * L.stage_bytes + (int64_t)chunk * VQ_CHUNK_BYTES + lane * 16;
-    int nfrag = L.tps * L.nstep;
-    if (chunk < nfrag) {
-        int ti = chunk / L.nstep, s = chunk % L.nstep;
-        int64_t k = (stage * L.tps + ti) * VQ_TILE_CODES + (lane & 31);
-        int d0 = 16 * s + 8 * (lane >> 5);
+    // every block reduces the statistics partials (16 KiB, L2-resident) to the global maxima -> the common scale
+    VqCbStats g_st;
+    {
+        const f32x4 *part = (const f32x4 *)(cb + L.off_part1);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int64_t i = threadIdx.x; i < L.nblk1; i += 256) {
+            f32x4 v = part[i];
+            a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]); a3 = fmaxf(a3, v[3]);
+        }
+        a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2); a3 = wave_max(a3);
+        a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4); a3 = block_max4(a3, red4);
+        g_st.maxabs_bits = __float_as_uint(a0); g_st.e2max_bits = __float_as_uint(a1);
+        g_st.enmax_bits = (metric == VQHIP_METRIC_L2) ? __float_as_uint(a2) : 0u;
+        g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
+            st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 0u;
+            st->r2max_bits = 0u; st->eh2max_bits = 0u;
+        }
+    }
+    const float se = cb_scale(&g_st), inv = 1.0f / se;
+    const int64_t k = tile * VQ_TILE_CODES + r;
+    char *stage_base = cb + L.off_frag + stage * L.stage_bytes;
+    float r2 = 0.0f, h2 = 0.0f;
+    for (int piece = g; piece < L.nstep * 2; piece += 8) {
+        const int s = piece >> 1, h = piece & 1;
+        const int d0 = 16 * s + 8 * h;
         half8 o;
+        if (k < K && d0 < D) {
+            float v[8];
+            if (d0 + 8 <= D && (D % 4) == 0) { load8<0>(src, k * D + d0, v); }
+            else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = (k < K && d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
-            o[j] = to_f16_ftz(a * se);
-        }
-        *(half8 *)dst = o;
-    } else {
-        // aux chunk: 4 floats per lane; lanes 0..(tps*8-1) carry -se*|e_k|^2/2 for the stage's codes
-        f32x4 o;
+                for (int j = 0; j < 8; ++j) v[j] = (d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = lane * 4 + j;
-            int64_t k = stage * L.tps * VQ_TILE_CODES + c;
-            float v = 0.0f;
-            // padded codes get a large FINITE negative score: -inf with the register index or-ed into its low
-            // mantissa bits would be a signalling NaN and poison v_max_f32
-            if (c < L.tps * VQ_TILE_CODES) v = (k < K) ? (-0.5f * en[k]) * se : -3.0e38f;
-            o[j] = v;
+            for (int j = 0; j < 8; ++j) {
+                _Float16 q = to_f16_ftz(v[j] * se);
+                float back = (float)q * inv, res = v[j] - back;
+                r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+                o[j] = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
         }
-        *(f32x4 *)dst = o;
+        *(half8 *)(stage_base + (int64_t)(ti * L.nstep + s) * VQ_CHUNK_BYTES + (h * 32 + r) * 16) = o;
+    }
+    // aux chunk slice of this tile: -se*|e_k|^2/2 for its 32 codes (padded codes: a large FINITE negative score;
+    // -inf with the register index or-ed into its mantissa would be a signalling NaN and poison v_max_f32)
+    if (g == 0) {
+        float v = (k < K) ? (-0.5f * en[k]) * se : -3.0e38f;
+        *(float *)(stage_base + (int64_t)L.tps * L.nstep * VQ_CHUNK_BYTES + (ti * 32 + r) * 4) = v;
+    }
+    red[0][g][r] = r2; red[1][g][r] = h2;
+    __syncthreads();
+    float a = 0.0f, b = 0.0f;
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += red[0][i][r]; b += red[1][i][r]; }
+    }
+    bool bad = !isfinite(a) || !isfinite(b);
+    a = wave_max(a); b = wave_max(b);       // waves 1..3 contribute zeros
+    a = block_max4(a, red4); b = block_max4(b, red4);
+    float badf = block_max4(__any(bad) ? 1.0f : 0.0f, red4);
+    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part2))[blockIdx.x] = f32x4{a, b, badf, 0.0f};
+}
+
+// Folds the image kernel's per-block partials into the statistics header (run by block 0 of the first kernel of every
+// consumer call; idempotent).
+__device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L, float *red4) {
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    const f32x4 *part = (const f32x4 *)(cb + L.off_part2);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int64_t i = threadIdx.x; i < L.nblk2; i += blockDim.x) {
+        f32x4 v = part[i];
+        a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]);
+    }
+    a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2);
+    a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4);
+    if (threadIdx.x == 0) {
+        st->r2max_bits = __float_as_uint(a0); st->eh2max_bits = __float_as_uint(a1);
+        if (a2 > 0.0f) st->nonfinite = 1u;
+        st->finalized = 1u;
     }
 }
 
@@ -281,8 +322,14 @@ __global__ void cb_frag_kernel(const float *e, int64_t K, int D, int metric, cha
 template <int DT>
 __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
                                                      char *__restrict__ ximg, float *__restrict__ xh2,
-                                                     float *__restrict__ rho2) {
+                                                     float *__restrict__ rho2, int *__restrict__ counters, char *cb,
+                                                     VqCbLayout L) {
     __shared__ float red[2][8][32];
+    __shared__ float red4[4];
+    if (blockIdx.x == 0) {   // housekeeping for the later kernels of this call (stream-ordered)
+        if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+        cb_finalize_stats(cb, L, red4);
+    }
     const int64_t tile = blockIdx.x;
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t t = tile * 32 + r;
@@ -646,19 +693,36 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
         if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
         if (v2[s] >= thr) ++nc;
     }
-    if (invalid || nc == 0) {
-        int pos = atomicAdd(&counters[2], 1);
-        exact_list[pos] = (int)n;
-        keys[n] = ~0ull;
-    } else if (unidentified) {
-        int pos = atomicAdd(&counters[0], 1);
-        rescan_list[pos] = (int)n;
-        rescan_cnt[pos] = 0;
-        thr_out[n] = thr;
-    } else if (nc > 1) {
-        int pos = atomicAdd(&counters[1], 1);
-        multi_list[pos] = (int)n;
-    } else {
+    // wave-aggregated list appends: one atomic per wave and list instead of one per row
+    const int lane = threadIdx.x & 63;
+    const bool to_exact = invalid || nc == 0;
+    const bool to_rescan = !to_exact && unidentified;
+    const bool to_multi = !to_exact && !to_rescan && nc > 1;
+    {
+        const u64 below = (1ull << lane) - 1ull;
+        u64 mk = __ballot(to_exact);
+        if (mk) {
+            int base = 0;
+            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[2], __popcll(mk));
+            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
+            if (to_exact) { exact_list[base + __popcll(mk & below)] = (int)n; keys[n] = ~0ull; }
+        }
+        mk = __ballot(to_rescan);
+        if (mk) {
+            int base = 0;
+            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[0], __popcll(mk));
+            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
+            if (to_rescan) { int pos = base + __popcll(mk & below); rescan_list[pos] = (int)n; rescan_cnt[pos] = 0; thr_out[n] = thr; }
+        }
+        mk = __ballot(to_multi);
+        if (mk) {
+            int base = 0;
+            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[1], __popcll(mk));
+            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
+            if (to_multi) multi_list[base + __popcll(mk & below)] = (int)n;
+        }
+    }
+    if (!to_exact && !to_rescan && !to_multi) {
         idx[n] = (int64_t)best;
         if (hist) atomicAdd(&hist[best], 1);
     }
@@ -678,9 +742,10 @@ __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ xi
     const int r = lane & 31, h = lane >> 5;
     const int nrows = counters[0];
     const int64_t ntiles = (nrows + 31) / 32;
-    const int64_t nitems = ntiles * nstages;
+    const int64_t nitems = ntiles * nstages * TPS;       // (tile of 32 rows, stage, tile-in-stage): short items, many waves
     for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
-        const int64_t ft = item / nstages, st = item % nstages;
+        const int64_t ft = item / (nstages * TPS), st = (item / TPS) % nstages;
+        const int ti = (int)(item % TPS);
         const int slot = (int)(ft * 32 + r);
         const bool valid = slot < nrows;
         const int64_t t = rescan_list[valid ? slot : 0];
@@ -691,8 +756,7 @@ __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ xi
         for (int s = 0; s < NSTEP; ++s) xf[s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
         const char *base = frag + st * (int64_t)STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-#pragma unroll 1
-        for (int ti = 0; ti < TPS; ++ti) {
+        {
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -881,7 +945,8 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
 
-        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? xn_in[row] : 0.0f;   // oracle-order |x|^2, precomputed
+        // oracle-order |x|^2: precomputed for whole-batch passes, computed per lane on the (rare) last-resort path
+        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
         for (int db = 0; db < D; db += DB) {
             // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
             float xfr[DB / 2];

@@ -29,7 +29,8 @@ struct VqCbLayout {
     int D, Dp, nstep, tps;  // dims, padded dims, k-steps of 16, tiles per stage
     int64_t nstages;
     int64_t stage_bytes;    // (tps*nstep + 1) KiB: fragment chunks + one aux chunk (-se*|e|^2/2)
-    int64_t off_stats, off_en, off_eexact, off_frag, total;
+    int64_t off_stats, off_part1, off_part2, off_en, off_eexact, off_frag, total;
+    int64_t nblk1, nblk2;   // blocks of the statistics / image kernels (their partial-result arrays)
 };
 
 VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
@@ -41,7 +42,11 @@ VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
     L.Kp = L.nstages * cps;
     L.stage_bytes = ((int64_t)L.tps * L.nstep + 1) * VQ_CHUNK_BYTES;
     L.off_stats = 0;
-    L.off_en = 256;
+    L.nblk1 = (K + 15) / 16;                 // cb_stats_kernel: 16 codes per block
+    L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
+    L.off_part1 = 256;                       // float4 {max|e|, max e2, max en, bad} per stats block
+    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // float4 {max r2, max eh2, bad, 0} per image block
+    L.off_en = (L.off_part2 + L.nblk2 * 16 + 255) / 256 * 256;
     L.off_eexact = (L.off_en + L.Kp * 4 + 255) / 256 * 256;
     L.off_frag = (L.off_eexact + K * (int64_t)D * 4 + 1023) / 1024 * 1024;
     L.total = L.off_frag + L.nstages * L.stage_bytes;
@@ -57,7 +62,7 @@ struct VqCbStats {
     uint32_t enmax_bits;    // max_k oracle |e_k|^2 (0 for COS)
     uint32_t nonfinite;     // !=0: some entry is NaN/Inf (or overflows the fp16 image)
     int32_t metric;
-    int32_t pad;
+    uint32_t finalized;     // r2max/eh2max folded in from the image kernel's partials (first consumer call does it)
 };
 
 struct VqWsLayout {

@@ -111,10 +111,14 @@ class VectorQuantizer(BaseQuantizer):
         w = self._embedding.weight.detach()
         shape = x.shape[:-1]
         x2 = x.detach().reshape(-1, x.shape[-1])
-        hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
+        # the code-hit histogram is a by-product of the re-rank epilogue; only the training callbacks consume it
+        hist = None
+        if self.training and len(self._callbacks.callbacks) > 0:
+            hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
         quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w))
         memo['distance'] = LazyDistance(self._distance, x2, w)
-        memo['hist'] = hist
+        if hist is not None:
+            memo['hist'] = hist
         return quant.reshape(shape), memo
 
     def _decode(self, quant: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, Memo]:
