@@ -240,3 +240,38 @@ def test_empty_and_ragged(ops):
     for N in (1, 31, 33, 257):
         x = synth.normal(N, N, 16)
         np.testing.assert_array_equal(ops.argmin(dev(x), cb).cpu().numpy(), co.l2_argmin(x, w.cpu().numpy()))
+
+
+@pytest.mark.parametrize('D', [8, 16, 24, 64, 128, 512, 768])
+@pytest.mark.parametrize('metric', ['L2', 'Cosine'])
+def test_all_supported_dims(ops, D, metric):
+    """Every padded-D instantiation of the proposal kernel (k-steps 1..32) and the fp32-only route (D=768)."""
+    N, K = 700, 1500
+    x, w = synth.make_inputs('normal', 100 + D, N, K, D)
+    if metric == 'Cosine':
+        ref = co.cos_argmin(x, w)
+        xq = ops.normalize_rows(dev(x))
+    else:
+        ref = co.l2_argmin(x, w)
+        xq = dev(x)
+    cb = ops.prepare_codebook(dev(w), metric)
+    np.testing.assert_array_equal(ops.argmin(xq, cb).cpu().numpy(), ref)
+
+
+def test_large_batch_many_slices_and_single_slice(ops):
+    """Slice counts 1..16 give identical indices (tuning knob 2 forces the split)."""
+    from vector_quantization_amd import _lib
+    L = _lib.lib()
+    N, K, D = 3000, 4096, 64
+    x, w = synth.make_inputs('normal', 55, N, K, D)
+    ref = co.l2_argmin(x, w)
+    cb = ops.prepare_codebook(dev(w), 'L2')
+    try:
+        for ns in (1, 2, 4, 8, 16):
+            L.vqhip_set_tuning(2, ns)
+            for pipe in (0, 1):
+                L.vqhip_set_tuning(0, pipe)
+                np.testing.assert_array_equal(ops.argmin(dev(x), cb).cpu().numpy(), ref)
+    finally:
+        L.vqhip_set_tuning(2, 0)
+        L.vqhip_set_tuning(0, 1)

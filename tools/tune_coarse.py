@@ -19,7 +19,7 @@ g = torch.Generator(device='cuda').manual_seed(3407)
 w = torch.randn(K, D, device='cuda', generator=g)
 x = torch.randn(N, D, device='cuda', generator=g).bfloat16()
 cb = ops.prepare_codebook(w, 'L2')
-variants = [(1, ns) for ns in (0, 1, 2, 4, 8)]
+variants = [(1, 0), (0, 0)]
 ref = None
 times = {v: [] for v in variants}
 for r in range(ROUNDS + 1):

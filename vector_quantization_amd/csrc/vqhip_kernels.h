@@ -486,7 +486,6 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int q = 0; q < 16; ++q) accB[tm][q] = -3.0e38f;     // "previous tile" of the very first tile: never wins
-        constexpr int EPS = (16 + NSTEP - 1) / NSTEP;                // accumulator registers retired per k-step
         for (int64_t st = st0; st < st1; ++st) {
             const int buf = (int)((st - st0) & 1);
             if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
@@ -510,27 +509,40 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                 uint32_t old[TM];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) old[tm] = __float_as_uint(b1[tm][ps]);
-                half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
+                // A fragments PF k-steps ahead of the MFMAs that consume them (ring of PF+1 registers sets)
+                constexpr int PF = 2;
+                half8 af[PF + 1];
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
                 for (int s = 0; s < NSTEP; ++s) {
-                    half8 a_nxt = a_cur;
-                    if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
+                    if (s + PF < NSTEP)
+                        af[(s + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + s + PF) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
-                        cur[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], cur[tm], 0, 0, 0);
+                        cur[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % (PF + 1)], xf[tm][s], cur[tm], 0, 0, 0);
+                    // retire 16/NSTEP accumulator registers of the previous tile per k-step (one every NSTEP/16 steps
+                    // when there are more k-steps than registers)
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
+                    for (int tm = 0; tm < TM; ++tm) {
+                        if constexpr (NSTEP <= 16) {
 #pragma unroll
-                        for (int i = 0; i < EPS; ++i) {
-                            const int q = s * EPS + i;
-                            if (q < 16 && (NSTEP <= 16 || (s % (NSTEP / 16)) == 0)) {
-                                const int qq = NSTEP <= 16 ? q : s / (NSTEP / 16);
+                            for (int i = 0; i < 16 / NSTEP; ++i) {
+                                const int qq = s * (16 / NSTEP) + i;
+                                float v = __uint_as_float((__float_as_uint(prv[tm][qq]) & 0xFFFFFFF0u) | (uint32_t)qq);
+                                b2[tm][ps] = __builtin_amdgcn_fmed3f(b1[tm][ps], b2[tm][ps], v);
+                                b1[tm][ps] = vmax(b1[tm][ps], v);
+                            }
+                        } else {
+                            if (s % (NSTEP / 16) == 0) {
+                                const int qq = s / (NSTEP / 16);
                                 float v = __uint_as_float((__float_as_uint(prv[tm][qq]) & 0xFFFFFFF0u) | (uint32_t)qq);
                                 b2[tm][ps] = __builtin_amdgcn_fmed3f(b1[tm][ps], b2[tm][ps], v);
                                 b1[tm][ps] = vmax(b1[tm][ps], v);
                             }
                         }
-                    a_cur = a_nxt;
+                    }
                 }
                 const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
 #pragma unroll
