@@ -149,8 +149,8 @@ int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream);
  * around that launch (bench.py's roofline leg).  enable(1) starts collecting, collect() synchronises on the
  * recorded events, returns the summed kernel milliseconds and launch count (HOST pointers) and resets. */
 int vqhip_profile_enable(int on);
-/* Kernel-variant knobs for A/B measurements (results never change): key 0 = software-pipelined epilogue,
- * key 1 = static wave priority. */
+/* Knob for A/B measurements (results never change): key 2 = number of codebook slices (1,2,4,8,16; 0 = automatic).
+ * Keys 0 and 1 are retired no-ops. */
 int vqhip_set_tuning(int key, int value);
 int vqhip_profile_collect(double *ms_sum, int64_t *launches);
 

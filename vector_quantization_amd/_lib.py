@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvqhip.so')
+LIB_PATH = os.environ.get('VQHIP_LIB') or os.path.join(_HERE, 'libvqhip.so')   # VQHIP_LIB: experiment builds
 
 METRIC_L2, METRIC_COS = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1

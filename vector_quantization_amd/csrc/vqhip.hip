@@ -54,14 +54,14 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 }
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
-static int g_tune_pipe = 1, g_tune_prio = 0, g_tune_slices = 0;   // proposal-kernel variant knobs (vqhip_set_tuning)
+static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
 
-template <int NSTEP, int TM, int WAVES, int TPS, int PIPE, int PRIO>
-static int launch_coarse_var(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+template <int NSTEP, int TT, int WAVES, int TPS>
+static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, hipStream_t s) {
-    constexpr int BM = WAVES * TM * 32;
+    constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TM, WAVES, TPS, PIPE, PRIO>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS>;
     static bool attr_set = false;
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -75,23 +75,11 @@ static int launch_coarse_var(const char *ximg, int64_t N, const char *frag, int6
     return VQHIP_OK;
 }
 
-template <int NSTEP, int TM, int WAVES, int TPS>
-static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
-                             int64_t Np, hipStream_t s) {
-    if (g_tune_pipe) {
-        if (g_tune_prio) return launch_coarse_var<NSTEP, TM, WAVES, TPS, 1, 1>(ximg, N, frag, nstages, nslices, rec, Np, s);
-        return launch_coarse_var<NSTEP, TM, WAVES, TPS, 1, 0>(ximg, N, frag, nstages, nslices, rec, Np, s);
-    }
-    if (g_tune_prio) return launch_coarse_var<NSTEP, TM, WAVES, TPS, 0, 1>(ximg, N, frag, nstages, nslices, rec, Np, s);
-    return launch_coarse_var<NSTEP, TM, WAVES, TPS, 0, 0>(ximg, N, frag, nstages, nslices, rec, Np, s);
-}
-
 static int pick_slices(int64_t ntb, int64_t nstages) {
     if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
     // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
-    // record write-back (N=65536: 2 slices 1304 TF, 8 slices 1254 TF), re-read the token image fewer times and write
-    // fewer records.  (Rows whose candidates cannot all be identified get a second proposal pass, so the number of
-    // candidate groups no longer matters for speed.)
+    // record write-back, re-read the token image fewer times and write fewer records.  (Rows whose candidates cannot
+    // all be identified get a second proposal pass, so the number of candidate groups does not matter for speed.)
     int64_t want = (256 + ntb - 1) / ntb;
     int ns = 1;
     while (ns < want && ns < VQ_MAX_SLICES) ns <<= 1;
@@ -102,22 +90,21 @@ static int pick_slices(int64_t ntb, int64_t nstages) {
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
                          int *nslices_out, hipStream_t s) {
     const int nstep = L.nstep;
-    // small batches use one token tile per wave so that more workgroups exist
+    // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
-#define VQ_CFG(NS, TM, W, TPS)                                                                      \
+#define VQ_CFG(NS, TT, W, TPS)                                                                      \
     {                                                                                               \
-        int64_t ntb = (N + (W) * (TM) * 32 - 1) / ((W) * (TM) * 32);                                \
+        int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
         int ns = pick_slices(ntb, L.nstages);                                                       \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TM, W, TPS>(ximg, N, frag, L.nstages, ns, rec, Np, s);         \
+        return launch_coarse_cfg<NS, TT, W, TPS>(ximg, N, frag, L.nstages, ns, rec, Np, s);         \
     }
     switch (nstep) {
-        case 1: if (small) VQ_CFG(1, 1, 8, 4) else VQ_CFG(1, 2, 8, 4)
-        case 2: if (small) VQ_CFG(2, 1, 8, 4) else VQ_CFG(2, 2, 8, 4)
-        case 4: if (small) VQ_CFG(4, 1, 8, 4) else VQ_CFG(4, 2, 8, 4)
-        case 8: if (small) VQ_CFG(8, 1, 8, 4) else VQ_CFG(8, 2, 8, 4)
-        case 16: if (small) VQ_CFG(16, 1, 8, 4) else VQ_CFG(16, 2, 8, 4)
-        case 32: VQ_CFG(32, 1, 8, 2)
+        case 2: if (small) VQ_CFG(2, 2, 8, 4) else VQ_CFG(2, 4, 8, 4)
+        case 4: if (small) VQ_CFG(4, 2, 8, 4) else VQ_CFG(4, 4, 8, 4)
+        case 8: if (small) VQ_CFG(8, 2, 8, 4) else VQ_CFG(8, 4, 8, 4)
+        case 16: if (small) VQ_CFG(16, 2, 8, 4) else VQ_CFG(16, 4, 8, 4)
+        case 32: VQ_CFG(32, 2, 8, 2)
         default: break;
     }
 #undef VQ_CFG
@@ -267,7 +254,7 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
         const char *frag = c + L.off_frag;
         switch (L.nstep) {
 #define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
-            VQ_RESCAN(1, 4) VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
+            VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }
@@ -495,9 +482,8 @@ int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R
 }
 
 int vqhip_set_tuning(int key, int value) {
-    if (key == 0) g_tune_pipe = value;
-    else if (key == 1) g_tune_prio = value;
-    else if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
+    if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
+    else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;
 }

@@ -112,7 +112,7 @@ __device__ __forceinline__ void atomic_max_filtered(uint32_t *p, uint32_t v) {
     if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
 }
 
-// C/D register -> row of the 32x32 MFMA tile (MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// C/D register -> row of the 32x32 MFMA tile (v_mfma_f32_32x32x2_f32, MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------------
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K
 
 // pass 2 (one 256-thread block per tile of 32 codes): the MFMA-fragment-major fp16 image, the aux chunk, and the fp16
 // residual / image norms with the final scale.
-// chunk (tile T, k-step s) holds, for lane l, codes T*32+(l&31), dims 16s + 8(l>>5) .. +8 — exactly the A operand of
-// v_mfma_f32_32x32x16_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
+// chunk (tile T, k-step s of 32 dims, half c) holds, for lane l, code T*32 + 16c + (l&15), dims 32s + 8(l>>4) .. +8 —
+// exactly the A operand of v_mfma_f32_16x16x32_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
 __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
     __shared__ float red[2][8][32];
     __shared__ float red4[4];
@@ -251,9 +251,11 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     const int64_t k = tile * VQ_TILE_CODES + r;
     char *stage_base = cb + L.off_frag + stage * L.stage_bytes;
     float r2 = 0.0f, h2 = 0.0f;
+    // pieces of 8 dims: k-step of 32 dims s32 = piece/4, quarter q4 = piece%4; the tile's two 16-code halves go
+    // to chunks (s32, 0) and (s32, 1); within a chunk lane = q4*16 + (code & 15)
     for (int piece = g; piece < L.nstep * 2; piece += 8) {
-        const int s = piece >> 1, h = piece & 1;
-        const int d0 = 16 * s + 8 * h;
+        const int s = piece >> 2, q4 = piece & 3;
+        const int d0 = 32 * s + 8 * q4;
         half8 o;
         if (k < K && d0 < D) {
             float v[8];
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
         }
-        *(half8 *)(stage_base + (int64_t)(ti * L.nstep + s) * VQ_CHUNK_BYTES + (h * 32 + r) * 16) = o;
+        *(half8 *)(stage_base + (int64_t)(ti * L.nstep + 2 * s + (r >> 4)) * VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = o;
     }
     // aux chunk slice of this tile: -se*|e_k|^2/2 for its 32 codes (padded codes: a large FINITE negative score;
     // -inf with the register index or-ed into its mantissa would be a signalling NaN and poison v_max_f32)
@@ -317,8 +319,8 @@ __device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L,
 // ------------------------------------------------------------------------------------------------
 // token preparation: fp16 (flush-to-zero) fragment-major image of x, |xh|^2 and |x - xh|^2 per row
 // ------------------------------------------------------------------------------------------------
-// One 256-thread block per tile of 32 tokens.  Image chunk (tile, k-step s) holds for lane l the dims
-// 16s + 8(l>>5) .. +8 of token tile*32 + (l&31): the B operand of v_mfma_f32_32x32x16_f16.
+// One 256-thread block per 32 tokens.  Image chunk (tile of 16 tokens, k-step s of 32 dims) holds for lane l the dims
+// 32s + 8(l>>4) .. +8 of token tile*16 + (l&15): the B operand of v_mfma_f32_16x16x32_f16.
 template <int DT>
 __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
                                                      char *__restrict__ ximg, float *__restrict__ xh2,
@@ -330,15 +332,16 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
         if (threadIdx.x < 8) counters[threadIdx.x] = 0;
         cb_finalize_stats(cb, L, red4);
     }
-    const int64_t tile = blockIdx.x;
+    const int64_t blk = blockIdx.x;
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int64_t t = tile * 32 + r;
+    const int64_t t = blk * 32 + r;
     const bool tvalid = t < N;
     const int64_t trow = tvalid ? t : (N - 1);
+    const int ns32 = nstep >> 1;
     float s_h = 0.0f, s_r = 0.0f;
-    for (int piece = g; piece < nstep * 2; piece += 8) {
-        const int s = piece >> 1, h = piece & 1;
-        const int d0 = 16 * s + 8 * h;
+    for (int piece = g; piece < ns32 * 4; piece += 8) {
+        const int s = piece >> 2, q4 = piece & 3;
+        const int d0 = 32 * s + 8 * q4;
         half8 f;
         if (tvalid && d0 < D) {
             float v[8];
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = (_Float16)0.0f;
         }
-        *(half8 *)(ximg + (tile * nstep + s) * (int64_t)VQ_CHUNK_BYTES + (h * 32 + r) * 16) = f;
+        *(half8 *)(ximg + ((blk * 2 + (r >> 4)) * ns32 + s) * (int64_t)VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = f;
     }
     red[0][g][r] = s_h; red[1][g][r] = s_r;
     __syncthreads();
@@ -377,44 +380,56 @@ __device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
     else t.v3 = fmaxf(t.v3, v);
 }
 
-// One workgroup = WAVES waves x TM token tiles of 32 tokens held in registers as MFMA B fragments;
-// it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds) and
-// keeps, per lane and per slot (tile-in-stage), the best score with its tile/register and the runner-up
-// value.  Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (accumulator initialised with the aux value).
-template <int NSTEP, int TM, int WAVES, int TPS, int PIPE, int PRIO>
+__device__ __forceinline__ void top_merge_lane(Top2 &t, int xor_mask) {   // fold the partner lane's record into t
+    Top2 o;
+    o.v1 = __shfl_xor(t.v1, xor_mask, 64); o.v2 = __shfl_xor(t.v2, xor_mask, 64); o.v3 = __shfl_xor(t.v3, xor_mask, 64);
+    o.c1 = __shfl_xor(t.c1, xor_mask, 64); o.c2 = __shfl_xor(t.c2, xor_mask, 64);
+    if (o.c1 != 0xFFFFFFFFu) top_insert(t, o.v1, o.c1);
+    if (o.c2 != 0xFFFFFFFFu) top_insert(t, o.v2, o.c2);
+    t.v3 = fmaxf(t.v3, o.v3);
+}
+
+// code row inside a 32-code tile for accumulator element e = 4*c + reg of lane l (v_mfma_f32_16x16x32: row = 4(l>>4)+reg)
+__device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); }
+
+// One workgroup = WAVES waves x TT token tiles of 16 tokens held in registers as MFMA B fragments for the whole kernel;
+// it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds, one stage ahead) and
+// keeps, per lane and token, the best score with its tile / register and the runner-up value.
+// Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
+// MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
+// The epilogue of tile t-1 (3 VALU per element) is spread over the MFMAs of tile t (two accumulator sets ping-pong).
+template <int NSTEP, int TT, int WAVES, int TPS>
 __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage
+    static_assert(NSTEP % 2 == 0 && TPS % 2 == 0, "16x16x32 layout: 32-dim k-steps, ping-pong by tile parity");
+    constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
+    constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage (2 per k-step and tile, + aux)
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
-    constexpr int BM = WAVES * TM * 32;
+    constexpr int BM = WAVES * TT * 16;
+    constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
     const int sl = blockIdx.x % nslices;
     const int64_t tb = blockIdx.x / nslices;
     const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
-    const int64_t ntt = (N + 31) / 32;                   // token tiles in the fp16 token image
+    const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image
 
     // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
-    half8 xf[TM][NSTEP];
-    int64_t tok[TM];
+    half8 xf[TT][NS32];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        int64_t tt = tb * (BM / 32) + wave * TM + tm;
-        tok[tm] = tt * 32 + r;
+    for (int t = 0; t < TT; ++t) {
+        int64_t tt = tb * (BM / 16) + wave * TT + t;
         tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
-        const char *src = ximg + tt * (int64_t)(NSTEP * VQ_CHUNK_BYTES) + lane * 16;
+        const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) xf[tm][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+        for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
     }
 
-    float b1[TM][TPS], b2[TM][TPS];
-    uint32_t t1[TM][TPS];
+    float b1[TT], b2[TT];
+    uint32_t t1[TT];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int ti = 0; ti < TPS; ++ti) { b1[tm][ti] = -INFINITY; b2[tm][ti] = -INFINITY; t1[tm][ti] = 0; }
+    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; t1[t] = 0; }
 
     auto issue_stage = [&](int64_t st, int buf) {
         const char *src = frag + st * (int64_t)STAGE_BYTES;
@@ -428,166 +443,99 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     if (st0 < st1) issue_stage(st0, 0);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
 
-    if (PRIO) {   // static priority for the younger half of an 8-wave workgroup (breaks MFMA/VALU lockstep of SIMD partners)
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= (WAVES / 2) * 64) __builtin_amdgcn_s_setprio(1);
-    }
-    if (PIPE == 0) {
+    f32x4 accA[2][TT], accB[2][TT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accB[c][t][q] = -3.0e38f;   // "previous tile" of the very first tile: never wins
+
     for (int64_t st = st0; st < st1; ++st) {
-            const int buf = (int)((st - st0) & 1);
-            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
-            const char *base = lds + buf * STAGE_BYTES;
-            const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-#pragma unroll
-            for (int ti = 0; ti < TPS; ++ti) {
-                f32x16 acc[TM];
-                // accumulator init = -se*|e|^2/2 of this lane's 16 code rows (rows 8g+4h+{0..3} per register group g)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        acc[tm][4 * g + 0] = a4[0]; acc[tm][4 * g + 1] = a4[1];
-                        acc[tm][4 * g + 2] = a4[2]; acc[tm][4 * g + 3] = a4[3];
-                    }
-                }
-                // A fragments one k-step ahead of the MFMAs that consume them
-                half8 a_cur = *(const half8 *)(base + (ti * NSTEP) * VQ_CHUNK_BYTES + lane * 16);
-#pragma unroll
-                for (int s = 0; s < NSTEP; ++s) {
-                    half8 a_nxt = a_cur;
-                    if (s + 1 < NSTEP) a_nxt = *(const half8 *)(base + (ti * NSTEP + s + 1) * VQ_CHUNK_BYTES + lane * 16);
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, xf[tm][s], acc[tm], 0, 0, 0);
-                    a_cur = a_nxt;
-                }
-                const uint32_t tg = (uint32_t)(st * TPS + ti);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const uint32_t old = __float_as_uint(b1[tm][ti]);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        float v = __uint_as_float((__float_as_uint(acc[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
-                        b2[tm][ti] = __builtin_amdgcn_fmed3f(b1[tm][ti], b2[tm][ti], v);
-                        b1[tm][ti] = vmax(b1[tm][ti], v);
-                    }
-                    t1[tm][ti] = (__float_as_uint(b1[tm][ti]) != old) ? tg : t1[tm][ti];
-                }
-            }
-            __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
-        }
-
-    } else {
-        // Software-pipelined form: the epilogue (top-2 tracking) of tile t-1 is spread over the MFMA steps of tile t, so
-        // that its VALU work issues in the shadow of this wave's own MFMAs.  Two accumulator sets ping-pong by tile parity.
-        static_assert(TPS % 2 == 0, "ping-pong needs an even number of tiles per stage");
-        f32x16 accA[TM], accB[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) accB[tm][q] = -3.0e38f;     // "previous tile" of the very first tile: never wins
-        for (int64_t st = st0; st < st1; ++st) {
-            const int buf = (int)((st - st0) & 1);
-            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
-            const char *base = lds + buf * STAGE_BYTES;
-            const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-#pragma unroll
-            for (int ti = 0; ti < TPS; ++ti) {
-                f32x16 (&cur)[TM] = (ti & 1) ? accB : accA;
-                f32x16 (&prv)[TM] = (ti & 1) ? accA : accB;
-                constexpr int PS_DUMMY = 0; (void)PS_DUMMY;
-                const int ps = (ti + TPS - 1) % TPS;                  // slot of the previous tile
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        cur[tm][4 * g + 0] = a4[0]; cur[tm][4 * g + 1] = a4[1];
-                        cur[tm][4 * g + 2] = a4[2]; cur[tm][4 * g + 3] = a4[3];
-                    }
-                }
-                uint32_t old[TM];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) old[tm] = __float_as_uint(b1[tm][ps]);
-                // A fragments PF k-steps ahead of the MFMAs that consume them (ring of PF+1 registers sets)
-                constexpr int PF = 2;
-                half8 af[PF + 1];
-#pragma unroll
-                for (int i = 0; i < PF; ++i)
-                    if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
-#pragma unroll
-                for (int s = 0; s < NSTEP; ++s) {
-                    if (s + PF < NSTEP)
-                        af[(s + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + s + PF) * VQ_CHUNK_BYTES + lane * 16);
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        cur[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s % (PF + 1)], xf[tm][s], cur[tm], 0, 0, 0);
-                    // retire 16/NSTEP accumulator registers of the previous tile per k-step (one every NSTEP/16 steps
-                    // when there are more k-steps than registers)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        if constexpr (NSTEP <= 16) {
-#pragma unroll
-                            for (int i = 0; i < 16 / NSTEP; ++i) {
-                                const int qq = s * (16 / NSTEP) + i;
-                                float v = __uint_as_float((__float_as_uint(prv[tm][qq]) & 0xFFFFFFF0u) | (uint32_t)qq);
-                                b2[tm][ps] = __builtin_amdgcn_fmed3f(b1[tm][ps], b2[tm][ps], v);
-                                b1[tm][ps] = vmax(b1[tm][ps], v);
-                            }
-                        } else {
-                            if (s % (NSTEP / 16) == 0) {
-                                const int qq = s / (NSTEP / 16);
-                                float v = __uint_as_float((__float_as_uint(prv[tm][qq]) & 0xFFFFFFF0u) | (uint32_t)qq);
-                                b2[tm][ps] = __builtin_amdgcn_fmed3f(b1[tm][ps], b2[tm][ps], v);
-                                b1[tm][ps] = vmax(b1[tm][ps], v);
-                            }
-                        }
-                    }
-                }
-                const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    t1[tm][ps] = (__float_as_uint(b1[tm][ps]) != old[tm]) ? tgp : t1[tm][ps];
-            }
-            __syncthreads();
-        }
-        // drain: epilogue of the last tile (slot TPS-1, held in accB since TPS is even)
-        if (st1 > st0) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const uint32_t old = __float_as_uint(b1[tm][TPS - 1]);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    float v = __uint_as_float((__float_as_uint(accB[tm][q]) & 0xFFFFFFF0u) | (uint32_t)q);
-                    b2[tm][TPS - 1] = __builtin_amdgcn_fmed3f(b1[tm][TPS - 1], b2[tm][TPS - 1], v);
-                    b1[tm][TPS - 1] = vmax(b1[tm][TPS - 1], v);
-                }
-                t1[tm][TPS - 1] = (__float_as_uint(b1[tm][TPS - 1]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[tm][TPS - 1];
-            }
-        }
-    }
-
-    // ---- merge slots, then the two lane halves; lanes 0..31 write one record per (token, slice) ----
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        Top2 t; t.v1 = t.v2 = t.v3 = -INFINITY; t.c1 = t.c2 = 0xFFFFFFFFu;
+        const int buf = (int)((st - st0) & 1);
+        if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+        const char *base = lds + buf * STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll
         for (int ti = 0; ti < TPS; ++ti) {
-            uint32_t bits = __float_as_uint(b1[tm][ti]);
-            uint32_t code = t1[tm][ti] * 32u + (uint32_t)mfma_row((int)(bits & 15u), h);
-            if (b1[tm][ti] > -INFINITY) top_insert(t, b1[tm][ti], code);
-            t.v3 = fmaxf(t.v3, b2[tm][ti]);
+            f32x4 (&cur)[2][TT] = (ti & 1) ? accB : accA;
+            f32x4 (&prv)[2][TT] = (ti & 1) ? accA : accB;
+            // accumulator init = -se*|e|^2/2 of this lane's code rows 16c + 4(l>>4) + {0..3}
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) cur[c][t] = a4;
+            }
+            uint32_t old[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) old[t] = __float_as_uint(b1[t]);
+            // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets);
+            // chunk ch = 2*s32 + c feeds the TT MFMAs of code half c at k-step s32
+            constexpr int PF = 1;
+            half8 af[PF + 1];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+            for (int ch = 0; ch < NSTEP; ++ch) {
+                if (ch + PF < NSTEP)
+                    af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
+                constexpr int TOTAL = NE * TT;
+#pragma unroll
+                for (int i = 0; i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                    const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % (NSTEP / TOTAL) == 0) ? ch / (NSTEP / TOTAL) : -1);
+                    if (id >= 0 && id < TOTAL) {
+                        const int t = id / NE, e = id % NE;
+                        float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+                    }
+                }
+            }
+            const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
         }
-        Top2 o;
-        o.v1 = __shfl_xor(t.v1, 32, 64); o.v2 = __shfl_xor(t.v2, 32, 64); o.v3 = __shfl_xor(t.v3, 32, 64);
-        o.c1 = __shfl_xor(t.c1, 32, 64); o.c2 = __shfl_xor(t.c2, 32, 64);
-        if (o.c1 != 0xFFFFFFFFu) top_insert(t, o.v1, o.c1);
-        if (o.c2 != 0xFFFFFFFFu) top_insert(t, o.v2, o.c2);
-        t.v3 = fmaxf(t.v3, o.v3);
-        if (h == 0 && tok[tm] < N) {
-            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tok[tm];
-            rp[0] = t.v1; rp[Np] = __uint_as_float(t.c1); rp[2 * Np] = t.v2;
-            rp[3 * Np] = __uint_as_float(t.c2); rp[4 * Np] = t.v3;
+        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+    }
+    // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
+    if (st1 > st0) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t old = __float_as_uint(b1[t]);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                float v = __uint_as_float((__float_as_uint(accB[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                b1[t] = vmax(b1[t], v);
+            }
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
+    }
+
+    // ---- merge the four lanes that share a token; lanes 0..15 write one record per (token, slice) ----
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        Top2 r; r.v1 = r.v2 = r.v3 = -INFINITY; r.c1 = r.c2 = 0xFFFFFFFFu;
+        {
+            uint32_t bits = __float_as_uint(b1[t]);
+            uint32_t code = t1[t] * 32u + (uint32_t)tile_row16((int)(bits & 7u), lane);
+            if (b1[t] > -INFINITY) top_insert(r, b1[t], code);
+            r.v3 = fmaxf(r.v3, b2[t]);
+        }
+        top_merge_lane(r, 16);
+        top_merge_lane(r, 32);
+        const int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+        if (lane < 16 && tokn < N) {
+            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
+            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
+            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
         }
     }
 }
@@ -741,56 +689,64 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
 }
 
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
-// operands, same instruction sequence), but every score >= the row's threshold is appended to the row's candidate
-// list.  One wave per (tile of 32 queued rows, codebook stage); fragments come straight from the L2-resident images.
+// operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
+// candidate list.  One wave per (32 queued rows, codebook stage, tile); fragments come straight from the L2-resident images.
 template <int NSTEP, int TPS>
 __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
                                                      int64_t nstages, const int *__restrict__ rescan_list,
                                                      const int *__restrict__ counters, const float *__restrict__ thr,
                                                      int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+    constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + 1;
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
     const int nrows = counters[0];
     const int64_t ntiles = (nrows + 31) / 32;
-    const int64_t nitems = ntiles * nstages * TPS;       // (tile of 32 rows, stage, tile-in-stage): short items, many waves
+    const int64_t nitems = ntiles * nstages * TPS;       // (32 rows, stage, tile-in-stage): short items, many waves
     for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
         const int64_t ft = item / (nstages * TPS), st = (item / TPS) % nstages;
         const int ti = (int)(item % TPS);
-        const int slot = (int)(ft * 32 + r);
-        const bool valid = slot < nrows;
-        const int64_t t = rescan_list[valid ? slot : 0];
-        const float mythr = valid ? thr[t] : INFINITY;
-        half8 xf[NSTEP];
-        const char *xsrc = ximg + (t >> 5) * (int64_t)(NSTEP * VQ_CHUNK_BYTES) + (h * 32 + (int)(t & 31)) * 16;
+        half8 xf[2][NS32];
+        float mythr[2];
+        int slot[2];
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) xf[s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
+        for (int t = 0; t < 2; ++t) {
+            slot[t] = (int)(ft * 32 + t * 16 + (lane & 15));
+            const bool valid = slot[t] < nrows;
+            const int64_t tk = rescan_list[valid ? slot[t] : 0];
+            mythr[t] = valid ? thr[tk] : INFINITY;
+            const char *xsrc = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
+#pragma unroll
+            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
+        }
         const char *base = frag + st * (int64_t)STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-        {
-            f32x16 acc;
+        f32x4 acc[2][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * h) * 4);
-                acc[4 * g + 0] = a4[0]; acc[4 * g + 1] = a4[1]; acc[4 * g + 2] = a4[2]; acc[4 * g + 3] = a4[3];
-            }
+        for (int c = 0; c < 2; ++c) {
+            f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+            acc[c][0] = a4; acc[c][1] = a4;
+        }
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                half8 a = *(const half8 *)(base + (ti * NSTEP + s) * VQ_CHUNK_BYTES + lane * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[s], acc, 0, 0, 0);
-            }
-            uint32_t hits = 0;
+        for (int ch = 0; ch < NSTEP; ++ch) {
+            half8 a = *(const half8 *)(base + (ti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) hits |= (acc[q] >= mythr) ? (1u << q) : 0u;
-            if (__any(hits != 0)) {
-                while (hits) {
-                    const int q = __ffs((int)hits) - 1;
-                    hits &= hits - 1;
-                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + mfma_row(q, h));
-                    const int pos = atomicAdd(&rescan_cnt[slot], 1);
-                    if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)slot * VQ_RESCAN_CAP + pos] = (int)code;
-                }
+            for (int t = 0; t < 2; ++t)
+                acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
+        }
+        uint32_t hits = 0;      // bit 8t + e
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+        if (__any(hits != 0)) {
+            while (hits) {
+                const int b = __ffs((int)hits) - 1;
+                hits &= hits - 1;
+                const int t = b >> 3, e = b & 7;
+                const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
+                const int pos = atomicAdd(&rescan_cnt[slot[t]], 1);
+                if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)slot[t] * VQ_RESCAN_CAP + pos] = (int)code;
             }
         }
     }

@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 #define VQ_WAVE 64
-#define VQ_TILE_CODES 32           // codes per MFMA tile (v_mfma_f32_32x32x16_f16: 32 rows)
+#define VQ_TILE_CODES 32           // codes per tile (two v_mfma_f32_16x16x32_f16 row blocks)
 #define VQ_CHUNK_BYTES 1024        // one wave-instruction of global_load_lds_dwordx4
 #define VQ_MAX_SLICES 16
 #define VQ_REC_FIELDS 5            // v1, c1, v2, c2, v3
@@ -14,9 +14,9 @@
 #define VQ_HD inline
 #endif
 
-// Padded inner dimension for the fp16 proposal pass: next power of two >= max(D,16), <= 512.
+// Padded inner dimension for the fp16 proposal pass (k-steps of 32): next power of two >= max(D,32), <= 512.
 VQ_HD int vq_padded_d(int D) {
-    int p = 16;
+    int p = 32;
     while (p < D) p <<= 1;
     return p;
 }
