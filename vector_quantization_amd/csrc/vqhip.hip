@@ -216,13 +216,17 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     VQ_CHECK_LAUNCH("x_prep_kernel");
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
     if (rc) return rc;
-    const int rgrid = (int)((N + 255) / 256);
+    const int rgrid = (int)((N + 1023) / 1024);
     int *rescan_list = flag_list;
     int *multi_list = (int *)(w + W.off_multi), *exact_list = (int *)(w + W.off_exact);
     float *thr = (float *)(w + W.off_thr);
     int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
-    refine_decide_kernel<<<rgrid, 256, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, rescan_list,
-                                               multi_list, exact_list, counters, keys, thr, rescan_cnt);
+    switch (nslices) {
+#define VQ_DECIDE(NSL) case NSL: refine_decide_kernel<NSL><<<rgrid, 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt); break;
+        VQ_DECIDE(1) VQ_DECIDE(2) VQ_DECIDE(4) VQ_DECIDE(8) VQ_DECIDE(16)
+#undef VQ_DECIDE
+        default: return fail(VQHIP_EINVAL, "vqhip_argmin: bad slice count");
+    }
     VQ_CHECK_LAUNCH("refine_decide_kernel");
     // re-rank kernels: one wave per queued row; LDS per wave = (1 + VQ_RR_BATCH) rows of D floats
     int wpb = 4;
@@ -253,7 +257,7 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     {
         const char *frag = c + L.off_frag;
         switch (L.nstep) {
-#define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
+#define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<1024, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
             VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");

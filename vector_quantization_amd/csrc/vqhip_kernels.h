@@ -622,66 +622,63 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
 //   an unidentified candidate may exist   -> rescan_list  (second proposal pass that emits every score >= thr)
 //   no usable bound (non-finite data)     -> exact_list   (whole-codebook fp32 pass)
 // counters: [0] rescan rows, [1] multi rows, [2] exact rows
+template <int NSL>
 __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
                                      const float *xh2, const float *rho2, int64_t Np, int64_t *idx, int32_t *hist,
                                      int *rescan_list, int *multi_list, int *exact_list, int *counters, u64 *keys,
                                      float *thr_out, int *rescan_cnt) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    const bool oob = n >= N;
+    if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
     bool invalid = !(m > 0.0f);
-    float v1[VQ_MAX_SLICES], v2[VQ_MAX_SLICES], v3[VQ_MAX_SLICES], c1[VQ_MAX_SLICES];
+    // NSL = compile-time slice count: all record loads are issued together
+    float v1[NSL], v2[NSL], v3[NSL], c1[NSL];
+    (void)nslices;
 #pragma unroll
-    for (int s = 0; s < VQ_MAX_SLICES; ++s) {
+    for (int s = 0; s < NSL; ++s) {
         const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
-        const bool on = s < nslices;
-        v1[s] = on ? rp[0] : -INFINITY; c1[s] = on ? rp[Np] : 0.0f;
-        v2[s] = on ? rp[2 * Np] : -INFINITY; v3[s] = on ? rp[4 * Np] : -INFINITY;
+        v1[s] = rp[0]; c1[s] = rp[Np]; v2[s] = rp[2 * Np]; v3[s] = rp[4 * Np];
     }
     float gbest = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < VQ_MAX_SLICES; ++s) gbest = fmaxf(gbest, v1[s]);
+    for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
     if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
     const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
     int nc = 0;
     bool unidentified = false;
     uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
-    for (int s = 0; s < VQ_MAX_SLICES; ++s) {
+    for (int s = 0; s < NSL; ++s) {
         if (v3[s] >= thr) unidentified = true;
         if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
         if (v2[s] >= thr) ++nc;
     }
-    // wave-aggregated list appends: one atomic per wave and list instead of one per row
-    const int lane = threadIdx.x & 63;
-    const bool to_exact = invalid || nc == 0;
-    const bool to_rescan = !to_exact && unidentified;
-    const bool to_multi = !to_exact && !to_rescan && nc > 1;
-    {
-        const u64 below = (1ull << lane) - 1ull;
-        u64 mk = __ballot(to_exact);
-        if (mk) {
-            int base = 0;
-            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[2], __popcll(mk));
-            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
-            if (to_exact) { exact_list[base + __popcll(mk & below)] = (int)n; keys[n] = ~0ull; }
-        }
-        mk = __ballot(to_rescan);
-        if (mk) {
-            int base = 0;
-            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[0], __popcll(mk));
-            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
-            if (to_rescan) { int pos = base + __popcll(mk & below); rescan_list[pos] = (int)n; rescan_cnt[pos] = 0; thr_out[n] = thr; }
-        }
-        mk = __ballot(to_multi);
-        if (mk) {
-            int base = 0;
-            if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&counters[1], __popcll(mk));
-            base = __shfl(base, __ffsll((long long)mk) - 1, 64);
-            if (to_multi) multi_list[base + __popcll(mk & below)] = (int)n;
-        }
+    // block-aggregated list appends: one atomic per 1024-thread block and list (the three counters are hot words:
+    // ~8-11 ns per same-address atomic, so per-wave appends from 1024 waves cost ~15 us)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool to_exact = !oob && (invalid || nc == 0);
+    const bool to_rescan = !oob && !to_exact && unidentified;
+    const bool to_multi = !oob && !to_exact && !to_rescan && nc > 1;
+    __shared__ int wcount[3][16];
+    __shared__ int wbase[3][16];
+    const u64 mk_e = __ballot(to_exact), mk_r = __ballot(to_rescan), mk_m = __ballot(to_multi);
+    if (lane == 0) { wcount[0][wave] = __popcll(mk_r); wcount[1][wave] = __popcll(mk_m); wcount[2][wave] = __popcll(mk_e); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int tot = 0;
+        const int nw = blockDim.x >> 6;
+        for (int i = 0; i < nw; ++i) { wbase[threadIdx.x][i] = tot; tot += wcount[threadIdx.x][i]; }
+        const int base = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+        for (int i = 0; i < nw; ++i) wbase[threadIdx.x][i] += base;
     }
+    __syncthreads();
+    const u64 below = (1ull << lane) - 1ull;
+    if (to_exact) { exact_list[wbase[2][wave] + __popcll(mk_e & below)] = (int)n; keys[n] = ~0ull; }
+    if (to_rescan) { int pos = wbase[0][wave] + __popcll(mk_r & below); rescan_list[pos] = (int)n; rescan_cnt[pos] = 0; thr_out[n] = thr; }
+    if (to_multi) multi_list[wbase[1][wave] + __popcll(mk_m & below)] = (int)n;
+    if (oob) return;
     if (!to_exact && !to_rescan && !to_multi) {
         idx[n] = (int64_t)best;
         if (hist) atomicAdd(&hist[best], 1);
@@ -690,7 +687,8 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
 
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
 // operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
-// candidate list.  One wave per (32 queued rows, codebook stage, tile); fragments come straight from the L2-resident images.
+// candidate list.  One wave per (64 queued rows, codebook stage); fragments come straight from the L2-resident images,
+// each A chunk feeds four MFMAs.
 template <int NSTEP, int TPS>
 __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
                                                      int64_t nstages, const int *__restrict__ rescan_list,
@@ -699,19 +697,19 @@ __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ xi
     constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + 1;
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int TR = (NSTEP <= 16) ? 4 : 2;            // 16-row sub-tiles per item (register budget at D=512)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
-    const int64_t ntiles = (nrows + 31) / 32;
-    const int64_t nitems = ntiles * nstages * TPS;       // (32 rows, stage, tile-in-stage): short items, many waves
+    const int64_t ngroups = (nrows + 16 * TR - 1) / (16 * TR);
+    const int64_t nitems = ngroups * nstages;
     for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
-        const int64_t ft = item / (nstages * TPS), st = (item / TPS) % nstages;
-        const int ti = (int)(item % TPS);
-        half8 xf[2][NS32];
-        float mythr[2];
-        int slot[2];
+        const int64_t fg = item / nstages, st = item % nstages;
+        half8 xf[TR][NS32];
+        float mythr[TR];
+        int slot[TR];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            slot[t] = (int)(ft * 32 + t * 16 + (lane & 15));
+        for (int t = 0; t < TR; ++t) {
+            slot[t] = (int)(fg * 16 * TR + t * 16 + (lane & 15));
             const bool valid = slot[t] < nrows;
             const int64_t tk = rescan_list[valid ? slot[t] : 0];
             mythr[t] = valid ? thr[tk] : INFINITY;
@@ -721,32 +719,39 @@ __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ xi
         }
         const char *base = frag + st * (int64_t)STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-        f32x4 acc[2][2];
+#pragma unroll 2
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x4 acc[2][TR];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
-            acc[c][0] = a4; acc[c][1] = a4;
-        }
+            for (int c = 0; c < 2; ++c) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
 #pragma unroll
-        for (int ch = 0; ch < NSTEP; ++ch) {
-            half8 a = *(const half8 *)(base + (ti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
+                for (int t = 0; t < TR; ++t) acc[c][t] = a4;
+            }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
-        }
-        uint32_t hits = 0;      // bit 8t + e
+            for (int ch = 0; ch < NSTEP; ++ch) {
+                half8 a = *(const half8 *)(base + (ti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TR; ++t)
+                    acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
+            }
+            uint32_t hits = 0;      // bit 8t + e
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
-        if (__any(hits != 0)) {
-            while (hits) {
-                const int b = __ffs((int)hits) - 1;
-                hits &= hits - 1;
-                const int t = b >> 3, e = b & 7;
-                const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
-                const int pos = atomicAdd(&rescan_cnt[slot[t]], 1);
-                if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)slot[t] * VQ_RESCAN_CAP + pos] = (int)code;
+            for (int t = 0; t < TR; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+            if (__any(hits != 0)) {
+                while (hits) {
+                    const int b = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const int t = b >> 3, e = b & 7;
+                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
+                    int sl_t = slot[0];
+#pragma unroll
+                    for (int i = 1; i < TR; ++i) sl_t = (t == i) ? slot[i] : sl_t;
+                    const int pos = atomicAdd(&rescan_cnt[sl_t], 1);
+                    if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)sl_t * VQ_RESCAN_CAP + pos] = (int)code;
+                }
             }
         }
     }
