@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Throughput of the encode path on the other BASELINE.json shapes (C3 VQ-KD cosine D=32, LlamaGen D=8, C1) plus the
+training-step pieces (VQ-KD / CVQ updates).  Reports tokens/s per shape; one process, CUDA events."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vector_quantization_amd import ops
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+
+g = torch.Generator(device='cuda').manual_seed(3407)
+def shape(name, N, K, D, metric, normalize=False, dtype=torch.float32):
+    w = torch.randn(K, D, device='cuda', generator=g); x = torch.randn(N, D, device='cuda', generator=g).to(dtype)
+    def enc():
+        ww, xx = w, x
+        if normalize: ww, xx = ops.normalize_rows(w), ops.normalize_rows(x)
+        cb = ops.prepare_codebook(ww, metric)
+        xq = ops.normalize_rows(xx) if metric == 'Cosine' else xx
+        return ops.argmin(xq, cb, return_stats=True)
+    idx, st = enc(); t = timeit(lambda: enc())
+    print(f'{name:34s} N={N:7d} K={K:5d} D={D:3d} {metric:6s}: {t*1e3:8.3f} ms  {N/t/1e6:8.1f} Mtok/s  '
+          f'rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])}', flush=True)
+
+shape('C1 VQGAN small', 1024, 1024, 256, 'L2')
+shape('C2 VQGAN 32 img bf16', 8192, 16384, 256, 'L2', dtype=torch.bfloat16)
+shape('C2 VQGAN 256 img bf16', 65536, 16384, 256, 'L2', dtype=torch.bfloat16)
+shape('C2 VQGAN 256 img fp32 x', 65536, 16384, 256, 'L2')
+shape('C3 VQ-KD cosine', 100352, 8192, 32, 'Cosine')
+shape('C4 CVQ cosine per-rank', 3072, 16384, 256, 'Cosine')
+shape('C5 LlamaGen D=8 normalize+L2', 65536, 16384, 8, 'L2', normalize=True)
+shape('cluster D=768 (fp32 route)', 8192, 8192, 768, 'Cosine')
+# training-step pieces (per-rank C4 shape)
+N, K, D = 3072, 16384, 256
+w = torch.randn(K, D, device='cuda', generator=g); x = torch.randn(N, D, device='cuda', generator=g)
+t = timeit(lambda: ops.col_argmin(x, w, 'L2'), reps=5); print(f'col_argmin (NearestAnchor) N={N} K={K} D={D}: {t*1e3:.3f} ms')
+idx = ops.argmin(x, ops.prepare_codebook(w, 'L2'))
+t = timeit(lambda: ops.scatter_add_rows(x, idx, K)); print(f'scatter_add_rows: {t*1e3:.3f} ms')
+t = timeit(lambda: ops.hist(idx, K)); print(f'hist: {t*1e3:.3f} ms')

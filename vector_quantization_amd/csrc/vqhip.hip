@@ -111,20 +111,34 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
 }
 
+template <int MODE>
+static int run_exact_tiled(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K,
+                           int D, int metric, u64 *keys, float *dout, hipStream_t s) {
+    constexpr int LDS = 2 * 32 * 128 * 4;
+    auto k0 = exact_tiled_kernel<0, MODE>;
+    auto k1 = exact_tiled_kernel<1, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        VQ_HIP(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
+    int grid = (int)(items < 1024 ? items : 1024);
+    if (x_dtype == VQHIP_DTYPE_F32) k0<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+    else k1<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+    VQ_CHECK_LAUNCH("exact_tiled_kernel");
+    return VQHIP_OK;
+}
+
 static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
                           int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
-    const int grid = row_list ? 256 : 1024;
-    if (row_list) {   // a few flagged rows against the whole codebook: small work items
-        if (x_dtype == VQHIP_DTYPE_F32)
-            exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
-        else
-            exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
-    } else {
-        if (x_dtype == VQHIP_DTYPE_F32)
-            exact_kernel<0, 0, 4><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
-        else
-            exact_kernel<1, 0, 4><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
-    }
+    // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items)
+    const int grid = 256;
+    if (x_dtype == VQHIP_DTYPE_F32)
+        exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    else
+        exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
     VQ_CHECK_LAUNCH("exact_kernel");
     return VQHIP_OK;
 }
@@ -206,6 +220,7 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
 
     if (!vq_coarse_supported(D)) {
         // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
+        VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
         return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
     }
     int nslices = 1, rc;
@@ -304,7 +319,7 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
         int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
         if (rc0) return rc0;
     }
-    int rc = run_exact_rows(x, x_dtype, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, s);
+    int rc = run_exact_tiled<0>(x, x_dtype, e, en, xn, N, K, D, metric, keys, nullptr, s);
     if (rc) return rc;
     finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, N, idx, dmin, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
@@ -331,11 +346,11 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
     }
     fill_u64_kernel<<<256, 256, 0, s>>>(keys, K, ~0ull);
     VQ_CHECK_LAUNCH("fill_u64_kernel");
-    if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 1, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, nullptr);
-    else if (x_dtype == VQHIP_DTYPE_BF16)
-        exact_kernel<1, 1, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, keys, nullptr);
-    else return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
+    {
+        int rc1 = run_exact_tiled<1>(x, x_dtype, e, en, xn, N, K, D, metric, keys, nullptr, s);
+        if (rc1) return rc1;
+    }
     VQ_CHECK_LAUNCH("exact_kernel<col>");
     finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, K, col_idx, nullptr, nullptr);
     VQ_CHECK_LAUNCH("finalize_kernel");
@@ -358,11 +373,11 @@ int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_
         int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
         if (rc0) return rc0;
     }
-    if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 2, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, nullptr, d);
-    else if (x_dtype == VQHIP_DTYPE_BF16)
-        exact_kernel<1, 2, 4><<<1024, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, nullptr, nullptr, nullptr, d);
-    else return fail(VQHIP_EINVAL, "vqhip_distance: x_dtype");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_distance: x_dtype");
+    {
+        int rc1 = run_exact_tiled<2>(x, x_dtype, e, en, xn, N, K, D, metric, nullptr, d, s);
+        if (rc1) return rc1;
+    }
     VQ_CHECK_LAUNCH("exact_kernel<dist>");
     return VQHIP_OK;
 }

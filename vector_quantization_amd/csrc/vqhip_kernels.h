@@ -1018,6 +1018,155 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
     }
 }
 
+// Whole-batch fp32 pass (argmin_exact, col_argmin, distance): a workgroup = 4 waves x 32 rows against a chunk of CT code
+// tiles.  Code tiles are staged through LDS once per workgroup (coalesced float4 loads, register prefetch of the next
+// tile, 16-byte XOR swizzle -> conflict-free ds_read_b128) and shared by the 4 waves; accumulators of all CT tiles stay
+// live so that the row fragments are loaded once per 256-dim block.  Same k-ordered fma chains as exact_kernel.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                          const float *__restrict__ en_in, const float *__restrict__ xn_in,
+                                                          int64_t N, int64_t K, int D, int metric, u64 *__restrict__ keys,
+                                                          float *__restrict__ dout) {
+    constexpr int CT = 8;                        // code tiles (32 codes) per work item
+    constexpr int DB = 128;                      // dims per register / LDS block
+    constexpr int NPRE = 32 * (DB / 4) / 256;    // 16-byte chunks of a tile per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float4 *tile = (float4 *)lds;                // [2][32 rows][DB/4 chunks], chunk index XOR (row & 15)
+    constexpr int CPR = DB / 4;                  // chunks per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrb = (N + 127) / 128;
+    const int64_t nchunks = (K + CT * 32 - 1) / (CT * 32);
+    const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < nrb * nchunks; item += gridDim.x) {
+        const int64_t rb = item / nchunks, chunk = item % nchunks;
+        const int64_t row = rb * 128 + wave * 32 + j;
+        const bool rvalid = row < N;
+        const int64_t rrow = rvalid ? row : N - 1;
+        const int64_t kbase = chunk * CT * 32;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {
+                const int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (d < D) {
+                    if (d + 3 < D && (D % 4) == 0) {
+                        if (DT == 0) {
+                            float4 t = *(const float4 *)((const float *)x + rrow * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            uint2 t = *(const uint2 *)((const uint16_t *)x + rrow * D + d);
+                            v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                            v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
+                        }
+                    } else {
+                        v0 = load_elem<DT>(x, rrow * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, rrow * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, rrow * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, rrow * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+            // staging: thread t owns the 16-byte chunks t, t+256, ... of the 32 x DB tile
+            float4 pre[NPRE];
+            auto fetch = [&](int ct) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    const int64_t k = kbase + ct * 32 + r;
+                    const int d = db + 4 * ch;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < K && d < D) {
+                        if (d + 3 < D && (D % 4) == 0) v = *(const float4 *)(e + k * D + d);
+                        else {
+                            v.x = e[k * D + d];
+                            if (d + 1 < D) v.y = e[k * D + d + 1];
+                            if (d + 2 < D) v.z = e[k * D + d + 2];
+                            if (d + 3 < D) v.w = e[k * D + d + 3];
+                        }
+                    }
+                    pre[i] = v;
+                }
+            };
+            auto stash = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    tile[(buf * 32 + r) * CPR + (ch ^ (r & 15))] = pre[i];
+                }
+            };
+            __syncthreads();            // previous block / item is done with both buffers
+            fetch(0);
+            stash(0);
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct + 1 < CT) fetch(ct + 1);
+                const float4 *trow = tile + ((ct & 1) * 32 + j) * (DB / 4);
+#pragma unroll
+                for (int q = 0; q < DB / 4; ++q) {
+                    if (db + 4 * q < D) {
+                        const float4 v = trow[q ^ (j & 15)];
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.y : v.x, xfr[2 * q], acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
+                    }
+                }
+                if (ct + 1 < CT) stash((ct + 1) & 1);
+                __syncthreads();
+            }
+        }
+
+        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? xn_in[row] : 0.0f;
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (metric == VQHIP_METRIC_L2) {
+                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = 1.0f - acc[c][q];
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+}
+
 // decode keys -> idx (+hist, +dmin).  rows = flagged list (device count) or all N
 __global__ void finalize_kernel(const u64 *keys, const int *row_list, const int *nrows_dev, int64_t N, int64_t *idx,
                                 float *dmin, int32_t *hist) {
