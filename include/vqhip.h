@@ -139,6 +139,15 @@ int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out,
 int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv,
                              void *stream);
 
+/* ---- callers either side of the path ------------------------------------------------------
+ * vqhip_transpose: in[B][R][C] -> out[B][C][R] for 2- or 4-byte elements.  With R = channels, C = h*w it is
+ *   'b c h w -> (b h w) c' (vq/tasks/image_tokenization/models/base.py:124,140); with R = h*w, C = channels the
+ *   inverse '(b h w) c -> b c h w' (base.py:126).
+ * vqhip_codebook_metrics: out[0] = nonzero(counts)/K (CodebookUsageMetric, runners/metrics.py:58-62),
+ *   out[1] = entropy of counts/sum(counts) in nats (CodebookPPLMetric, :65-73); counts int64[K], out double[2]. */
+int vqhip_transpose(const void *in, void *out, int elem_bytes, int64_t B, int R, int C, void *stream);
+int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *stream);
+
 /* ---- diagnostics ------------------------------------------------------------------------------------
  * Copies the counters of the last vqhip_argmin on `ws` to out[4] (DEVICE int32): rows given a second proposal
  * pass, rows with more than one identified candidate (re-ranked exactly), rows sent to the whole-codebook fp32

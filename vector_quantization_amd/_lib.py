@@ -40,6 +40,8 @@ SIGNATURES = {
     'vqhip_vq_backward': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_ste': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'vqhip_normalize_rows_bwd': (_i32, [_vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp]),
+    'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    'vqhip_codebook_metrics': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_argmin_stats': (_i32, [_vp, _vp, _vp]),
     'vqhip_profile_enable': (_i32, [_i32]),
     'vqhip_set_tuning': (_i32, [_i32, _i32]),

@@ -500,6 +500,26 @@ int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R
     return VQHIP_OK;
 }
 
+int vqhip_transpose(const void *in, void *out, int elem_bytes, int64_t B, int R, int C, void *stream) {
+    if (!in || !out || B < 0 || R <= 0 || C <= 0 || (elem_bytes != 2 && elem_bytes != 4))
+        return fail(VQHIP_EINVAL, "vqhip_transpose: bad argument");
+    if (B == 0) return VQHIP_OK;
+    if (B > 65535) return fail(VQHIP_EINVAL, "vqhip_transpose: batch too large for one launch");
+    dim3 grid((C + 63) / 64, (R + 63) / 64, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_bytes == 4) transpose_kernel<uint32_t><<<grid, 256, 0, s>>>((const uint32_t *)in, (uint32_t *)out, B, R, C);
+    else transpose_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t *)in, (uint16_t *)out, B, R, C);
+    VQ_CHECK_LAUNCH("transpose_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *stream) {
+    if (!counts || !out || K <= 0) return fail(VQHIP_EINVAL, "vqhip_codebook_metrics: bad argument");
+    codebook_metrics_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counts, K, out);
+    VQ_CHECK_LAUNCH("codebook_metrics_kernel");
+    return VQHIP_OK;
+}
+
 int vqhip_set_tuning(int key, int value) {
     if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops

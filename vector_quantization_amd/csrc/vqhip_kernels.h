@@ -1406,3 +1406,61 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const void *x, const f
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// callers of the path: BCHW <-> (BHW)C rearrangement and codebook metrics
+// ------------------------------------------------------------------------------------------------
+// 'b c h w -> (b h w) c' (models/base.py:124,140) as a 64x64 LDS-tiled transpose per image: in[b][c][p] -> out[b][p][c]
+// (TO_TOKENS) or the inverse '(b h w) c -> b c h w' (base.py:126).  T = 2-byte or 4-byte element.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t B, int R, int C) {
+    // in: [B][R][C] -> out: [B][C][R]
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+    const int64_t b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const T *src = in + b * (int64_t)R * C;
+    T *dst = out + b * (int64_t)R * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 4 * i][tx] = src[(int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < R && c < C) dst[(int64_t)c * R + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+// CodebookUsageMetric / CodebookPPLMetric summaries (runners/metrics.py:58-73) from the accumulated counts:
+// out[0] = #nonzero / K, out[1] = entropy of counts / sum(counts) in nats.  One block.
+__global__ __launch_bounds__(1024) void codebook_metrics_kernel(const int64_t *counts, int64_t K, double *out) {
+    __shared__ double red[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double tot = 0.0, nz = 0.0;
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) { tot += (double)counts[k]; nz += counts[k] != 0 ? 1.0 : 0.0; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_xor(tot, off, 64); nz += __shfl_xor(nz, off, 64); }
+    if (lane == 0) { red[0][wave] = tot; red[1][wave] = nz; }
+    __syncthreads();
+    tot = 0.0; nz = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { tot += red[0][i]; nz += red[1][i]; }
+    double ent = 0.0;
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
+        const double c = (double)counts[k];
+        if (c > 0.0) { const double p = c / tot; ent -= p * log(p); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ent += __shfl_xor(ent, off, 64);
+    __syncthreads();
+    if (lane == 0) red[2][wave] = ent;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) e += red[2][i];
+        out[0] = nz / (double)K;
+        out[1] = tot > 0.0 ? e : 0.0;
+    }
+}

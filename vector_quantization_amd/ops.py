@@ -317,3 +317,23 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
     check(_lib.lib().vqhip_vq_backward(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
                                        _ptr(gx), _ptr(gw), _stream()), 'vqhip_vq_backward')
     return gx, gw
+
+
+def transpose_last2(t: torch.Tensor) -> torch.Tensor:
+    """[B, R, C] -> [B, C, R] for fp32 / bf16 / fp16 tensors (the BCHW <-> (BHW)C rearrangement)."""
+    _require_cuda(t)
+    assert t.dim() == 3 and t.element_size() in (2, 4)
+    t = t.contiguous()
+    B, R, C = t.shape
+    out = torch.empty(B, C, R, dtype=t.dtype, device=t.device)
+    check(_lib.lib().vqhip_transpose(_ptr(t), _ptr(out), t.element_size(), B, R, C, _stream()), 'vqhip_transpose')
+    return out
+
+
+def codebook_metrics(counts: torch.Tensor) -> torch.Tensor:
+    """float64[2] device tensor: (usage = nonzero/K, entropy in nats) of an int64 count vector."""
+    _require_cuda(counts)
+    counts = counts.to(torch.int64).contiguous()
+    out = torch.empty(2, dtype=torch.float64, device=counts.device)
+    check(_lib.lib().vqhip_codebook_metrics(_ptr(counts), counts.numel(), _ptr(out), _stream()), 'vqhip_codebook_metrics')
+    return out
