@@ -93,8 +93,10 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', device_id=dev)
 
     from vector_quantization_amd import _lib, ops
@@ -113,7 +115,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +138,7 @@ def main():
     L.vqhip_profile_enable(0)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     loss = 1.25 * float(sse.item()) / (N * DIM)
@@ -174,7 +176,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -49,6 +49,18 @@ static void prof_end(hipStream_t s) {
     ++g_prof_used;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember what was set for (kernel, device)
+static int ensure_dyn_lds(const void *kern, size_t bytes, size_t (&set)[16]) {
+    int dev = 0;
+    VQ_HIP(hipGetDevice(&dev));
+    dev &= 15;
+    if (bytes > set[dev]) {
+        VQ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        set[dev] = bytes;
+    }
+    return VQHIP_OK;
+}
+
 static inline int waves_grid(int64_t rows, int waves_per_block) {
     return (int)((rows + waves_per_block - 1) / waves_per_block);
 }
@@ -62,11 +74,8 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
     auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static size_t lds_set[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
     prof_begin(s);
     kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np);
@@ -117,12 +126,9 @@ static int run_exact_tiled(const void *x, int x_dtype, const float *e, const flo
     constexpr int LDS = 2 * 32 * 128 * 4;
     auto k0 = exact_tiled_kernel<0, MODE>;
     auto k1 = exact_tiled_kernel<1, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        VQ_HIP(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    static size_t set0[16] = {0}, set1[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)k0, LDS, set0)) return rc;
+    if (int rc = ensure_dyn_lds((const void *)k1, LDS, set1)) return rc;
     int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
     int grid = (int)(items < 1024 ? items : 1024);
     if (x_dtype == VQHIP_DTYPE_F32) k0<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
@@ -250,14 +256,11 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
     const size_t rr_lds = per_wave * wpb;
     {
-        static size_t lds_set[4] = {0, 0, 0, 0};
+        static size_t lds_set[4][16] = {{0}};
         const void *kerns[4] = {(const void *)refine_rerank_kernel<0, 0>, (const void *)refine_rerank_kernel<1, 0>,
                                 (const void *)refine_rerank_kernel<0, 1>, (const void *)refine_rerank_kernel<1, 1>};
         for (int i = 0; i < 4; ++i)
-            if (rr_lds > lds_set[i]) {
-                VQ_HIP(hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_lds));
-                lds_set[i] = rr_lds;
-            }
+            if (int rc2 = ensure_dyn_lds(kerns[i], rr_lds, lds_set[i])) return rc2;
     }
     if (x_dtype == VQHIP_DTYPE_F32)
         refine_rerank_kernel<0, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
