@@ -123,9 +123,8 @@ def main():
         step()
     ops.hist(step()[0], K_CODES, out=hist)                # code-usage statistics outside the timed region
     L = _lib.lib()
-    for key, name in ((0, 'VQHIP_TUNE_PIPE'), (1, 'VQHIP_TUNE_PRIO'), (2, 'VQHIP_TUNE_SLICES')):   # A/B knobs (results unchanged)
-        if name in os.environ:
-            L.vqhip_set_tuning(key, int(os.environ[name]))
+    if 'VQHIP_TUNE_SLICES' in os.environ:                   # A/B knob (results unchanged): codebook slices
+        L.vqhip_set_tuning(2, int(os.environ['VQHIP_TUNE_SLICES']))
     barrier()
     L.vqhip_profile_enable(1)
     t0 = time.perf_counter()

@@ -73,8 +73,11 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
 int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
                    float *d, void *ws, void *stream);
 
-/* NearestAnchor: col_idx[k] = argmin_n d[n,k], lowest n on ties (vq/algorithms/cvqvae/anchors.py:83),
- * same arithmetic contract as vqhip_argmin_exact; never materialises d. */
+/* NearestAnchor: col_idx[k] = argmin_n d[n,k], lowest n on ties (vq/algorithms/cvqvae/anchors.py:83), same arithmetic
+ * contract as vqhip_argmin (bit-identical to the fp32 definition, operand order of the reference kept); never
+ * materialises d.  Runs the proposal + re-rank pipeline with the roles of latents and codes swapped.
+ * COS: x and e already normalised.  `ws` = vqhip_col_workspace_bytes(N, K, D). */
+int64_t vqhip_col_workspace_bytes(int64_t N, int64_t K, int D);
 int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
                      int64_t *col_idx, void *ws, void *stream);
 

@@ -275,3 +275,28 @@ def test_large_batch_many_slices_and_single_slice(ops):
     finally:
         L.vqhip_set_tuning(2, 0)
         L.vqhip_set_tuning(0, 1)
+
+
+@pytest.mark.parametrize('metric', ['L2', 'Cosine'])
+@pytest.mark.parametrize('dtype', [None, torch.bfloat16])
+def test_col_argmin_fast_path(ops, metric, dtype):
+    """NearestAnchor at a CVQ-like shape: the role-swapped proposal pipeline equals the oracle's d.argmin(0),
+    including duplicated latents (lowest token index wins) and codes nobody is near."""
+    N, K, D = 3000, 4096, 256
+    x, w = synth.make_inputs('normal', 91, N, K, D)
+    x[1500] = x[7]                       # duplicated latents: ties between token 7 and 1500
+    x[2999] = x[7]
+    w[5] = x[7]                          # a code sitting exactly on them (distance 0)
+    if dtype is not None:
+        x = synth.bf16_round(x)
+        w[5] = x[7]
+    if metric == 'Cosine':
+        xo, wo = co.normalize_rows(x), co.normalize_rows(w)
+        d_ref = co.cos_dist(x, w)
+        col = ops.col_argmin(dev(xo), dev(wo), metric)
+    else:
+        d_ref = co.l2_dist(x, w)
+        col = ops.col_argmin(dev(x, dtype), dev(w), metric)
+    ref = co.col_argmin(d_ref)
+    np.testing.assert_array_equal(col.cpu().numpy(), ref)
+    assert ref[5] == 7

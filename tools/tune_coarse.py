@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B the proposal-kernel variants in ONE process with interleaved rounds (cdna guide §5.4 rule 24).
+"""A/B the proposal-kernel slice counts in ONE process with interleaved rounds (cdna guide §5.4 rule 24).
 Prints median / min kernel milliseconds per variant (HIP events around the coarse kernel) and TFLOP/s."""
 import ctypes
 import os
@@ -19,12 +19,12 @@ g = torch.Generator(device='cuda').manual_seed(3407)
 w = torch.randn(K, D, device='cuda', generator=g)
 x = torch.randn(N, D, device='cuda', generator=g).bfloat16()
 cb = ops.prepare_codebook(w, 'L2')
-variants = [(1, 0), (0, 0)]
+variants = [(1, ns) for ns in (0, 1, 2, 4, 8)]
 ref = None
 times = {v: [] for v in variants}
 for r in range(ROUNDS + 1):
     for v in variants:
-        L.vqhip_set_tuning(0, v[0]); L.vqhip_set_tuning(2, v[1])
+        L.vqhip_set_tuning(2, v[1])
         L.vqhip_profile_enable(1)
         for _ in range(3):
             idx = ops.argmin(x, cb)
@@ -40,5 +40,5 @@ for r in range(ROUNDS + 1):
 flops = 2.0 * N * K * D
 for v in variants:
     t = np.array(times[v])
-    print(f'pipe={v[0]} nslices={v[1]}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  '
+    print(f'nslices={v[1]} (0 = automatic): median {np.median(t):.4f} ms  min {t.min():.4f} ms  '
           f'-> {flops / np.median(t) / 1e9:.0f} TFLOP/s (median)')

@@ -186,9 +186,8 @@ int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, 
     return VQHIP_OK;
 }
 
-int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
-    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS))
-        return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
+// metric may carry the internal words (VQ_METRIC_DOT, VQ_METRIC_SWAP)
+static int codebook_prepare_impl(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
     if (K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: K too large");
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
@@ -202,15 +201,19 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
     return VQHIP_OK;
 }
 
-int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
-                 int64_t *idx, int32_t *hist, void *ws, void *stream) {
-    if (N == 0) return VQHIP_OK;
-    if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
-    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
-    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
-    if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
-    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
-    if (N == 0) return VQHIP_OK;
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
+    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS))
+        return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
+    return codebook_prepare_impl(e, K, D, metric, cb, stream);
+}
+
+int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
+                       float *dmin, int32_t *hist, void *ws, void *stream);
+
+// The proposal + decision pipeline: N rows `x` against the K codes whose prepared image is `cb` and whose fp32 rows
+// (as used by the exact definition) are `e_exact`.  `metric` may carry the internal words (DOT, SWAP).
+static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, const void *cb, int64_t N, int64_t K, int D,
+                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     VqWsLayout W = vq_ws_layout(N, K, D);
@@ -222,13 +225,7 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     int *flag_list = (int *)(w + W.off_flag);
     u64 *keys = (u64 *)(w + W.off_keys);
     const float *en = (const float *)(c + L.off_en);
-    const float *e_exact = (metric == VQHIP_METRIC_COS) ? (const float *)(c + L.off_eexact) : e;
 
-    if (!vq_coarse_supported(D)) {
-        // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
-        VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
-        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
-    }
     int nslices = 1, rc;
     char *ximg = w + W.off_ximg;
     const int xgrid = (int)((N + 31) / 32);
@@ -299,6 +296,24 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
     return VQHIP_OK;
 }
 
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
+                 int64_t *idx, int32_t *hist, void *ws, void *stream) {
+    if (N == 0) return VQHIP_OK;
+    if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
+    if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
+    VqCbLayout L = vq_cb_layout(K, D);
+    const float *e_exact = (metric == VQHIP_METRIC_COS) ? (const float *)((const char *)cb + L.off_eexact) : e;
+    if (!vq_coarse_supported(D)) {
+        // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
+        VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
+        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
+    }
+    return argmin_pipeline(x, x_dtype, e_exact, cb, N, K, D, metric, idx, hist, ws, stream);
+}
+
 int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
                        float *dmin, int32_t *hist, void *ws, void *stream) {
     if (N == 0) return VQHIP_OK;
@@ -329,13 +344,47 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
     return VQHIP_OK;
 }
 
+int64_t vqhip_col_workspace_bytes(int64_t N, int64_t K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    // [pipeline workspace for K rows against N codes][image of the latents as codes][fp32 copy of bf16 latents]
+    int64_t a = (vq_ws_layout(K, N, D).total + 1023) / 1024 * 1024;
+    int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+    int64_t legacy = vq_ws_layout(N, K, D).total;        // fp32-only route (D without a proposal image)
+    int64_t t = a + b + N * (int64_t)D * 4;
+    return t > legacy ? t : legacy;
+}
+
 int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
                      int64_t *col_idx, void *ws, void *stream) {
     if (!x || !e || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_col_argmin: bad argument");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin: N or K too large");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_col_argmin: metric");
     hipStream_t s = (hipStream_t)stream;
-    VqWsLayout W = vq_ws_layout(N, K, D);
     char *w = (char *)ws;
+    if (vq_coarse_supported(D)) {
+        // Roles swapped: the K codebook rows are the "rows", the N latents are the "codes"; the same proposal + exact
+        // re-rank pipeline then returns for every code its nearest latent.  The exact finishing keeps the reference's
+        // operand order: (chain + |x_n|^2) + |e_k|^2 = (chain + code norm) + row norm  (VQ_METRIC_SWAP); cosine uses
+        // the operands as given (both normalised by the caller): VQ_METRIC_DOT.
+        const int64_t a = (vq_ws_layout(K, N, D).total + 1023) / 1024 * 1024;
+        const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+        char *pipe_ws = w, *img = w + a;
+        const float *codes = (const float *)x;
+        if (x_dtype == VQHIP_DTYPE_BF16) {
+            float *copy = (float *)(w + a + b);
+            int64_t n = N * (int64_t)D;
+            int grid = (int)((n + 255) / 256); grid = grid > 4096 ? 4096 : grid;
+            bf16_to_f32_kernel<<<grid, 256, 0, s>>>((const uint16_t *)x, n, copy);
+            VQ_CHECK_LAUNCH("bf16_to_f32_kernel");
+            codes = copy;
+        }
+        const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : VQ_METRIC_DOT;
+        int rc = codebook_prepare_impl(codes, N, D, m, img, stream);
+        if (rc) return rc;
+        return argmin_pipeline(e, VQHIP_DTYPE_F32, codes, img, K, N, D, m, col_idx, nullptr, pipe_ws, stream);
+    }
+    VqWsLayout W = vq_ws_layout(N, K, D);
     u64 *keys = (u64 *)(w + W.off_keys);
     float *en = (float *)(w + W.off_en);
     if (metric == VQHIP_METRIC_L2) {
@@ -349,12 +398,10 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
     }
     fill_u64_kernel<<<256, 256, 0, s>>>(keys, K, ~0ull);
     VQ_CHECK_LAUNCH("fill_u64_kernel");
-    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
     {
         int rc1 = run_exact_tiled<1>(x, x_dtype, e, en, xn, N, K, D, metric, keys, nullptr, s);
         if (rc1) return rc1;
     }
-    VQ_CHECK_LAUNCH("exact_kernel<col>");
     finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, K, col_idx, nullptr, nullptr);
     VQ_CHECK_LAUNCH("finalize_kernel");
     return VQHIP_OK;

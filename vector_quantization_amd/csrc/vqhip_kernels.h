@@ -14,6 +14,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
+// internal metric word: low bits = VQHIP_METRIC_L2 / _COS / VQ_METRIC_DOT (1 - x.e on operands used as given: the
+// row/column-swapped NearestAnchor pass), bit 8 = the L2 finishing adds the CODE norm first: (c + |code|^2) + |row|^2
+#define VQ_METRIC_DOT 2
+#define VQ_METRIC_SWAP 0x100
+#define VQ_IS_L2(m) (((m) & 3) == VQHIP_METRIC_L2)
+#define VQ_IS_COS(m) (((m) & 3) == VQHIP_METRIC_COS)
+#define VQ_SWAPPED(m) (((m) & VQ_METRIC_SWAP) != 0)
+
 #define VQ_F16_MIN_NORMAL 6.103515625e-05f
 #define VQ_U 5.9604644775390625e-08f /* 2^-24 */
 
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K
 #pragma unroll
         for (int c = 0; c < 4; ++c) p[c] = p[c] + __shfl_xor(p[c], off, 64);
     float m_e2 = 0.0f, m_en = 0.0f;
-    if (metric == VQHIP_METRIC_COS) {
+    if (VQ_IS_COS(metric)) {
         amax = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -199,9 +207,10 @@ __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (k0 + c >= K) continue;
-            if (lane == 0) en[k0 + c] = p[c];
+            if (lane == 0) en[k0 + c] = VQ_IS_L2(metric) ? p[c] : 0.0f;     // DOT: operands are used as given, no bias
             bad |= !isfinite(p[c]);
-            m_e2 = fmaxf(m_e2, p[c]); m_en = fmaxf(m_en, p[c]);
+            m_e2 = fmaxf(m_e2, p[c]);
+            if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, p[c]);
         }
     }
     amax = wave_max(amax);
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     const int ti = (int)(tile % L.tps);
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
     VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
-    const float *src = (metric == VQHIP_METRIC_COS) ? (const float *)(cb + L.off_eexact) : e;
+    const float *src = (VQ_IS_COS(metric)) ? (const float *)(cb + L.off_eexact) : e;
     const float *en = (const float *)(cb + L.off_en);
     // every block reduces the statistics partials (16 KiB, L2-resident) to the global maxima -> the common scale
     VqCbStats g_st;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
         a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2); a3 = wave_max(a3);
         a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4); a3 = block_max4(a3, red4);
         g_st.maxabs_bits = __float_as_uint(a0); g_st.e2max_bits = __float_as_uint(a1);
-        g_st.enmax_bits = (metric == VQHIP_METRIC_L2) ? __float_as_uint(a2) : 0u;
+        g_st.enmax_bits = (VQ_IS_L2(metric)) ? __float_as_uint(a2) : 0u;
         g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
@@ -564,7 +573,7 @@ __device__ float sqnorm_thread(const void *x, int64_t off, int D) {   // oracle 
 template <int DT>
 __device__ float oracle_distance(const void *x, int64_t xoff, const float *erow, int D, int metric, float xn, float en) {
     float c = 0.0f;
-    if (metric == VQHIP_METRIC_L2) {
+    if (VQ_IS_L2(metric)) {
         for (int d = 0; d < D; ++d) c = fmaf(-2.0f * load_elem<DT>(x, xoff + d), erow[d], c);
         float t = (c + xn) + en;
         t = (t < 0.0f) ? 0.0f : t;
@@ -597,7 +606,7 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
     float ENmax = __uint_as_float(st->enmax_bits);
     float Df = (float)Dp;
     float m;
-    if (metric == VQHIP_METRIC_L2) {
+    if (VQ_IS_L2(metric)) {
         // S: rounding slop of the fp32 definition itself (squared-distance units): the D-term fma chain, the two
         // additions and the sqrt tie window.  B: |proposal score - real score| <= fp16 residuals (Cauchy-Schwarz)
         // + fp32 MFMA accumulation + the 4 low mantissa bits that carry the register index.
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const
                 const float4 *xr = (const float4 *)xs;
                 const float4 *er = (const float4 *)(es + lane * Dq);
                 float c = 0.0f;
-                const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+                const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
 #pragma unroll 4
                 for (int q = 0; q < Dq / 4; ++q) {
                     float4 a = xr[q], bb = er[q];
@@ -844,8 +853,8 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const
                     c = fmaf(sx * a.z, bb.z, c); c = fmaf(sx * a.w, bb.w, c);
                 }
                 float dist;
-                if (metric == VQHIP_METRIC_L2) {
-                    float t = (c + xn) + en[mycode];
+                if (VQ_IS_L2(metric)) {
+                    float t = VQ_SWAPPED(metric) ? (c + en[mycode]) + xn : (c + xn) + en[mycode];
                     t = (t < 0.0f) ? 0.0f : t;
                     dist = sqrtf(t);
                 } else {
@@ -864,21 +873,6 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const
             if (hist) atomicAdd(&hist[best], 1);
         }
         __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// oracle-order |x|^2 for the rows of a device-side list (wave per row, persistent)
-template <int DT>
-__global__ __launch_bounds__(256) void row_sqnorm_list_kernel(const void *x, int D, const int *row_list, const int *nrows_dev,
-                                                              float *xn_out) {
-    const int lane = threadIdx.x & 63;
-    const int nrows = *nrows_dev;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nrows; i += gridDim.x * 4) {
-        const int64_t r = row_list[i];
-        float p = 0.0f;
-        for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(x, r * D + d); p = fmaf(a, a, p); }
-        p = wave_sum_tree(p);
-        if (lane == 0) xn_out[r] = p;
     }
 }
 
@@ -903,7 +897,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
     const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
     const int64_t ntiles = (nrows + 31) / 32;
     const int64_t nchunks = (K + CHUNK - 1) / CHUNK;
-    const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
 
     for (int64_t item = blockIdx.x; item < ntiles * nchunks; item += gridDim.x) {
         const int64_t tile = item / nchunks, chunk = item % nchunks;
@@ -919,7 +913,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
             for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
 
         // oracle-order |x|^2: precomputed for whole-batch passes, computed per lane on the (rare) last-resort path
-        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
         for (int db = 0; db < D; db += DB) {
             // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
             float xfr[DB / 2];
@@ -987,8 +981,9 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
             for (int q = 0; q < 16; ++q) {
                 const int64_t k = kbase + c * 32 + mfma_row(q, h);
                 float d;
-                if (metric == VQHIP_METRIC_L2) {
-                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                if (VQ_IS_L2(metric)) {
+                    const float enk = (k < K) ? en_in[k] : 0.0f;
+                    float t = VQ_SWAPPED(metric) ? (acc[c][q] + enk) + xn : (acc[c][q] + xn) + enk;
                     t = (t < 0.0f) ? 0.0f : t;
                     d = sqrtf(t);
                 } else {
@@ -1037,7 +1032,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
     const int j = lane & 31, h = lane >> 5;
     const int64_t nrb = (N + 127) / 128;
     const int64_t nchunks = (K + CT * 32 - 1) / (CT * 32);
-    const float sx = (metric == VQHIP_METRIC_L2) ? -2.0f : 1.0f;
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
 
     for (int64_t item = blockIdx.x; item < nrb * nchunks; item += gridDim.x) {
         const int64_t rb = item / nchunks, chunk = item % nchunks;
@@ -1129,7 +1124,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
             }
         }
 
-        const float xn = (metric == VQHIP_METRIC_L2 && rvalid) ? xn_in[row] : 0.0f;
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? xn_in[row] : 0.0f;
         u64 best = ~0ull;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -1137,7 +1132,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
             for (int q = 0; q < 16; ++q) {
                 const int64_t k = kbase + c * 32 + mfma_row(q, h);
                 float d;
-                if (metric == VQHIP_METRIC_L2) {
+                if (VQ_IS_L2(metric)) {
                     float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
                     t = (t < 0.0f) ? 0.0f : t;
                     d = sqrtf(t);
@@ -1463,4 +1458,10 @@ __global__ __launch_bounds__(1024) void codebook_metrics_kernel(const int64_t *c
         out[0] = nz / (double)K;
         out[1] = tot > 0.0 ? e : 0.0;
     }
+}
+
+// bf16 -> fp32 copy (the column pass needs the latents as an fp32 "codebook")
+__global__ void bf16_to_f32_kernel(const uint16_t *in, int64_t n, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bf16_to_f32(in[i]);
 }

@@ -144,7 +144,7 @@ def col_argmin(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     K = e.shape[0]
     L = _lib.lib()
     out = torch.empty(K, dtype=torch.int64, device=x.device)
-    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
+    ws = _bytes(L.vqhip_col_workspace_bytes(N, K, D), x.device)
     check(L.vqhip_col_argmin(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(out), _ptr(ws), _stream()),
           'vqhip_col_argmin')
     return out
