@@ -300,3 +300,28 @@ def test_col_argmin_fast_path(ops, metric, dtype):
     ref = co.col_argmin(d_ref)
     np.testing.assert_array_equal(col.cpu().numpy(), ref)
     assert ref[5] == 7
+
+
+@pytest.mark.parametrize('name,N,K,D,metric,normalize', [
+    ('C3 VQ-KD', 512 * 196, 8192, 32, 'Cosine', False),          # configs[2]: K=8192 D=32, 14x14 tokens, batch 512
+    ('C5 LlamaGen', 65536, 16384, 8, 'L2', True),                 # configs[4] reference shape: D=8 + NormalizeCallback
+])
+def test_full_size_other_configs(ops, name, N, K, D, metric, normalize):
+    """BASELINE.json configs[2] / configs[4] at full size: the proposal pipeline equals the fp32-only pass on every
+    row, the histogram has the right mass, and a row sample matches the CPU oracle."""
+    g = torch.Generator(device='cuda').manual_seed(3407)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    if normalize:
+        x, w = ops.normalize_rows(x), ops.normalize_rows(w)
+    xq = ops.normalize_rows(x) if metric == 'Cosine' else x
+    wq = ops.normalize_rows(w) if metric == 'Cosine' else w
+    cb = ops.prepare_codebook(w, metric)
+    hist = torch.zeros(K, dtype=torch.int32, device='cuda')
+    idx, st = ops.argmin(xq, cb, hist=hist, return_stats=True)
+    assert int(hist.sum()) == N
+    assert torch.equal(idx, ops.argmin_exact(xq, wq, metric))
+    rows = torch.arange(0, N, 997, device='cuda')
+    fn = co.cos_argmin if metric == 'Cosine' else co.l2_argmin
+    np.testing.assert_array_equal(idx[rows].cpu().numpy(), fn(x[rows].cpu().numpy(), w.cpu().numpy()))
+    print(f'{name}: rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])} of {N}')
