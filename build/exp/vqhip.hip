@@ -1,0 +1,601 @@
+// libvqhip — host entry points (C ABI in include/vqhip.h).  gfx950 only.
+#include "vqhip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vqhip_kernels.h"
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *what, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), "%s%s%s", what, detail[0] ? ": " : "", detail);
+    return code;
+}
+
+#define VQ_CHECK_LAUNCH(name)                                            \
+    do {                                                                 \
+        hipError_t err__ = hipGetLastError();                            \
+        if (err__ != hipSuccess) return fail(VQHIP_ELAUNCH, name, hipGetErrorString(err__)); \
+    } while (0)
+
+#define VQ_HIP(call)                                                     \
+    do {                                                                 \
+        hipError_t err__ = (call);                                       \
+        if (err__ != hipSuccess) return fail(VQHIP_ELAUNCH, #call, hipGetErrorString(err__)); \
+    } while (0)
+
+// ---- optional per-launch timing of the proposal kernel (bench.py roofline) -------------------------------
+// Events are recorded on the caller's stream right around the coarse_kernel launch; vqhip_profile_collect
+// synchronises on them.  Disabled (zero overhead) unless vqhip_profile_enable(1) was called.
+#include <vector>
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+
+static void prof_begin(hipStream_t s) {
+    if (!g_prof_on) return;
+    if (g_prof_used == g_prof_events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return; }
+        g_prof_events.emplace_back(a, b);
+    }
+    (void)hipEventRecord(g_prof_events[g_prof_used].first, s);
+}
+static void prof_end(hipStream_t s) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_prof_events[g_prof_used].second, s);
+    ++g_prof_used;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember what was set for (kernel, device)
+static int ensure_dyn_lds(const void *kern, size_t bytes, size_t (&set)[16]) {
+    int dev = 0;
+    VQ_HIP(hipGetDevice(&dev));
+    dev &= 15;
+    if (bytes > set[dev]) {
+        VQ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        set[dev] = bytes;
+    }
+    return VQHIP_OK;
+}
+
+static inline int waves_grid(int64_t rows, int waves_per_block) {
+    return (int)((rows + waves_per_block - 1) / waves_per_block);
+}
+
+// ---- proposal-pass dispatch ------------------------------------------------------------------------
+static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
+
+template <int NSTEP, int TT, int WAVES, int TPS>
+static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+                             int64_t Np, hipStream_t s) {
+    constexpr int BM = WAVES * TT * 16;
+    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS>;
+    static size_t lds_set[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
+    int64_t ntb = (N + BM - 1) / BM;
+    prof_begin(s);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np);
+    prof_end(s);
+    VQ_CHECK_LAUNCH("coarse_kernel");
+    return VQHIP_OK;
+}
+
+static int pick_slices(int64_t ntb, int64_t nstages) {
+    if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
+    // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
+    // record write-back, re-read the token image fewer times and write fewer records.  (Rows whose candidates cannot
+    // all be identified get a second proposal pass, so the number of candidate groups does not matter for speed.)
+    int64_t want = (256 + ntb - 1) / ntb;
+    int ns = 1;
+    while (ns < want && ns < VQ_MAX_SLICES) ns <<= 1;
+    while (ns > 1 && ns > nstages) ns >>= 1;
+    return ns;
+}
+
+static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
+                         int *nslices_out, hipStream_t s) {
+    const int nstep = L.nstep;
+    // small batches use fewer tokens per wave so that more workgroups exist
+    const bool small = N <= 256 * 64;
+#define VQ_CFG(NS, TT, W, TPS)                                                                      \
+    {                                                                                               \
+        int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
+        int ns = pick_slices(ntb, L.nstages);                                                       \
+        *nslices_out = ns;                                                                          \
+        return launch_coarse_cfg<NS, TT, W, TPS>(ximg, N, frag, L.nstages, ns, rec, Np, s);         \
+    }
+    switch (nstep) {
+        case 2: if (small) VQ_CFG(2, 2, 8, 4) else VQ_CFG(2, 4, 8, 4)
+        case 4: if (small) VQ_CFG(4, 2, 8, 4) else VQ_CFG(4, 4, 8, 4)
+        case 8: if (small) VQ_CFG(8, 2, 8, 4) else VQ_CFG(8, 4, 8, 4)
+        case 16: if (small) VQ_CFG(16, 2, 8, 4) else VQ_CFG(16, 4, 8, 4)
+        case 32: VQ_CFG(32, 2, 8, 2)
+        default: break;
+    }
+#undef VQ_CFG
+    return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
+}
+
+template <int MODE>
+static int run_exact_tiled(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K,
+                           int D, int metric, u64 *keys, float *dout, hipStream_t s) {
+    constexpr int LDS = 2 * 32 * 128 * 4;
+    auto k0 = exact_tiled_kernel<0, MODE>;
+    auto k1 = exact_tiled_kernel<1, MODE>;
+    static size_t set0[16] = {0}, set1[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)k0, LDS, set0)) return rc;
+    if (int rc = ensure_dyn_lds((const void *)k1, LDS, set1)) return rc;
+    int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
+    int grid = (int)(items < 1024 ? items : 1024);
+    if (x_dtype == VQHIP_DTYPE_F32) k0<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+    else k1<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+    VQ_CHECK_LAUNCH("exact_tiled_kernel");
+    return VQHIP_OK;
+}
+
+static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
+                          int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
+    // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items)
+    const int grid = 256;
+    if (x_dtype == VQHIP_DTYPE_F32)
+        exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    else
+        exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+    VQ_CHECK_LAUNCH("exact_kernel");
+    return VQHIP_OK;
+}
+
+extern "C" {
+
+int vqhip_version(void) { return VQHIP_VERSION; }
+const char *vqhip_last_error(void) { return g_err; }
+
+int64_t vqhip_codebook_bytes(int64_t K, int D) {
+    if (K <= 0 || D <= 0) return 0;
+    return vq_cb_layout(K, D).total;
+}
+
+int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D) {
+    if (N < 0 || K <= 0 || D <= 0) return 0;
+    return vq_ws_layout(N > 0 ? N : 1, K, D).total;
+}
+
+int vqhip_row_sqnorm(const void *v, int dtype, int64_t R, int D, float *out, void *stream) {
+    if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) row_sqnorm_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
+    else if (dtype == VQHIP_DTYPE_BF16) row_sqnorm_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
+    else return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: dtype");
+    VQ_CHECK_LAUNCH("row_sqnorm_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, float *out, void *stream) {
+    if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_normalize_rows: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) normalize_rows_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
+    else if (dtype == VQHIP_DTYPE_BF16) normalize_rows_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
+    else return fail(VQHIP_EINVAL, "vqhip_normalize_rows: dtype");
+    VQ_CHECK_LAUNCH("normalize_rows_kernel");
+    return VQHIP_OK;
+}
+
+// metric may carry the internal words (VQ_METRIC_DOT, VQ_METRIC_SWAP)
+static int codebook_prepare_impl(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
+    if (K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: K too large");
+    hipStream_t s = (hipStream_t)stream;
+    VqCbLayout L = vq_cb_layout(K, D);
+    char *c = (char *)cb;
+    cb_stats_kernel<<<(int)((K + 15) / 16), 256, 0, s>>>(e, K, D, metric, c, L);
+    VQ_CHECK_LAUNCH("cb_stats_kernel");
+    if (vq_coarse_supported(D)) {
+        cb_image_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(e, K, D, metric, c, L);
+        VQ_CHECK_LAUNCH("cb_image_kernel");
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
+    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS))
+        return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
+    return codebook_prepare_impl(e, K, D, metric, cb, stream);
+}
+
+int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
+                       float *dmin, int32_t *hist, void *ws, void *stream);
+
+// The proposal + decision pipeline: N rows `x` against the K codes whose prepared image is `cb` and whose fp32 rows
+// (as used by the exact definition) are `e_exact`.  `metric` may carry the internal words (DOT, SWAP).
+static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, const void *cb, int64_t N, int64_t K, int D,
+                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    VqCbLayout L = vq_cb_layout(K, D);
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    const char *c = (const char *)cb;
+    char *w = (char *)ws;
+    const int64_t Np = (N + 63) / 64 * 64;
+    int *counters = (int *)(w + W.off_counters);
+    float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *rec = (float *)(w + W.off_rec);
+    int *flag_list = (int *)(w + W.off_flag);
+    u64 *keys = (u64 *)(w + W.off_keys);
+    const float *en = (const float *)(c + L.off_en);
+
+    int nslices = 1, rc;
+    char *ximg = w + W.off_ximg;
+    const int xgrid = (int)((N + 31) / 32);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    VQ_CHECK_LAUNCH("x_prep_kernel");
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
+    if (rc) return rc;
+    const int rgrid = (int)((N + 1023) / 1024);
+    int *rescan_list = flag_list;
+    int *multi_list = (int *)(w + W.off_multi), *exact_list = (int *)(w + W.off_exact);
+    float *thr = (float *)(w + W.off_thr);
+    int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
+    switch (nslices) {
+#define VQ_DECIDE(NSL) case NSL: refine_decide_kernel<NSL><<<rgrid, 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt); break;
+        VQ_DECIDE(1) VQ_DECIDE(2) VQ_DECIDE(4) VQ_DECIDE(8) VQ_DECIDE(16)
+#undef VQ_DECIDE
+        default: return fail(VQHIP_EINVAL, "vqhip_argmin: bad slice count");
+    }
+    VQ_CHECK_LAUNCH("refine_decide_kernel");
+    // re-rank kernels: one wave per queued row; LDS per wave = (1 + VQ_RR_BATCH) rows of D floats
+    int wpb = 4;
+    size_t per_wave = (size_t)(VQ_RR_BATCH + 1) * ((D + 3) & ~3) * sizeof(float);
+    while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
+    if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
+    const size_t rr_lds = per_wave * wpb;
+    {
+        static size_t lds_set[4][16] = {{0}};
+        const void *kerns[4] = {(const void *)refine_rerank_kernel<0, 0>, (const void *)refine_rerank_kernel<1, 0>,
+                                (const void *)refine_rerank_kernel<0, 1>, (const void *)refine_rerank_kernel<1, 1>};
+        for (int i = 0; i < 4; ++i)
+            if (int rc2 = ensure_dyn_lds(kerns[i], rr_lds, lds_set[i])) return rc2;
+    }
+    if (x_dtype == VQHIP_DTYPE_F32)
+        refine_rerank_kernel<0, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
+                                                                  nullptr, nullptr);
+    else
+        refine_rerank_kernel<1, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
+                                                                  nullptr, nullptr);
+    VQ_CHECK_LAUNCH("refine_rerank_kernel");
+    // second-chance proposals for rows with a possibly unidentified candidate, then their exact re-rank
+    {
+        const char *frag = c + L.off_frag;
+        switch (L.nstep) {
+#define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<1024, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
+            VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
+#undef VQ_RESCAN
+            default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
+        }
+        VQ_CHECK_LAUNCH("rescan_kernel");
+    }
+    if (x_dtype == VQHIP_DTYPE_F32)
+        refine_rerank_kernel<0, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
+                                                                 exact_list, keys);
+    else
+        refine_rerank_kernel<1, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
+                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
+                                                                 exact_list, keys);
+    VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");
+    // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
+    rc = run_exact_rows(x, x_dtype, e_exact, en, nullptr, N, K, D, metric, exact_list, counters + 2, keys, s);
+    if (rc) return rc;
+    finalize_kernel<<<16, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
+                 int64_t *idx, int32_t *hist, void *ws, void *stream) {
+    if (N == 0) return VQHIP_OK;
+    if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
+    if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
+    VqCbLayout L = vq_cb_layout(K, D);
+    const float *e_exact = (metric == VQHIP_METRIC_COS) ? (const float *)((const char *)cb + L.off_eexact) : e;
+    if (!vq_coarse_supported(D)) {
+        // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
+        VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
+        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
+    }
+    return argmin_pipeline(x, x_dtype, e_exact, cb, N, K, D, metric, idx, hist, ws, stream);
+}
+
+int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
+                       float *dmin, int32_t *hist, void *ws, void *stream) {
+    if (N == 0) return VQHIP_OK;
+    if (!x || !e || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: bad argument");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: x_dtype");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: N or K too large");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    char *w = (char *)ws;
+    u64 *keys = (u64 *)(w + W.off_keys);
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    fill_u64_kernel<<<256, 256, 0, s>>>(keys, N, ~0ull);
+    VQ_CHECK_LAUNCH("fill_u64_kernel");
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
+    int rc = run_exact_tiled<0>(x, x_dtype, e, en, xn, N, K, D, metric, keys, nullptr, s);
+    if (rc) return rc;
+    finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, N, idx, dmin, hist);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int64_t vqhip_col_workspace_bytes(int64_t N, int64_t K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    // [pipeline workspace for K rows against N codes][image of the latents as codes][fp32 copy of bf16 latents]
+    int64_t a = (vq_ws_layout(K, N, D).total + 1023) / 1024 * 1024;
+    int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+    int64_t legacy = vq_ws_layout(N, K, D).total;        // fp32-only route (D without a proposal image)
+    int64_t t = a + b + N * (int64_t)D * 4;
+    return t > legacy ? t : legacy;
+}
+
+int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
+                     int64_t *col_idx, void *ws, void *stream) {
+    if (!x || !e || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_col_argmin: bad argument");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin: N or K too large");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_col_argmin: metric");
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)ws;
+    if (vq_coarse_supported(D)) {
+        // Roles swapped: the K codebook rows are the "rows", the N latents are the "codes"; the same proposal + exact
+        // re-rank pipeline then returns for every code its nearest latent.  The exact finishing keeps the reference's
+        // operand order: (chain + |x_n|^2) + |e_k|^2 = (chain + code norm) + row norm  (VQ_METRIC_SWAP); cosine uses
+        // the operands as given (both normalised by the caller): VQ_METRIC_DOT.
+        const int64_t a = (vq_ws_layout(K, N, D).total + 1023) / 1024 * 1024;
+        const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+        char *pipe_ws = w, *img = w + a;
+        const float *codes = (const float *)x;
+        if (x_dtype == VQHIP_DTYPE_BF16) {
+            float *copy = (float *)(w + a + b);
+            int64_t n = N * (int64_t)D;
+            int grid = (int)((n + 255) / 256); grid = grid > 4096 ? 4096 : grid;
+            bf16_to_f32_kernel<<<grid, 256, 0, s>>>((const uint16_t *)x, n, copy);
+            VQ_CHECK_LAUNCH("bf16_to_f32_kernel");
+            codes = copy;
+        }
+        const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : VQ_METRIC_DOT;
+        int rc = codebook_prepare_impl(codes, N, D, m, img, stream);
+        if (rc) return rc;
+        return argmin_pipeline(e, VQHIP_DTYPE_F32, codes, img, K, N, D, m, col_idx, nullptr, pipe_ws, stream);
+    }
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    u64 *keys = (u64 *)(w + W.off_keys);
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
+    fill_u64_kernel<<<256, 256, 0, s>>>(keys, K, ~0ull);
+    VQ_CHECK_LAUNCH("fill_u64_kernel");
+    {
+        int rc1 = run_exact_tiled<1>(x, x_dtype, e, en, xn, N, K, D, metric, keys, nullptr, s);
+        if (rc1) return rc1;
+    }
+    finalize_kernel<<<256, 256, 0, s>>>(keys, nullptr, nullptr, K, col_idx, nullptr, nullptr);
+    VQ_CHECK_LAUNCH("finalize_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, float *d, void *ws,
+                   void *stream) {
+    if (!x || !e || !d || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_distance: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    char *w = (char *)ws;
+    float *en = (float *)(w + W.off_en);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, en, stream);
+        if (rc) return rc;
+    }
+    float *xn = (float *)(w + W.off_xh2);
+    if (metric == VQHIP_METRIC_L2) {
+        int rc0 = vqhip_row_sqnorm(x, x_dtype, N, D, xn, stream);
+        if (rc0) return rc0;
+    }
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_distance: x_dtype");
+    {
+        int rc1 = run_exact_tiled<2>(x, x_dtype, e, en, xn, N, K, D, metric, nullptr, d, s);
+        if (rc1) return rc1;
+    }
+    VQ_CHECK_LAUNCH("exact_kernel<dist>");
+    return VQHIP_OK;
+}
+
+int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                          float *z_ste, double *sse, void *stream) {
+    if (!x || !e || !idx || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: bad argument");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((N + 3) / 4);
+    grid = grid > 1024 ? 1024 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32) gather_ste_loss_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_ste_loss_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
+    else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");
+    VQ_CHECK_LAUNCH("gather_ste_loss_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream) {
+    if (!idx || !hist || N < 0 || K <= 0) return fail(VQHIP_EINVAL, "vqhip_hist: bad argument");
+    if (N == 0) return VQHIP_OK;
+    int grid = (int)((N + 255) / 256); grid = grid > 2048 ? 2048 : grid;
+    hist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, N, K, hist);
+    VQ_CHECK_LAUNCH("hist_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_scatter_add_rows(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst, void *stream) {
+    if (!src || !idx || !dst || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_scatter_add_rows: bad argument");
+    if (N == 0) return VQHIP_OK;
+    scatter_add_rows_kernel<<<waves_grid(N, 4), 256, 0, (hipStream_t)stream>>>(src, idx, N, K, D, dst);
+    VQ_CHECK_LAUNCH("scatter_add_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out, void *stream) {
+    if (!x || !row_idx || !out || K < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_rows: bad argument");
+    if (K == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == VQHIP_DTYPE_F32) gather_rows_kernel<0><<<waves_grid(K, 4), 256, 0, s>>>(x, row_idx, K, D, out);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_rows_kernel<1><<<waves_grid(K, 4), 256, 0, s>>>(x, row_idx, K, D, out);
+    else return fail(VQHIP_EINVAL, "vqhip_gather_rows: x_dtype");
+    VQ_CHECK_LAUNCH("gather_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay, int centroid_only,
+                      void *stream) {
+    if (!w || !hist || !sums || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_update: bad argument");
+    vqkd_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, hist, sums, K, D, decay, centroid_only);
+    VQ_CHECK_LAUNCH("vqkd_update_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev, const float *anchors,
+                     int64_t K, int D, float ema_decay, float eps, int stage, void *stream) {
+    if (!w || !p || K <= 0 || D <= 0 || stage < 1 || stage > 3 || ((stage & 1) && (!hist || (numel <= 0 && !numel_dev))) ||
+        ((stage & 2) && !anchors)) return fail(VQHIP_EINVAL, "vqhip_cvq_update: bad argument");
+    cvq_update_kernel<<<waves_grid(K, 4), 256, 0, (hipStream_t)stream>>>(w, p, hist, numel, numel_dev, anchors, K, D, ema_decay, eps, stage);
+    VQ_CHECK_LAUNCH("cvq_update_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
+    if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
+    VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VQHIP_OK;
+}
+
+int vqhip_diff(const void *a, int a_dtype, const void *b, int b_dtype, int64_t n, float scale, const float *scale_dev,
+               float *out, double *sse, void *stream) {
+    if (!a || !b || n < 0 || (!out && !sse)) return fail(VQHIP_EINVAL, "vqhip_diff: bad argument");
+    if (n == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((n + 255) / 256); grid = grid > 2048 ? 2048 : grid;
+    if (a_dtype == 0 && b_dtype == 0) diff_kernel<0, 0><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 0 && b_dtype == 1) diff_kernel<0, 1><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 1 && b_dtype == 0) diff_kernel<1, 0><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else if (a_dtype == 1 && b_dtype == 1) diff_kernel<1, 1><<<grid, 256, 0, s>>>(a, b, n, scale, scale_dev, out, sse);
+    else return fail(VQHIP_EINVAL, "vqhip_diff: dtype");
+    VQ_CHECK_LAUNCH("diff_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, const float *g_zste,
+                      const float *g_cb, const float *g_cm, float *grad_x, float *grad_w, void *stream) {
+    if (!x || !e || !idx || N < 0 || D <= 0 || (!grad_x && !grad_w)) return fail(VQHIP_EINVAL, "vqhip_vq_backward: bad argument");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((N + 3) / 4); grid = grid > 2048 ? 2048 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32)
+        vq_backward_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+    else if (x_dtype == VQHIP_DTYPE_BF16)
+        vq_backward_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+    else return fail(VQHIP_EINVAL, "vqhip_vq_backward: x_dtype");
+    VQ_CHECK_LAUNCH("vq_backward_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream) {
+    if (!x || !z || !out || n < 0) return fail(VQHIP_EINVAL, "vqhip_ste: bad argument");
+    if (n == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((n + 255) / 256); grid = grid > 4096 ? 4096 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32) ste_kernel<0><<<grid, 256, 0, s>>>(x, z, n, out);
+    else if (x_dtype == VQHIP_DTYPE_BF16) ste_kernel<1><<<grid, 256, 0, s>>>(x, z, n, out);
+    else return fail(VQHIP_EINVAL, "vqhip_ste: dtype");
+    VQ_CHECK_LAUNCH("ste_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv, void *stream) {
+    if (!v || !g || !gv || R < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_normalize_rows_bwd: bad argument");
+    if (R == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VQHIP_DTYPE_F32) normalize_bwd_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, g, R, D, eps, gv);
+    else if (dtype == VQHIP_DTYPE_BF16) normalize_bwd_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, g, R, D, eps, gv);
+    else return fail(VQHIP_EINVAL, "vqhip_normalize_rows_bwd: dtype");
+    VQ_CHECK_LAUNCH("normalize_bwd_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_transpose(const void *in, void *out, int elem_bytes, int64_t B, int R, int C, void *stream) {
+    if (!in || !out || B < 0 || R <= 0 || C <= 0 || (elem_bytes != 2 && elem_bytes != 4))
+        return fail(VQHIP_EINVAL, "vqhip_transpose: bad argument");
+    if (B == 0) return VQHIP_OK;
+    if (B > 65535) return fail(VQHIP_EINVAL, "vqhip_transpose: batch too large for one launch");
+    dim3 grid((C + 63) / 64, (R + 63) / 64, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_bytes == 4) transpose_kernel<uint32_t><<<grid, 256, 0, s>>>((const uint32_t *)in, (uint32_t *)out, B, R, C);
+    else transpose_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t *)in, (uint16_t *)out, B, R, C);
+    VQ_CHECK_LAUNCH("transpose_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *stream) {
+    if (!counts || !out || K <= 0) return fail(VQHIP_EINVAL, "vqhip_codebook_metrics: bad argument");
+    codebook_metrics_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counts, K, out);
+    VQ_CHECK_LAUNCH("codebook_metrics_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_set_tuning(int key, int value) {
+    if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
+    else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
+    else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
+    return VQHIP_OK;
+}
+
+int vqhip_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_used = 0;
+    return VQHIP_OK;
+}
+
+int vqhip_profile_collect(double *ms_sum, int64_t *launches) {
+    if (!ms_sum || !launches) return fail(VQHIP_EINVAL, "vqhip_profile_collect: bad argument");
+    double total = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        VQ_HIP(hipEventSynchronize(g_prof_events[i].second));
+        float ms = 0.0f;
+        VQ_HIP(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+        total += ms;
+    }
+    *ms_sum = total;
+    *launches = (int64_t)g_prof_used;
+    g_prof_used = 0;
+    return VQHIP_OK;
+}
+
+}  // extern "C"

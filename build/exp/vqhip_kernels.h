@@ -1,0 +1,1472 @@
+// Device kernels of libvqhip (gfx950 / CDNA4 only — wave64, MFMA, LDS-DMA).
+//
+// Arithmetic contract: the result of every index-producing entry point is the argmin of the
+// fp32 definition evaluated with k-ordered fma chains — exactly what v_mfma_f32_32x32x2_f32 and the
+// scalar fmaf loops below compute, and what oracle/vq_oracle.c restates on the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vqhip_layout.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+// internal metric word: low bits = VQHIP_METRIC_L2 / _COS / VQ_METRIC_DOT (1 - x.e on operands used as given: the
+// row/column-swapped NearestAnchor pass), bit 8 = the L2 finishing adds the CODE norm first: (c + |code|^2) + |row|^2
+#define VQ_METRIC_DOT 2
+#define VQ_METRIC_SWAP 0x100
+#define VQ_IS_L2(m) (((m) & 3) == VQHIP_METRIC_L2)
+#define VQ_IS_COS(m) (((m) & 3) == VQHIP_METRIC_COS)
+#define VQ_SWAPPED(m) (((m) & VQ_METRIC_SWAP) != 0)
+
+#define VQ_F16_MIN_NORMAL 6.103515625e-05f
+#define VQ_U 5.9604644775390625e-08f /* 2^-24 */
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+template <int DT>
+__device__ __forceinline__ float load_elem(const void *p, int64_t i) {
+    if (DT == 0) return ((const float *)p)[i];
+    return bf16_to_f32(((const uint16_t *)p)[i]);
+}
+
+// 8 consecutive elements starting at element offset i (i % 8 == 0, rows 16/32-byte aligned)
+template <int DT>
+__device__ __forceinline__ void load8(const void *p, int64_t i, float (&v)[8]) {
+    if (DT == 0) {
+        const float4 *q = (const float4 *)((const float *)p + i);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        uint4 a = *(const uint4 *)((const uint16_t *)p + i);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xFFFF0000u);
+    }
+}
+
+
+// raw 8-element vector loads for the proposal-pass prologue (kept as integers until all are in flight)
+template <int DT> struct RawVec;
+template <> struct RawVec<0> {
+    struct type { float4 a, b; };
+    static __device__ __forceinline__ type load(const void *p, int64_t i) {
+        const float4 *q = (const float4 *)((const float *)p + i);
+        type t; t.a = q[0]; t.b = q[1]; return t;
+    }
+    static __device__ __forceinline__ void unpack(const type &t, float (&v)[8]) {
+        v[0] = t.a.x; v[1] = t.a.y; v[2] = t.a.z; v[3] = t.a.w; v[4] = t.b.x; v[5] = t.b.y; v[6] = t.b.z; v[7] = t.b.w;
+    }
+};
+template <> struct RawVec<1> {
+    typedef uint4 type;
+    static __device__ __forceinline__ type load(const void *p, int64_t i) { return *(const uint4 *)((const uint16_t *)p + i); }
+    static __device__ __forceinline__ void unpack(const type &a, float (&v)[8]) {
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xFFFF0000u);
+    }
+};
+
+// single-instruction max (hipcc otherwise wraps fmaxf on MFMA results in canonicalising v_max pairs)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// fp32 -> fp16 (RNE) with subnormal results flushed to zero, so the MFMA never sees an fp16 subnormal
+__device__ __forceinline__ _Float16 to_f16_ftz(float v) {
+    _Float16 q = (_Float16)v;
+    float b = (float)q;
+    if (fabsf(b) < VQ_F16_MIN_NORMAL) q = (_Float16)0.0f;   // NaN compares false and stays NaN
+    return q;
+}
+
+__device__ __forceinline__ float wave_sum_tree(float p) {   // halving tree 32,16,...,1 (oracle order)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+__device__ __forceinline__ float wave_max(float p) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = fmaxf(p, __shfl_xor(p, off, 64));
+    return p;
+}
+
+// power-of-two scale that maps max|e| into [2^13, 2^14)
+__device__ __forceinline__ float cb_scale(const VqCbStats *st) {
+    float m = __uint_as_float(st->maxabs_bits);
+    if (!(m > 0.0f) || st->nonfinite) return 1.0f;
+    int ex;
+    (void)frexpf(m, &ex);            // m = f * 2^ex, f in [0.5,1)
+    int sh = 14 - ex;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    return ldexpf(1.0f, sh);
+}
+
+
+// atomicMax on a hot word: read first (L2 hit), issue the atomic only when it would raise the value —
+// same-address atomics serialise at ~11 ns each, and after the first few waves the filter drops them all
+__device__ __forceinline__ void atomic_max_filtered(uint32_t *p, uint32_t v) {
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
+
+// C/D register -> row of the 32x32 MFMA tile (v_mfma_f32_32x32x2_f32, MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// row kernels: oracle-order |v|^2 and F.normalize
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void row_sqnorm_kernel(const void *v, int64_t R, int D, float *out) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    if (lane == 0) out[r] = p;
+}
+
+template <int DT>
+__global__ void normalize_rows_kernel(const void *v, int64_t R, int D, float eps, float *out) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p);
+    float den = (nrm < eps) ? eps : nrm;
+    for (int d = lane; d < D; d += 64) out[r * D + d] = load_elem<DT>(v, r * D + d) / den;
+}
+
+// ------------------------------------------------------------------------------------------------
+// codebook preparation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_max4(float v, float *red) {    // max over the 4 waves of a 256-thread block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
+// The four rows of a wave are loaded together and reduced with interleaved shuffle trees; maxima are reduced per
+// block and written as one partial per block (same-line atomics from ~1000 concurrent blocks cost ~25 us).
+__global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    float *en = (float *)(cb + L.off_en);
+    float *ex = (float *)(cb + L.off_eexact);
+    const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    float p[4] = {0, 0, 0, 0}, amax = 0.0f;
+    bool bad = false;
+    for (int d = lane; d < D; d += 64) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = (k0 + c < K) ? e[(k0 + c) * D + d] : 0.0f;
+            p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = p[c] + __shfl_xor(p[c], off, 64);
+    float m_e2 = 0.0f, m_en = 0.0f;
+    if (VQ_IS_COS(metric)) {
+        amax = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + c >= K) continue;
+            float nrm = sqrtf(p[c]);
+            float den = (nrm < 1e-12f) ? 1e-12f : nrm;
+            float q2 = 0.0f;
+            for (int d = lane; d < D; d += 64) {
+                float a = e[(k0 + c) * D + d] / den;
+                ex[(k0 + c) * D + d] = a;
+                amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+            }
+            q2 = wave_sum_tree(q2);
+            bad |= !isfinite(q2);
+            m_e2 = fmaxf(m_e2, q2);
+            if (lane == 0) en[k0 + c] = 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + c >= K) continue;
+            if (lane == 0) en[k0 + c] = VQ_IS_L2(metric) ? p[c] : 0.0f;     // DOT: operands are used as given, no bias
+            bad |= !isfinite(p[c]);
+            m_e2 = fmaxf(m_e2, p[c]);
+            if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, p[c]);
+        }
+    }
+    amax = wave_max(amax);
+    bad = __any(bad);
+    amax = block_max4(amax, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
+    float badf = block_max4(bad ? 1.0f : 0.0f, red);
+    // per-block partial result; reduced by every block of cb_image_kernel (no hot-word atomics, no memset)
+    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part1))[blockIdx.x] = f32x4{amax, m_e2, m_en, badf};
+    (void)st;
+}
+
+// pass 2 (one 256-thread block per tile of 32 codes): the MFMA-fragment-major fp16 image, the aux chunk, and the fp16
+// residual / image norms with the final scale.
+// chunk (tile T, k-step s of 32 dims, half c) holds, for lane l, code T*32 + 16c + (l&15), dims 32s + 8(l>>4) .. +8 —
+// exactly the A operand of v_mfma_f32_16x16x32_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
+__global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    __shared__ float red[2][8][32];
+    __shared__ float red4[4];
+    const int64_t tile = blockIdx.x;
+    const int64_t stage = tile / L.tps;
+    const int ti = (int)(tile % L.tps);
+    const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    const float *src = (VQ_IS_COS(metric)) ? (const float *)(cb + L.off_eexact) : e;
+    const float *en = (const float *)(cb + L.off_en);
+    // every block reduces the statistics partials (16 KiB, L2-resident) to the global maxima -> the common scale
+    VqCbStats g_st;
+    {
+        const f32x4 *part = (const f32x4 *)(cb + L.off_part1);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int64_t i = threadIdx.x; i < L.nblk1; i += 256) {
+            f32x4 v = part[i];
+            a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]); a3 = fmaxf(a3, v[3]);
+        }
+        a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2); a3 = wave_max(a3);
+        a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4); a3 = block_max4(a3, red4);
+        g_st.maxabs_bits = __float_as_uint(a0); g_st.e2max_bits = __float_as_uint(a1);
+        g_st.enmax_bits = (VQ_IS_L2(metric)) ? __float_as_uint(a2) : 0u;
+        g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
+            st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 0u;
+            st->r2max_bits = 0u; st->eh2max_bits = 0u;
+        }
+    }
+    const float se = cb_scale(&g_st), inv = 1.0f / se;
+    const int64_t k = tile * VQ_TILE_CODES + r;
+    char *stage_base = cb + L.off_frag + stage * L.stage_bytes;
+    float r2 = 0.0f, h2 = 0.0f;
+    // pieces of 8 dims: k-step of 32 dims s32 = piece/4, quarter q4 = piece%4; the tile's two 16-code halves go
+    // to chunks (s32, 0) and (s32, 1); within a chunk lane = q4*16 + (code & 15)
+    for (int piece = g; piece < L.nstep * 2; piece += 8) {
+        const int s = piece >> 2, q4 = piece & 3;
+        const int d0 = 32 * s + 8 * q4;
+        half8 o;
+        if (k < K && d0 < D) {
+            float v[8];
+            if (d0 + 8 <= D && (D % 4) == 0) { load8<0>(src, k * D + d0, v); }
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 q = to_f16_ftz(v[j] * se);
+                float back = (float)q * inv, res = v[j] - back;
+                r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+                o[j] = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+        }
+        *(half8 *)(stage_base + (int64_t)(ti * L.nstep + 2 * s + (r >> 4)) * VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = o;
+    }
+    // aux chunk slice of this tile: -se*|e_k|^2/2 for its 32 codes (padded codes: a large FINITE negative score;
+    // -inf with the register index or-ed into its mantissa would be a signalling NaN and poison v_max_f32)
+    if (g == 0) {
+        float v = (k < K) ? (-0.5f * en[k]) * se : -3.0e38f;
+        *(float *)(stage_base + (int64_t)L.tps * L.nstep * VQ_CHUNK_BYTES + (ti * 32 + r) * 4) = v;
+    }
+    red[0][g][r] = r2; red[1][g][r] = h2;
+    __syncthreads();
+    float a = 0.0f, b = 0.0f;
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += red[0][i][r]; b += red[1][i][r]; }
+    }
+    bool bad = !isfinite(a) || !isfinite(b);
+    a = wave_max(a); b = wave_max(b);       // waves 1..3 contribute zeros
+    a = block_max4(a, red4); b = block_max4(b, red4);
+    float badf = block_max4(__any(bad) ? 1.0f : 0.0f, red4);
+    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part2))[blockIdx.x] = f32x4{a, b, badf, 0.0f};
+}
+
+// Folds the image kernel's per-block partials into the statistics header (run by block 0 of the first kernel of every
+// consumer call; idempotent).
+__device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L, float *red4) {
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    const f32x4 *part = (const f32x4 *)(cb + L.off_part2);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int64_t i = threadIdx.x; i < L.nblk2; i += blockDim.x) {
+        f32x4 v = part[i];
+        a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]);
+    }
+    a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2);
+    a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4);
+    if (threadIdx.x == 0) {
+        st->r2max_bits = __float_as_uint(a0); st->eh2max_bits = __float_as_uint(a1);
+        if (a2 > 0.0f) st->nonfinite = 1u;
+        st->finalized = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token preparation: fp16 (flush-to-zero) fragment-major image of x, |xh|^2 and |x - xh|^2 per row
+// ------------------------------------------------------------------------------------------------
+// One 256-thread block per 32 tokens.  Image chunk (tile of 16 tokens, k-step s of 32 dims) holds for lane l the dims
+// 32s + 8(l>>4) .. +8 of token tile*16 + (l&15): the B operand of v_mfma_f32_16x16x32_f16.
+template <int DT>
+__global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
+                                                     char *__restrict__ ximg, float *__restrict__ xh2,
+                                                     float *__restrict__ rho2, int *__restrict__ counters, char *cb,
+                                                     VqCbLayout L) {
+    __shared__ float red[2][8][32];
+    __shared__ float red4[4];
+    if (blockIdx.x == 0) {   // housekeeping for the later kernels of this call (stream-ordered)
+        if (threadIdx.x < 8) counters[threadIdx.x] = 0;
+        cb_finalize_stats(cb, L, red4);
+    }
+    const int64_t blk = blockIdx.x;
+    const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t t = blk * 32 + r;
+    const bool tvalid = t < N;
+    const int64_t trow = tvalid ? t : (N - 1);
+    const int ns32 = nstep >> 1;
+    float s_h = 0.0f, s_r = 0.0f;
+    for (int piece = g; piece < ns32 * 4; piece += 8) {
+        const int s = piece >> 2, q4 = piece & 3;
+        const int d0 = 32 * s + 8 * q4;
+        half8 f;
+        if (tvalid && d0 < D) {
+            float v[8];
+            load8<DT>(x, trow * D + d0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 q = to_f16_ftz(v[j]);
+                float b = (float)q, res = v[j] - b;
+                s_h = fmaf(b, b, s_h); s_r = fmaf(res, res, s_r);
+                f[j] = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (_Float16)0.0f;
+        }
+        *(half8 *)(ximg + ((blk * 2 + (r >> 4)) * ns32 + s) * (int64_t)VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = f;
+    }
+    red[0][g][r] = s_h; red[1][g][r] = s_r;
+    __syncthreads();
+    if (g == 0 && tvalid) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a += red[0][i][r]; b += red[1][i][r]; }
+        xh2[t] = a; rho2[t] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 MFMA proposal pass
+// ------------------------------------------------------------------------------------------------
+struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
+
+__device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
+    if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }
+    else if (v > t.v2) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = v; t.c2 = c; }
+    else t.v3 = fmaxf(t.v3, v);
+}
+
+__device__ __forceinline__ void top_merge_lane(Top2 &t, int xor_mask) {   // fold the partner lane's record into t
+    Top2 o;
+    o.v1 = __shfl_xor(t.v1, xor_mask, 64); o.v2 = __shfl_xor(t.v2, xor_mask, 64); o.v3 = __shfl_xor(t.v3, xor_mask, 64);
+    o.c1 = __shfl_xor(t.c1, xor_mask, 64); o.c2 = __shfl_xor(t.c2, xor_mask, 64);
+    if (o.c1 != 0xFFFFFFFFu) top_insert(t, o.v1, o.c1);
+    if (o.c2 != 0xFFFFFFFFu) top_insert(t, o.v2, o.c2);
+    t.v3 = fmaxf(t.v3, o.v3);
+}
+
+// code row inside a 32-code tile for accumulator element e = 4*c + reg of lane l (v_mfma_f32_16x16x32: row = 4(l>>4)+reg)
+__device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); }
+
+// One workgroup = WAVES waves x TT token tiles of 16 tokens held in registers as MFMA B fragments for the whole kernel;
+// it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds, one stage ahead) and
+// keeps, per lane and token, the best score with its tile / register and the runner-up value.
+// Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
+// MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
+// The epilogue of tile t-1 (3 VALU per element) is spread over the MFMAs of tile t (two accumulator sets ping-pong).
+template <int NSTEP, int TT, int WAVES, int TPS>
+__global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
+    const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
+    float *__restrict__ rec, int64_t Np) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(NSTEP % 2 == 0 && TPS % 2 == 0, "16x16x32 layout: 32-dim k-steps, ping-pong by tile parity");
+    constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
+    constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage (2 per k-step and tile, + aux)
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int BM = WAVES * TT * 16;
+    constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = blockIdx.x % nslices;
+    const int64_t tb = blockIdx.x / nslices;
+    const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
+    const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image
+
+    // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
+    half8 xf[TT][NS32];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        int64_t tt = tb * (BM / 16) + wave * TT + t;
+        tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
+        const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+    }
+
+    float b1[TT], b2[TT];
+    uint32_t t1[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; t1[t] = 0; }
+
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+
+    if (st0 < st1) issue_stage(st0, 0);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+
+    f32x4 accA[2][TT], accB[2][TT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accB[c][t][q] = -3.0e38f;   // "previous tile" of the very first tile: never wins
+
+    for (int64_t st = st0; st < st1; ++st) {
+        const int buf = (int)((st - st0) & 1);
+        if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+        const char *base = lds + buf * STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x4 (&cur)[2][TT] = (ti & 1) ? accB : accA;
+            f32x4 (&prv)[2][TT] = (ti & 1) ? accA : accB;
+            // accumulator init = -se*|e|^2/2 of this lane's code rows 16c + 4(l>>4) + {0..3}
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) cur[c][t] = a4;
+            }
+            uint32_t old[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) old[t] = __float_as_uint(b1[t]);
+            // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets);
+            // chunk ch = 2*s32 + c feeds the TT MFMAs of code half c at k-step s32
+            constexpr int PF = 1;
+            half8 af[PF + 1];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+            for (int ch = 0; ch < NSTEP; ++ch) {
+                if (ch + PF < NSTEP)
+                    af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
+                constexpr int TOTAL = NE * TT;
+#pragma unroll
+                for (int i = 0; i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                    const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % (NSTEP / TOTAL) == 0) ? ch / (NSTEP / TOTAL) : -1);
+                    if (id >= 0 && id < TOTAL) {
+                        const int t = id / NE, e = id % NE;
+#ifdef VQ_EXPERIMENT_NO_EPI
+                        if (e == 0) { float v = prv[0][t][0]; b1[t] = vmax(b1[t], v); }   // keep the accumulators alive
+                        else asm volatile("" :: "v"(prv[e >> 2][t][e & 3]));
+#else
+                        float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+#endif
+                    }
+                }
+            }
+            const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
+        }
+        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+    }
+    // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
+    if (st1 > st0) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t old = __float_as_uint(b1[t]);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                float v = __uint_as_float((__float_as_uint(accB[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                b1[t] = vmax(b1[t], v);
+            }
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
+    }
+
+    // ---- merge the four lanes that share a token; lanes 0..15 write one record per (token, slice) ----
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        Top2 r; r.v1 = r.v2 = r.v3 = -INFINITY; r.c1 = r.c2 = 0xFFFFFFFFu;
+        {
+            uint32_t bits = __float_as_uint(b1[t]);
+            uint32_t code = t1[t] * 32u + (uint32_t)tile_row16((int)(bits & 7u), lane);
+            if (b1[t] > -INFINITY) top_insert(r, b1[t], code);
+            r.v3 = fmaxf(r.v3, b2[t]);
+        }
+        top_merge_lane(r, 16);
+        top_merge_lane(r, 32);
+        const int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+        if (lane < 16 && tokn < N) {
+            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
+            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
+            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scalar evaluation (refine)
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ float sqnorm_thread(const void *x, int64_t off, int D) {   // oracle order, one thread
+    float p[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) p[j] = 0.0f;
+    for (int base = 0; base < D; base += 64) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            if (base + j < D) { float a = load_elem<DT>(x, off + base + j); p[j] = fmaf(a, a, p[j]); }
+    }
+#pragma unroll
+    for (int off2 = 32; off2 >= 1; off2 >>= 1)
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < off2) p[j] = p[j] + p[j + off2];
+    return p[0];
+}
+
+template <int DT>
+__device__ float oracle_distance(const void *x, int64_t xoff, const float *erow, int D, int metric, float xn, float en) {
+    float c = 0.0f;
+    if (VQ_IS_L2(metric)) {
+        for (int d = 0; d < D; ++d) c = fmaf(-2.0f * load_elem<DT>(x, xoff + d), erow[d], c);
+        float t = (c + xn) + en;
+        t = (t < 0.0f) ? 0.0f : t;
+        return sqrtf(t);
+    }
+    for (int d = 0; d < D; ++d) c = fmaf(load_elem<DT>(x, xoff + d), erow[d], c);
+    return 1.0f - c;
+}
+
+// torch.argmin order on (distance, index): NaN first, then smaller distance, then smaller index
+__device__ __forceinline__ u64 dist_key(float d, uint32_t k) {
+    if (isnan(d)) return (u64)k;
+    if (d == 0.0f) d = 0.0f;                 // -0 and +0 tie (lowest index wins), as in torch.argmin
+    uint32_t b = __float_as_uint(d);
+    // distances are >= 0 for L2; COS distances may be slightly negative: make the map monotone for both signs
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((u64)b + 1ull) << 32 | (u64)k;      // b+1 <= 2^32 : fits in the upper 33 bits
+}
+
+// Rigorous per-row margin (in scaled score units) between the proposal score and the fp32 definition.
+// Returns a negative value when the bound cannot be formed (non-finite data): the row is then flagged.
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2) {
+    if (st->nonfinite != 0 || !isfinite(X2) || !isfinite(R2)) return -1.0f;
+    const float infl = 1.0f + 1e-5f;
+    float se = cb_scale(st);
+    float Xh = sqrtf(X2) * infl, rho = sqrtf(R2) * infl, Xn = Xh + rho;
+    float Emax = sqrtf(__uint_as_float(st->e2max_bits)) * infl;
+    float Rmax = sqrtf(__uint_as_float(st->r2max_bits)) * infl;
+    float Ehmax = sqrtf(__uint_as_float(st->eh2max_bits)) * infl;
+    float ENmax = __uint_as_float(st->enmax_bits);
+    float Df = (float)Dp;
+    float m;
+    if (VQ_IS_L2(metric)) {
+        // S: rounding slop of the fp32 definition itself (squared-distance units): the D-term fma chain, the two
+        // additions and the sqrt tie window.  B: |proposal score - real score| <= fp16 residuals (Cauchy-Schwarz)
+        // + fp32 MFMA accumulation + the 4 low mantissa bits that carry the register index.
+        float mag = Xn * Xn + ENmax + 2.0f * Xn * Emax;
+        if (!(mag < 1e30f)) return -1.0f;
+        float S = 2.0f * (1.01f * Df * VQ_U * 2.0f * Xn * Emax + 2.1f * VQ_U * mag) + 4.0f * VQ_U * mag;
+        float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax + 0.5f * ENmax);
+        m = 2.0f * B + 0.5f * S;
+    } else {
+        float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax);
+        m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
+    }
+    m = m * se * infl + 1e-37f;
+    return isfinite(m) ? m : -1.0f;
+}
+
+#define VQ_RESCAN_CAP 32     // candidate slots per rescanned row
+
+// thread per token: merge the slice records under the margin.  Outcomes:
+//   one candidate                         -> idx written here
+//   several identified candidates         -> multi_list   (exact re-rank of those candidates)
+//   an unidentified candidate may exist   -> rescan_list  (second proposal pass that emits every score >= thr)
+//   no usable bound (non-finite data)     -> exact_list   (whole-codebook fp32 pass)
+// counters: [0] rescan rows, [1] multi rows, [2] exact rows
+template <int NSL>
+__global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
+                                     const float *xh2, const float *rho2, int64_t Np, int64_t *idx, int32_t *hist,
+                                     int *rescan_list, int *multi_list, int *exact_list, int *counters, u64 *keys,
+                                     float *thr_out, int *rescan_cnt) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool oob = n >= N;
+    if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+    bool invalid = !(m > 0.0f);
+    // NSL = compile-time slice count: all record loads are issued together
+    float v1[NSL], v2[NSL], v3[NSL], c1[NSL];
+    (void)nslices;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+        const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+        v1[s] = rp[0]; c1[s] = rp[Np]; v2[s] = rp[2 * Np]; v3[s] = rp[4 * Np];
+    }
+    float gbest = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
+    if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
+    const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
+    int nc = 0;
+    bool unidentified = false;
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+        if (v3[s] >= thr) unidentified = true;
+        if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
+        if (v2[s] >= thr) ++nc;
+    }
+    // block-aggregated list appends: one atomic per 1024-thread block and list (the three counters are hot words:
+    // ~8-11 ns per same-address atomic, so per-wave appends from 1024 waves cost ~15 us)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool to_exact = !oob && (invalid || nc == 0);
+    const bool to_rescan = !oob && !to_exact && unidentified;
+    const bool to_multi = !oob && !to_exact && !to_rescan && nc > 1;
+    __shared__ int wcount[3][16];
+    __shared__ int wbase[3][16];
+    const u64 mk_e = __ballot(to_exact), mk_r = __ballot(to_rescan), mk_m = __ballot(to_multi);
+    if (lane == 0) { wcount[0][wave] = __popcll(mk_r); wcount[1][wave] = __popcll(mk_m); wcount[2][wave] = __popcll(mk_e); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int tot = 0;
+        const int nw = blockDim.x >> 6;
+        for (int i = 0; i < nw; ++i) { wbase[threadIdx.x][i] = tot; tot += wcount[threadIdx.x][i]; }
+        const int base = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+        for (int i = 0; i < nw; ++i) wbase[threadIdx.x][i] += base;
+    }
+    __syncthreads();
+    const u64 below = (1ull << lane) - 1ull;
+    if (to_exact) { exact_list[wbase[2][wave] + __popcll(mk_e & below)] = (int)n; keys[n] = ~0ull; }
+    if (to_rescan) { int pos = wbase[0][wave] + __popcll(mk_r & below); rescan_list[pos] = (int)n; rescan_cnt[pos] = 0; thr_out[n] = thr; }
+    if (to_multi) multi_list[wbase[1][wave] + __popcll(mk_m & below)] = (int)n;
+    if (oob) return;
+    if (!to_exact && !to_rescan && !to_multi) {
+        idx[n] = (int64_t)best;
+        if (hist) atomicAdd(&hist[best], 1);
+    }
+}
+
+// Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
+// operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
+// candidate list.  One wave per (64 queued rows, codebook stage); fragments come straight from the L2-resident images,
+// each A chunk feeds four MFMAs.
+template <int NSTEP, int TPS>
+__global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
+                                                     int64_t nstages, const int *__restrict__ rescan_list,
+                                                     const int *__restrict__ counters, const float *__restrict__ thr,
+                                                     int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+    constexpr int NS32 = NSTEP / 2;
+    constexpr int NCH = TPS * NSTEP + 1;
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int TR = (NSTEP <= 16) ? 4 : 2;            // 16-row sub-tiles per item (register budget at D=512)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrows = counters[0];
+    const int64_t ngroups = (nrows + 16 * TR - 1) / (16 * TR);
+    const int64_t nitems = ngroups * nstages;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
+        const int64_t fg = item / nstages, st = item % nstages;
+        half8 xf[TR][NS32];
+        float mythr[TR];
+        int slot[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            slot[t] = (int)(fg * 16 * TR + t * 16 + (lane & 15));
+            const bool valid = slot[t] < nrows;
+            const int64_t tk = rescan_list[valid ? slot[t] : 0];
+            mythr[t] = valid ? thr[tk] : INFINITY;
+            const char *xsrc = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
+#pragma unroll
+            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
+        }
+        const char *base = frag + st * (int64_t)STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+#pragma unroll 2
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x4 acc[2][TR];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+#pragma unroll
+                for (int t = 0; t < TR; ++t) acc[c][t] = a4;
+            }
+#pragma unroll
+            for (int ch = 0; ch < NSTEP; ++ch) {
+                half8 a = *(const half8 *)(base + (ti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+                    acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
+            }
+            uint32_t hits = 0;      // bit 8t + e
+#pragma unroll
+            for (int t = 0; t < TR; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+            if (__any(hits != 0)) {
+                while (hits) {
+                    const int b = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const int t = b >> 3, e = b & 7;
+                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
+                    int sl_t = slot[0];
+#pragma unroll
+                    for (int i = 1; i < TR; ++i) sl_t = (t == i) ? slot[i] : sl_t;
+                    const int pos = atomicAdd(&rescan_cnt[sl_t], 1);
+                    if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)sl_t * VQ_RESCAN_CAP + pos] = (int)code;
+                }
+            }
+        }
+    }
+}
+
+// wave per queued row (persistent): exact fp32 evaluation of its candidates.  The row and (up to VQ_RR_BATCH at
+// a time) candidate code rows are staged in LDS with coalesced loads; lane j then runs the fma chain of the j-th
+// candidate in d order.
+#define VQ_RR_BATCH 8
+template <int DT, int SRC>
+__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const float *e_exact, const char *cb,
+                                                            VqCbLayout L, int D, int metric, int nslices,
+                                                            const float *rec, const float *xh2, const float *rho2,
+                                                            int64_t Np, int64_t *idx, int32_t *hist,
+                                                            const int *multi_list, int *counters,
+                                                            const int *rescan_cnt, const int *cand_list, int *exact_list,
+                                                            u64 *keys) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int Dq = (D + 3) & ~3;                                  // rows padded to 16 bytes
+    float *xs = (float *)lds + (size_t)wave * (VQ_RR_BATCH + 1) * Dq;   // [Dq] row, then [BATCH][Dq] candidate rows
+    float *es = xs + Dq;
+    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const float *en = (const float *)(cb + L.off_en);
+    const int nrows = counters[SRC == 0 ? 1 : 0];
+    for (int item = blockIdx.x * nwaves + wave; item < nrows; item += gridDim.x * nwaves) {
+        const int64_t n = multi_list[item];
+        bool cand;
+        uint32_t code = 0xFFFFFFFFu;
+        if (SRC == 0) {
+            // lane i < 2*nslices owns candidate slot (slice i/2, field i%2) of the proposal records
+            const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+            float v = -INFINITY;
+            if (lane < 2 * nslices) {
+                const float *rp = rec + (int64_t)(lane >> 1) * VQ_REC_FIELDS * Np + n;
+                v = rp[(2 * (lane & 1)) * Np];
+                code = __float_as_uint(rp[(2 * (lane & 1) + 1) * Np]);
+            }
+            const float gbest = wave_max((lane & 1) ? -INFINITY : v);
+            cand = (lane < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
+        } else {
+            // rescanned row: lane j owns the j-th emitted candidate; an overflowing list goes to the fp32 pass
+            const int cnt = rescan_cnt[item];
+            if (cnt > VQ_RESCAN_CAP || cnt <= 0) {
+                if (lane == 0) {
+                    int pos = atomicAdd(&counters[2], 1);
+                    exact_list[pos] = (int)n;
+                    keys[n] = ~0ull;
+                }
+                continue;
+            }
+            cand = lane < cnt;
+            if (cand) code = (uint32_t)cand_list[(int64_t)item * VQ_RESCAN_CAP + lane];
+        }
+        u64 cmask = __ballot(cand);
+        const int ncand = __popcll(cmask);
+        // stage x (oracle-order |x|^2 on the way)
+        float p = 0.0f;
+        for (int d = lane; d < Dq; d += 64) {
+            float a = d < D ? load_elem<DT>(x, n * D + d) : 0.0f;
+            xs[d] = a; p = fmaf(a, a, p);
+        }
+        const float xn = wave_sum_tree(p);
+        u64 key = ~0ull;
+        for (int b0 = 0; b0 < ncand; b0 += VQ_RR_BATCH) {
+            // j-th candidate of this batch = (b0+j)-th set bit of cmask
+            uint32_t mycode = 0xFFFFFFFFu;
+            u64 mm = cmask;
+            for (int j = 0; j < VQ_RR_BATCH && mm; ++j) {
+                const int src = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const uint32_t k = __shfl(code, src, 64);
+                if (lane == j) mycode = k;
+                const float *er = e_exact + (int64_t)k * D;
+                for (int d = lane; d < Dq; d += 64) es[j * Dq + d] = d < D ? er[d] : 0.0f;
+            }
+            cmask = mm;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mycode != 0xFFFFFFFFu) {
+                const float4 *xr = (const float4 *)xs;
+                const float4 *er = (const float4 *)(es + lane * Dq);
+                float c = 0.0f;
+                const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+#pragma unroll 4
+                for (int q = 0; q < Dq / 4; ++q) {
+                    float4 a = xr[q], bb = er[q];
+                    c = fmaf(sx * a.x, bb.x, c); c = fmaf(sx * a.y, bb.y, c);
+                    c = fmaf(sx * a.z, bb.z, c); c = fmaf(sx * a.w, bb.w, c);
+                }
+                float dist;
+                if (VQ_IS_L2(metric)) {
+                    float t = VQ_SWAPPED(metric) ? (c + en[mycode]) + xn : (c + xn) + en[mycode];
+                    t = (t < 0.0f) ? 0.0f : t;
+                    dist = sqrtf(t);
+                } else {
+                    dist = 1.0f - c;
+                }
+                u64 kk = dist_key(dist, mycode);
+                key = kk < key ? kk : key;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { u64 o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
+        if (lane == 0) {
+            const uint32_t best = (uint32_t)(key & 0xFFFFFFFFull);
+            idx[n] = (int64_t)best;
+            if (hist) atomicAdd(&hist[best], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32 MFMA pass (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain)
+// ------------------------------------------------------------------------------------------------
+// MODE 0: row argmin via 64-bit atomicMin keys[row]; MODE 1: column argmin keys[code]; MODE 2: store d[N,K]
+// Work item = (tile of 32 rows, chunk of 4*CT*32 codes); persistent grid-stride loop over items.
+template <int DT, int MODE, int CT>
+__global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                    const float *__restrict__ en_in,
+                                                    const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
+                                                    int metric, const int *__restrict__ row_list,
+                                                    const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
+                                                    float *__restrict__ dout) {
+    // CT = code tiles (32 codes) per wave: 4 for whole-batch passes, 1 when only a few flagged rows need the
+    // whole codebook (more, smaller work items)
+    constexpr int DB = 256;                     // dims per register block
+    constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    const int64_t ntiles = (nrows + 31) / 32;
+    const int64_t nchunks = (K + CHUNK - 1) / CHUNK;
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < ntiles * nchunks; item += gridDim.x) {
+        const int64_t tile = item / nchunks, chunk = item % nchunks;
+        const int64_t slot = tile * 32 + j;
+        const bool rvalid = slot < nrows;
+        const int64_t row = rvalid ? (row_list ? (int64_t)row_list[slot] : slot) : 0;
+        const int64_t kbase = chunk * CHUNK + (int64_t)wave * CT * 32;
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        // oracle-order |x|^2: precomputed for whole-batch passes, computed per lane on the (rare) last-resort path
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {      // 4 consecutive dims per load
+                int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (rvalid && d < D) {
+                    if (DT == 0) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)((const float *)x + row * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            v0 = load_elem<DT>(x, row * D + d);
+                            if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                            if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                            if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                        }
+                    } else if (d + 3 < D && (D % 4) == 0) {
+                        uint2 t = *(const uint2 *)((const uint16_t *)x + row * D + d);
+                        v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                        v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
+                    } else {
+                        v0 = load_elem<DT>(x, row * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int64_t k = kbase + c * 32 + j;         // this lane's A row (code)
+                const bool kvalid = k < K;
+                const float *erow = e + (kvalid ? k : 0) * D;
+#pragma unroll
+                for (int s4 = 0; s4 < DB / 4; ++s4) {
+                    int d = db + 4 * s4;
+                    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (d < D) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)(erow + d);
+                            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
+                        } else {
+                            a0 = erow[d];
+                            if (d + 1 < D) a1 = erow[d + 1];
+                            if (d + 2 < D) a2 = erow[d + 2];
+                            if (d + 3 < D) a3 = erow[d + 3];
+                        }
+                        if (!kvalid) { a0 = a1 = a2 = a3 = 0.0f; }
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1 : a0, xfr[2 * s4], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a3 : a2, xfr[2 * s4 + 1], acc[c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // epilogue: C[code row][token col j]
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (VQ_IS_L2(metric)) {
+                    const float enk = (k < K) ? en_in[k] : 0.0f;
+                    float t = VQ_SWAPPED(metric) ? (acc[c][q] + enk) + xn : (acc[c][q] + xn) + enk;
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = 1.0f - acc[c][q];
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    // column argmin: reduce over the 32 token lanes of this half, one atomic per code
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+}
+
+// Whole-batch fp32 pass (argmin_exact, col_argmin, distance): a workgroup = 4 waves x 32 rows against a chunk of CT code
+// tiles.  Code tiles are staged through LDS once per workgroup (coalesced float4 loads, register prefetch of the next
+// tile, 16-byte XOR swizzle -> conflict-free ds_read_b128) and shared by the 4 waves; accumulators of all CT tiles stay
+// live so that the row fragments are loaded once per 256-dim block.  Same k-ordered fma chains as exact_kernel.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                          const float *__restrict__ en_in, const float *__restrict__ xn_in,
+                                                          int64_t N, int64_t K, int D, int metric, u64 *__restrict__ keys,
+                                                          float *__restrict__ dout) {
+    constexpr int CT = 8;                        // code tiles (32 codes) per work item
+    constexpr int DB = 128;                      // dims per register / LDS block
+    constexpr int NPRE = 32 * (DB / 4) / 256;    // 16-byte chunks of a tile per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float4 *tile = (float4 *)lds;                // [2][32 rows][DB/4 chunks], chunk index XOR (row & 15)
+    constexpr int CPR = DB / 4;                  // chunks per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrb = (N + 127) / 128;
+    const int64_t nchunks = (K + CT * 32 - 1) / (CT * 32);
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < nrb * nchunks; item += gridDim.x) {
+        const int64_t rb = item / nchunks, chunk = item % nchunks;
+        const int64_t row = rb * 128 + wave * 32 + j;
+        const bool rvalid = row < N;
+        const int64_t rrow = rvalid ? row : N - 1;
+        const int64_t kbase = chunk * CT * 32;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {
+                const int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (d < D) {
+                    if (d + 3 < D && (D % 4) == 0) {
+                        if (DT == 0) {
+                            float4 t = *(const float4 *)((const float *)x + rrow * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            uint2 t = *(const uint2 *)((const uint16_t *)x + rrow * D + d);
+                            v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                            v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
+                        }
+                    } else {
+                        v0 = load_elem<DT>(x, rrow * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, rrow * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, rrow * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, rrow * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+            // staging: thread t owns the 16-byte chunks t, t+256, ... of the 32 x DB tile
+            float4 pre[NPRE];
+            auto fetch = [&](int ct) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    const int64_t k = kbase + ct * 32 + r;
+                    const int d = db + 4 * ch;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < K && d < D) {
+                        if (d + 3 < D && (D % 4) == 0) v = *(const float4 *)(e + k * D + d);
+                        else {
+                            v.x = e[k * D + d];
+                            if (d + 1 < D) v.y = e[k * D + d + 1];
+                            if (d + 2 < D) v.z = e[k * D + d + 2];
+                            if (d + 3 < D) v.w = e[k * D + d + 3];
+                        }
+                    }
+                    pre[i] = v;
+                }
+            };
+            auto stash = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    tile[(buf * 32 + r) * CPR + (ch ^ (r & 15))] = pre[i];
+                }
+            };
+            __syncthreads();            // previous block / item is done with both buffers
+            fetch(0);
+            stash(0);
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct + 1 < CT) fetch(ct + 1);
+                const float4 *trow = tile + ((ct & 1) * 32 + j) * (DB / 4);
+#pragma unroll
+                for (int q = 0; q < DB / 4; ++q) {
+                    if (db + 4 * q < D) {
+                        const float4 v = trow[q ^ (j & 15)];
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.y : v.x, xfr[2 * q], acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
+                    }
+                }
+                if (ct + 1 < CT) stash((ct + 1) & 1);
+                __syncthreads();
+            }
+        }
+
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? xn_in[row] : 0.0f;
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (VQ_IS_L2(metric)) {
+                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = 1.0f - acc[c][q];
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+}
+
+// decode keys -> idx (+hist, +dmin).  rows = flagged list (device count) or all N
+__global__ void finalize_kernel(const u64 *keys, const int *row_list, const int *nrows_dev, int64_t N, int64_t *idx,
+                                float *dmin, int32_t *hist) {
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = row_list ? (int64_t)row_list[i] : i;
+        u64 key = keys[row];
+        uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
+        idx[row] = (int64_t)k;
+        if (hist) atomicAdd(&hist[k], 1);
+        if (dmin) {
+            u64 hi = key >> 32;
+            float d;
+            if (hi == 0) d = __uint_as_float(0x7FC00000u);
+            else {
+                uint32_t b = (uint32_t)(hi - 1ull);
+                b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+                d = __uint_as_float(b);
+            }
+            dmin[row] = d;
+        }
+    }
+}
+
+__global__ void fill_u64_kernel(u64 *p, int64_t n, u64 v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode / STE / loss partial sums, histogram, scatter-add, gathers, codebook updates
+// ------------------------------------------------------------------------------------------------
+// wave per token row, 4 elements (16 B) per lane and step, grid-stride over rows:
+// z = e[idx], z_ste = x + (z - x), sse += (z-x)^2 (fp32 within a lane's 4 elements, double across; one atomic per block)
+template <int DT>
+__global__ __launch_bounds__(256) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
+                                                              int D, float *z, float *zste, double *sse) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    const bool vec = (D % 4) == 0;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const float *er = e + idx[n] * D;
+        if (vec) {
+            for (int d = lane * 4; d < D; d += 256) {
+                float4 zv = *(const float4 *)(er + d);
+                float xv[4];
+                if (DT == 0) {
+                    float4 t = *(const float4 *)((const float *)x + n * D + d);
+                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                } else {
+                    uint2 t = *(const uint2 *)((const uint16_t *)x + n * D + d);
+                    xv[0] = __uint_as_float(t.x << 16); xv[1] = __uint_as_float(t.x & 0xFFFF0000u);
+                    xv[2] = __uint_as_float(t.y << 16); xv[3] = __uint_as_float(t.y & 0xFFFF0000u);
+                }
+                float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
+                if (z) *(float4 *)(z + n * D + d) = zv;
+                if (zste) *(float4 *)(zste + n * D + d) = make_float4(xv[0] + d0, xv[1] + d1, xv[2] + d2, xv[3] + d3);
+                s += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                float xv = load_elem<DT>(x, n * D + d), zv = er[d];
+                float df = zv - xv;
+                if (z) z[n * D + d] = zv;
+                if (zste) zste[n * D + d] = xv + df;
+                s += (double)(df * df);
+            }
+        }
+    }
+    if (sse) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+__global__ void hist_kernel(const int64_t *idx, int64_t N, int64_t K, int32_t *hist) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k = idx[i];
+        if (k >= 0 && k < K) atomicAdd(&hist[k], 1);
+    }
+}
+
+// wave per source row; lanes sweep the row so each atomic wave-instruction adds 256 contiguous bytes
+__global__ void scatter_add_rows_kernel(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst) {
+    int64_t n = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    int64_t k = idx[n];
+    if (k < 0 || k >= K) return;
+    for (int d = lane; d < D; d += 64) atomicAdd(&dst[k * D + d], src[n * D + d]);
+}
+
+template <int DT>
+__global__ void gather_rows_kernel(const void *x, const int64_t *row_idx, int64_t K, int D, float *out) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int64_t n = row_idx[k];
+    for (int d = lane; d < D; d += 64) out[k * D + d] = load_elem<DT>(x, n * D + d);
+}
+
+// VQ-KD codebook update, wave per code (callbacks.py:66-70,126-128,73-75)
+__global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *sums, int64_t K, int D, float decay,
+                                   int centroid_only) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    int64_t occ = hist[k];
+    float cnt = (float)(occ > 0 ? occ : 1);
+    if (centroid_only) {   // VQKDCallback._kmeans alone (callbacks.py:66-70): where(occurred, sums/count, w)
+        if (occ > 0)
+            for (int d = lane; d < D; d += 64) w[k * D + d] = sums[k * D + d] / cnt;
+        return;
+    }
+    // c = where(occurred, sums / max(count,1), w); then normalize
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        p = fmaf(c, c, p);
+    }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p), den = (nrm < 1e-12f) ? 1e-12f : nrm;
+    float om = 1.0f - decay;
+    float q = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        c = c / den;
+        float v = w[k * D + d] * decay + c * om;       // todd.utils.ema
+        q = fmaf(v, v, q);
+    }
+    q = wave_sum_tree(q);
+    float nrm2 = sqrtf(q), den2 = (nrm2 < 1e-12f) ? 1e-12f : nrm2;
+    for (int d = lane; d < D; d += 64) {
+        float c = (occ > 0) ? sums[k * D + d] / cnt : w[k * D + d];
+        c = c / den;
+        float v = w[k * D + d] * decay + c * om;
+        w[k * D + d] = v / den2;
+    }
+}
+
+// CVQ-VAE update, wave per code (quantizer_callback.py:94-102)
+__global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
+                                  const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage) {
+    int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    // stage bit 0: p = ema(p, hist/numel); stage bit 1: w = ema(w, anchors, decay(p))
+    float pk = p[k];
+    if (stage & 1) {
+        if (numel_dev) numel = *numel_dev;      // all-reduced token count left on the device (no host sync)
+        float freq = (float)hist[k] / (float)numel;
+        pk = pk * ema_decay + freq * (1.0f - ema_decay);
+    }
+    if (stage & 2) {
+        float decay = 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
+        float om = 1.0f - decay;
+        for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors[k * D + d] * om;
+    }
+    if (lane == 0 && (stage & 1)) p[k] = pk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise pieces of the autograd path (losses.py:50,62; utils/ste.py:10; F.normalize backward)
+// ------------------------------------------------------------------------------------------------
+// sse += sum (a-b)^2 (double accumulation across lanes/blocks), optional out = (a-b)*scale
+template <int DTA, int DTB>
+__global__ __launch_bounds__(256) void diff_kernel(const void *a, const void *b, int64_t n, float scale,
+                                                   const float *scale_dev, float *out, double *sse) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    if (scale_dev) scale *= *scale_dev;          // upstream scalar gradient left on the device
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float df = load_elem<DTA>(a, i) - load_elem<DTB>(b, i);
+        if (out) out[i] = df * scale;
+        s += (double)(df * df);
+    }
+    if (sse) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// out = x + (z - x)
+template <int DT>
+__global__ void ste_kernel(const void *x, const float *z, int64_t n, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float xv = load_elem<DT>(x, i);
+        out[i] = xv + (z[i] - xv);
+    }
+}
+
+// backward of y = v / max(|v|, eps) per row: gv = (g - y*(y.g)) / max(|v|, eps)   (rows with |v| < eps: g / eps)
+template <int DT>
+__global__ void normalize_bwd_kernel(const void *v, const float *g, int64_t R, int D, float eps, float *gv) {
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float p = 0.0f;
+    for (int d = lane; d < D; d += 64) { float a = load_elem<DT>(v, r * D + d); p = fmaf(a, a, p); }
+    p = wave_sum_tree(p);
+    float nrm = sqrtf(p);
+    bool clamped = nrm < eps;
+    float den = clamped ? eps : nrm;
+    float dot = 0.0f;
+    for (int d = lane; d < D; d += 64) dot = fmaf(load_elem<DT>(v, r * D + d) / den, g[r * D + d], dot);
+    dot = wave_sum_tree(dot);
+    for (int d = lane; d < D; d += 64) {
+        float y = load_elem<DT>(v, r * D + d) / den;
+        gv[r * D + d] = clamped ? g[r * D + d] / den : (g[r * D + d] - y * dot) / den;
+    }
+}
+
+// fused backward of the quantizer forward, z = W[idx], z_ste = x + sg(z - x), m_cb = mse(z, sg x), m_cm = mse(sg z, x):
+//   grad_x = g_zste + g_cm*(2/ND)*(x - z)        grad_W[idx] += g_cb*(2/ND)*(z - x)
+// wave per token row; g_cb / g_cm are device scalars (upstream gradients of the two MSE values), nullable = 0.
+template <int DT>
+__global__ __launch_bounds__(256) void vq_backward_kernel(const void *x, const float *e, const int64_t *idx, int64_t N, int D,
+                                                          const float *g_zste, const float *g_cb, const float *g_cm,
+                                                          float *grad_x, float *grad_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float s = 2.0f / ((float)N * (float)D);
+    const float kx = (g_cm ? *g_cm : 0.0f) * s, kw = (g_cb ? *g_cb : 0.0f) * s;
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+        const int64_t k = idx[n];
+        for (int d = lane; d < D; d += 64) {
+            float xv = load_elem<DT>(x, n * D + d), zv = e[k * D + d];
+            float df = zv - xv;
+            if (grad_x) grad_x[n * D + d] = (g_zste ? g_zste[n * D + d] : 0.0f) - kx * df;
+            if (grad_w && kw != 0.0f) atomicAdd(&grad_w[k * D + d], kw * df);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// callers of the path: BCHW <-> (BHW)C rearrangement and codebook metrics
+// ------------------------------------------------------------------------------------------------
+// 'b c h w -> (b h w) c' (models/base.py:124,140) as a 64x64 LDS-tiled transpose per image: in[b][c][p] -> out[b][p][c]
+// (TO_TOKENS) or the inverse '(b h w) c -> b c h w' (base.py:126).  T = 2-byte or 4-byte element.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t B, int R, int C) {
+    // in: [B][R][C] -> out: [B][C][R]
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+    const int64_t b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const T *src = in + b * (int64_t)R * C;
+    T *dst = out + b * (int64_t)R * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 4 * i][tx] = src[(int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < R && c < C) dst[(int64_t)c * R + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+// CodebookUsageMetric / CodebookPPLMetric summaries (runners/metrics.py:58-73) from the accumulated counts:
+// out[0] = #nonzero / K, out[1] = entropy of counts / sum(counts) in nats.  One block.
+__global__ __launch_bounds__(1024) void codebook_metrics_kernel(const int64_t *counts, int64_t K, double *out) {
+    __shared__ double red[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double tot = 0.0, nz = 0.0;
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) { tot += (double)counts[k]; nz += counts[k] != 0 ? 1.0 : 0.0; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { tot += __shfl_xor(tot, off, 64); nz += __shfl_xor(nz, off, 64); }
+    if (lane == 0) { red[0][wave] = tot; red[1][wave] = nz; }
+    __syncthreads();
+    tot = 0.0; nz = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { tot += red[0][i]; nz += red[1][i]; }
+    double ent = 0.0;
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
+        const double c = (double)counts[k];
+        if (c > 0.0) { const double p = c / tot; ent -= p * log(p); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ent += __shfl_xor(ent, off, 64);
+    __syncthreads();
+    if (lane == 0) red[2][wave] = ent;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double e = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) e += red[2][i];
+        out[0] = nz / (double)K;
+        out[1] = tot > 0.0 ? e : 0.0;
+    }
+}
+
+// bf16 -> fp32 copy (the column pass needs the latents as an fp32 "codebook")
+__global__ void bf16_to_f32_kernel(const uint16_t *in, int64_t n, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bf16_to_f32(in[i]);
+}
