@@ -124,6 +124,37 @@ def _cvq_rank(rank, world):
     return w_new
 
 
+def _cvq_sync_rank(rank, world):
+    """NearestAnchor(sync=True) (configs/cluster/model.py:28): latents / matrix / quant are all-gathered, every rank
+    computes the same global anchors (anchors.py:50-57) — no averaging."""
+    from vector_quantization_amd.quantizers.anchors import NearestAnchor
+    from vector_quantization_amd.utils import is_sync
+    g = np.load(os.path.join(GOLDEN, 'update_cvq_l2.npz'))
+    spec = json.loads(str(g['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    half = N // 2
+    xr = x[rank * half:(rank + 1) * half]          # contiguous shards: the gathered order equals the original order
+    d = co.l2_dist(xr, w)
+
+    class OracleNearest(NearestAnchor):
+        def _anchors(self, x, e, d, quant, p, memo):
+            idx = co.col_argmin(d.numpy())
+            return torch.from_numpy(x.numpy()[idx]), memo
+
+    anchors, _ = OracleNearest(sync=True)(torch.from_numpy(xr), torch.from_numpy(w), torch.from_numpy(d),
+                                          torch.from_numpy(co.row_argmin(d)), torch.zeros(K))
+    assert is_sync(anchors)
+    np.testing.assert_array_equal(anchors.numpy(), x[g['col_idx'].astype(np.int64)])   # == single-process result
+    return anchors.numpy()
+
+
+def test_cvq_sync_anchor_gloo():
+    a, b = _run(_cvq_sync_rank)
+    np.testing.assert_array_equal(a, b)
+
+
 def test_cvq_two_rank_update_gloo():
     a, b = _run(_cvq_rank)
     np.testing.assert_array_equal(a, b)
