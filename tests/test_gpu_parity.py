@@ -358,3 +358,54 @@ def test_hip_graph_capture_and_replay(ops):
     ref2 = co.l2_argmin(x2, w)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref2)
     np.testing.assert_array_equal(zs.cpu().numpy(), co.gather_ste(x2, w, ref2)[1])
+
+
+def test_mass_duplicates_overflow_to_fp32_pass(ops):
+    """Hundreds of identical codes (dead codes collapsed on one point, as after a bad k-means init): every duplicate is a
+    candidate, the per-row candidate list overflows, and the last-resort fp32 pass must return the LOWEST duplicate."""
+    N, K, D = 512, 2048, 64
+    x, w = synth.make_inputs('normal', 13, N, K, D)
+    dup = np.arange(300, 300 + 400)
+    w[dup] = w[300]                                  # 400 copies of code 300
+    x[:64] = w[300] + 0.01 * x[:64]                  # 64 tokens right next to it
+    ref = co.l2_argmin(x, w)
+    assert (ref[:64] == 300).all()
+    cb = ops.prepare_codebook(dev(w), 'L2')
+    idx, st = ops.argmin(dev(x), cb, return_stats=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    assert int(st[2]) >= 64, f'expected the duplicated rows in the fp32 pass, stats={st.tolist()}'
+    # cosine + histogram through the same path
+    refc = co.cos_argmin(x, w)
+    cbc = ops.prepare_codebook(dev(w), 'Cosine')
+    hist = torch.zeros(K, dtype=torch.int32, device='cuda')
+    idxc = ops.argmin(ops.normalize_rows(dev(x)), cbc, hist=hist)
+    np.testing.assert_array_equal(idxc.cpu().numpy(), refc)
+    np.testing.assert_array_equal(hist.cpu().numpy().astype(np.int64), co.bincount(refc, K))
+
+
+def test_randomised_shapes_sweep(ops):
+    """Random (N, K, D, metric, dtype, distribution) draws against the oracle: ragged tiles, tiny codebooks, duplicated
+    rows, scaled data."""
+    g = synth.rng(2024)
+    kinds = ['normal', 'planted', 'vqgan_init', 'int', 'unit']
+    for trial in range(24):
+        N = int(g.integers(1, 600))
+        K = int(g.integers(1, 900))
+        D = int(g.choice([8, 16, 24, 32, 40, 64, 96, 128, 200, 256]))
+        metric = 'L2' if g.random() < 0.6 else 'Cosine'
+        kind = kinds[int(g.integers(0, len(kinds)))]
+        x, w = synth.make_inputs(kind, 500 + trial, N, K, D)
+        scale = float(10.0 ** g.integers(-3, 4))
+        x, w = (x * np.float32(scale)).astype(np.float32), (w * np.float32(scale)).astype(np.float32)
+        bf16 = g.random() < 0.3
+        if bf16:
+            x = synth.bf16_round(x)
+        if metric == 'Cosine':
+            ref = co.cos_argmin(x, w)
+            xq = ops.normalize_rows(dev(x, torch.bfloat16 if bf16 else None))
+        else:
+            ref = co.l2_argmin(x, w)
+            xq = dev(x, torch.bfloat16 if bf16 else None)
+        cb = ops.prepare_codebook(dev(w), metric)
+        got = ops.argmin(xq, cb).cpu().numpy()
+        assert np.array_equal(got, ref), f'trial {trial}: N={N} K={K} D={D} {metric} {kind} scale={scale} bf16={bf16}'
