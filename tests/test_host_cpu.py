@@ -89,3 +89,13 @@ def test_no_cpu_fallback():
         q(torch.zeros(4, 16), {})
     with pytest.raises(_lib.VqhipError):
         q.decode(torch.zeros(4, dtype=torch.long), {})
+
+
+def test_integration_table_names_exist():
+    """Every class INTEGRATION.md promises to register exists under the reference's name."""
+    from vector_quantization_amd import integration
+    for names in integration.REPLACED.values():
+        for n in names:
+            assert hasattr(Q, n), n
+    with pytest.raises(ImportError):           # the reference package is not in this image
+        integration.register_into_reference()
