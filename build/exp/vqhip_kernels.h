@@ -488,8 +488,12 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                 if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
             for (int ch = 0; ch < NSTEP; ++ch) {
+#ifdef VQ_EXPERIMENT_NO_LDS
+                if (ch + PF < NSTEP) af[(ch + PF) % (PF + 1)] = af[ch % (PF + 1)];
+#else
                 if (ch + PF < NSTEP)
                     af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+#endif
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
                     cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                     if (id >= 0 && id < TOTAL) {
                         const int t = id / NE, e = id % NE;
 #ifdef VQ_EXPERIMENT_NO_EPI
-                        if (e == 0) { float v = prv[0][t][0]; b1[t] = vmax(b1[t], v); }   // keep the accumulators alive
+                        if (e == 0) { float v = prv[0][t][0]; b1[t] = vmax(b1[t], v); }
                         else asm volatile("" :: "v"(prv[e >> 2][t][e & 3]));
 #else
                         float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
