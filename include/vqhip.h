@@ -157,6 +157,13 @@ int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *
  * pass, reserved. */
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream);
 
+/* Verification aid: scores[N*K] = the fp16-MFMA proposal score of every (row, code) pair (same operands and
+ * instruction sequence as the production kernels), margin[N] = the per-row margin the decision step uses (scaled
+ * score units, negative = no usable bound), scale[1] = the power-of-two codebook scale.  A test checks the error
+ * bound |score - exact score| <= margin/2 against float64. */
+int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int64_t N, int64_t K, int D, int metric,
+                                float *scores, float *margin, float *scale, void *ws, void *stream);
+
 /* Per-launch timing of the proposal (distance+argmin) kernel with HIP events recorded on the caller's stream
  * around that launch (bench.py's roofline leg).  enable(1) starts collecting, collect() synchronises on the
  * recorded events, returns the summed kernel milliseconds and launch count (HOST pointers) and resets. */

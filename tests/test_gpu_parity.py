@@ -409,3 +409,30 @@ def test_randomised_shapes_sweep(ops):
         cb = ops.prepare_codebook(dev(w), metric)
         got = ops.argmin(xq, cb).cpu().numpy()
         assert np.array_equal(got, ref), f'trial {trial}: N={N} K={K} D={D} {metric} {kind} scale={scale} bf16={bf16}'
+
+
+@pytest.mark.parametrize('kind,metric,scale', [('normal', 'L2', 1.0), ('normal', 'Cosine', 1.0), ('vqgan_init', 'L2', 1.0),
+                                                ('normal', 'L2', 1e-3), ('normal', 'L2', 300.0), ('planted', 'L2', 1.0)])
+def test_margin_holds(ops, kind, metric, scale):
+    """The rigorous error bound behind the exactness claim, checked directly: for EVERY (row, code) pair the fp16-MFMA
+    proposal score is within margin/2 of the exact (float64) score, with slack to spare."""
+    N, K, D = 256, 2048, 256
+    x, w = synth.make_inputs(kind, 31, N, K, D)
+    x, w = (x * np.float32(scale)).astype(np.float32), (w * np.float32(scale)).astype(np.float32)
+    if metric == 'Cosine':
+        xe, we = co.normalize_rows(x), co.normalize_rows(w)
+        en = np.zeros(K, np.float64)
+        xq = dev(xe)
+    else:
+        xe, we = x, w
+        en = co.row_sqnorm(w).astype(np.float64)
+        xq = dev(x)
+    cb = ops.prepare_codebook(dev(w), metric)
+    scores, margin, se = ops.debug_proposal_scores(xq, cb)
+    scores, margin, se = scores.cpu().numpy().astype(np.float64), margin.cpu().numpy().astype(np.float64), float(se.item())
+    exact = se * (xe.astype(np.float64) @ we.astype(np.float64).T - 0.5 * en[None, :])
+    err = np.abs(scores - exact).max(1)
+    assert (margin > 0).all()
+    ratio = err / (0.5 * margin)
+    assert ratio.max() <= 1.0, f'error exceeds the bound: max ratio {ratio.max():.3f}'
+    print(f'{kind}/{metric}/x{scale}: max |score error| / (margin/2) = {ratio.max():.4f} (median {np.median(ratio):.4f})')

@@ -44,6 +44,7 @@ SIGNATURES = {
     'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vqhip_codebook_metrics': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_argmin_stats': (_i32, [_vp, _vp, _vp]),
+    'vqhip_debug_proposal_scores': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_profile_enable': (_i32, [_i32]),
     'vqhip_set_tuning': (_i32, [_i32, _i32]),
     'vqhip_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

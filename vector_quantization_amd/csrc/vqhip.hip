@@ -570,6 +570,36 @@ int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *
     return VQHIP_OK;
 }
 
+int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int64_t N, int64_t K, int D, int metric,
+                                float *scores, float *margin, float *scale, void *ws, void *stream) {
+    if (!x || !cb || !scores || !margin || !scale || !ws || N <= 0 || K <= 0 || !vq_coarse_supported(D))
+        return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    VqCbLayout L = vq_cb_layout(K, D);
+    VqWsLayout W = vq_ws_layout(N, K, D);
+    const char *c = (const char *)cb;
+    char *w = (char *)ws;
+    int *counters = (int *)(w + W.off_counters);
+    float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2);
+    char *ximg = w + W.off_ximg;
+    const int xgrid = (int)((N + 31) / 32);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    else if (x_dtype == VQHIP_DTYPE_BF16) x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    else return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: x_dtype");
+    VQ_CHECK_LAUNCH("x_prep_kernel");
+    const char *frag = c + L.off_frag;
+    switch (L.nstep) {
+#define VQ_DBG(NS, TPS) case NS: debug_scores_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, N, K, scores); break;
+        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, 4) VQ_DBG(32, 2)
+#undef VQ_DBG
+        default: return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: unsupported padded D");
+    }
+    VQ_CHECK_LAUNCH("debug_scores_kernel");
+    debug_margin_kernel<<<(int)((N + 255) / 256), 256, 0, s>>>(c, L, N, metric, xh2, rho2, margin, scale);
+    VQ_CHECK_LAUNCH("debug_margin_kernel");
+    return VQHIP_OK;
+}
+
 int vqhip_set_tuning(int key, int value) {
     if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops

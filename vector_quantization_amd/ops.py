@@ -337,3 +337,18 @@ def codebook_metrics(counts: torch.Tensor) -> torch.Tensor:
     out = torch.empty(2, dtype=torch.float64, device=counts.device)
     check(_lib.lib().vqhip_codebook_metrics(_ptr(counts), counts.numel(), _ptr(out), _stream()), 'vqhip_codebook_metrics')
     return out
+
+
+def debug_proposal_scores(x: torch.Tensor, cb: PreparedCodebook):
+    """(scores[N, K], margin[N], scale) of the fp16 proposal pass — verification aid for the error-bound tests."""
+    _require_cuda(x)
+    x, dt = _latents(x)
+    N, D = x.shape
+    L = _lib.lib()
+    scores = torch.empty(N, cb.K, dtype=torch.float32, device=x.device)
+    margin = torch.empty(N, dtype=torch.float32, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = _bytes(L.vqhip_workspace_bytes(N, cb.K, D), x.device)
+    check(L.vqhip_debug_proposal_scores(_ptr(x), dt, _ptr(cb.image), N, cb.K, D, cb.metric, _ptr(scores), _ptr(margin),
+                                        _ptr(scale), _ptr(ws), _stream()), 'vqhip_debug_proposal_scores')
+    return scores, margin, scale
