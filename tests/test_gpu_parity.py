@@ -242,10 +242,11 @@ def test_empty_and_ragged(ops):
         np.testing.assert_array_equal(ops.argmin(dev(x), cb).cpu().numpy(), co.l2_argmin(x, w.cpu().numpy()))
 
 
-@pytest.mark.parametrize('D', [8, 16, 24, 64, 128, 512, 768])
+@pytest.mark.parametrize('D', [8, 12, 16, 24, 64, 128, 512, 520, 640, 768, 776, 1024, 1032])
 @pytest.mark.parametrize('metric', ['L2', 'Cosine'])
 def test_all_supported_dims(ops, D, metric):
-    """Every padded-D instantiation of the proposal kernel (k-steps 1..32) and the fp32-only route (D=768)."""
+    """Every padded-D instantiation of the proposal kernel (k-steps of 16: 2..32 pipelined, 48 and 64 with one tile per
+    stage) and the fp32-only route (D % 8 != 0 or D > 1024)."""
     N, K = 700, 1500
     x, w = synth.make_inputs('normal', 100 + D, N, K, D)
     if metric == 'Cosine':
@@ -413,10 +414,10 @@ def test_randomised_shapes_sweep(ops):
 
 @pytest.mark.parametrize('kind,metric,scale', [('normal', 'L2', 1.0), ('normal', 'Cosine', 1.0), ('vqgan_init', 'L2', 1.0),
                                                 ('normal', 'L2', 1e-3), ('normal', 'L2', 300.0), ('planted', 'L2', 1.0)])
-def test_margin_holds(ops, kind, metric, scale):
+def test_margin_holds(ops, kind, metric, scale, D=256):
     """The rigorous error bound behind the exactness claim, checked directly: for EVERY (row, code) pair the fp16-MFMA
     proposal score is within margin/2 of the exact (float64) score, with slack to spare."""
-    N, K, D = 256, 2048, 256
+    N, K = 256, 2048
     x, w = synth.make_inputs(kind, 31, N, K, D)
     x, w = (x * np.float32(scale)).astype(np.float32), (w * np.float32(scale)).astype(np.float32)
     if metric == 'Cosine':
@@ -436,3 +437,22 @@ def test_margin_holds(ops, kind, metric, scale):
     ratio = err / (0.5 * margin)
     assert ratio.max() <= 1.0, f'error exceeds the bound: max ratio {ratio.max():.3f}'
     print(f'{kind}/{metric}/x{scale}: max |score error| / (margin/2) = {ratio.max():.4f} (median {np.median(ratio):.4f})')
+
+
+@pytest.mark.parametrize('D', [32, 768, 1024])
+def test_margin_holds_other_dims(ops, D):
+    test_margin_holds(ops, 'normal', 'L2', 1.0, D=D)
+    test_margin_holds(ops, 'normal', 'Cosine', 1.0, D=D)
+
+
+def test_cluster_shape_d768(ops):
+    """configs/cluster (CLIP/DINO/MAE/ViT features, D=768, K=8192, cosine, NearestAnchor): proposal path at 48 k-steps,
+    row and column argmin against the oracle."""
+    N, K, D = 1024, 8192, 768
+    x, w = synth.make_inputs('normal', 768, N, K, D)
+    xo, wo = co.normalize_rows(x), co.normalize_rows(w)
+    cb = ops.prepare_codebook(dev(w), 'Cosine')
+    idx = ops.argmin(dev(xo), cb)
+    np.testing.assert_array_equal(idx.cpu().numpy(), co.cos_argmin(x, w))
+    col = ops.col_argmin(dev(xo), dev(wo), 'Cosine')
+    np.testing.assert_array_equal(col.cpu().numpy(), co.col_argmin(co.cos_dist(x, w)))

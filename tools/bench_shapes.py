@@ -32,7 +32,10 @@ shape('C2 VQGAN 256 img fp32 x', 65536, 16384, 256, 'L2')
 shape('C3 VQ-KD cosine', 100352, 8192, 32, 'Cosine')
 shape('C4 CVQ cosine per-rank', 3072, 16384, 256, 'Cosine')
 shape('C5 LlamaGen D=8 normalize+L2', 65536, 16384, 8, 'L2', normalize=True)
-shape('cluster D=768 (fp32 route)', 8192, 8192, 768, 'Cosine')
+shape('cluster D=768 cosine', 8192, 8192, 768, 'Cosine')
+shape('cluster D=768 cosine, 64k rows', 65536, 8192, 768, 'Cosine')
+shape('D=1024 L2', 65536, 8192, 1024, 'L2')
+shape('D=1032 (fp32 route)', 8192, 8192, 1032, 'L2')
 # training-step pieces (per-rank C4 shape)
 N, K, D = 3072, 16384, 256
 w = torch.randn(K, D, device='cuda', generator=g); x = torch.randn(N, D, device='cuda', generator=g)

@@ -114,6 +114,8 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         case 8: if (small) VQ_CFG(8, 2, 8, 4) else VQ_CFG(8, 4, 8, 4)
         case 16: if (small) VQ_CFG(16, 2, 8, 4) else VQ_CFG(16, 4, 8, 4)
         case 32: VQ_CFG(32, 2, 8, 2)
+        case 48: VQ_CFG(48, 2, 8, 1)
+        case 64: VQ_CFG(64, 1, 8, 1)
         default: break;
     }
 #undef VQ_CFG
@@ -273,7 +275,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         const char *frag = c + L.off_frag;
         switch (L.nstep) {
 #define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<1024, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
-            VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2)
+            VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2) VQ_RESCAN(48, 1) VQ_RESCAN(64, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }
@@ -590,7 +592,7 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
     const char *frag = c + L.off_frag;
     switch (L.nstep) {
 #define VQ_DBG(NS, TPS) case NS: debug_scores_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, N, K, scores); break;
-        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, 4) VQ_DBG(32, 2)
+        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, 4) VQ_DBG(32, 2) VQ_DBG(48, 1) VQ_DBG(64, 1)
 #undef VQ_DBG
         default: return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: unsupported padded D");
     }

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    static_assert(NSTEP % 2 == 0 && TPS % 2 == 0, "16x16x32 layout: 32-dim k-steps, ping-pong by tile parity");
+    static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
+    constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
     constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
     constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage (2 per k-step and tile, + aux)
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
@@ -467,8 +468,8 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll
         for (int ti = 0; ti < TPS; ++ti) {
-            f32x4 (&cur)[2][TT] = (ti & 1) ? accB : accA;
-            f32x4 (&prv)[2][TT] = (ti & 1) ? accA : accB;
+            f32x4 (&cur)[2][TT] = (PIPE && (ti & 1)) ? accB : accA;
+            f32x4 (&prv)[2][TT] = (PIPE && (ti & 1)) ? accA : accB;
             // accumulator init = -se*|e|^2/2 of this lane's code rows 16c + 4(l>>4) + {0..3}
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                 // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
                 constexpr int TOTAL = NE * TT;
 #pragma unroll
-                for (int i = 0; i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                for (int i = 0; PIPE && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
                     const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % (NSTEP / TOTAL) == 0) ? ch / (NSTEP / TOTAL) : -1);
                     if (id >= 0 && id < TOTAL) {
                         const int t = id / NE, e = id % NE;
@@ -506,7 +507,17 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                     }
                 }
             }
-            const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;  // tile id of the previous tile
+            if constexpr (!PIPE) {   // large D: one tile per stage, epilogue in place (the SIMD's other wave covers it)
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float v = __uint_as_float((__float_as_uint(cur[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+                    }
+            }
+            const uint32_t tgp = (uint32_t)(st * TPS + ti) - (PIPE ? 1u : 0u);  // tile the retired elements belong to
 #pragma unroll
             for (int t = 0; t < TT; ++t)
                 t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
         __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
     }
     // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
-    if (st1 > st0) {
+    if (PIPE && st1 > st0) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const uint32_t old = __float_as_uint(b1[t]);
@@ -706,7 +717,7 @@ __global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ xi
     constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + 1;
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
-    constexpr int TR = (NSTEP <= 16) ? 4 : 2;            // 16-row sub-tiles per item (register budget at D=512)
+    constexpr int TR = (NSTEP <= 16) ? 4 : (NSTEP <= 48 ? 2 : 1);   // 16-row sub-tiles per item (register budget)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
     const int64_t ngroups = (nrows + 16 * TR - 1) / (16 * TR);
@@ -1477,7 +1488,7 @@ __global__ __launch_bounds__(256) void debug_scores_kernel(const char *__restric
     constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + 1;
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
-    constexpr int TR = (NSTEP <= 16) ? 4 : 2;
+    constexpr int TR = (NSTEP <= 16) ? 4 : (NSTEP <= 48 ? 2 : 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ngroups = (N + 16 * TR - 1) / (16 * TR);
     for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < ngroups * nstages; item += (int64_t)gridDim.x * 4) {

@@ -14,15 +14,17 @@
 #define VQ_HD inline
 #endif
 
-// Padded inner dimension for the fp16 proposal pass (k-steps of 32): next power of two >= max(D,32), <= 512.
+// Padded inner dimension for the fp16 proposal pass (k-steps of 32): next power of two >= max(D,32) up to 512,
+// then 768 and 1024 (one tile per LDS stage).
 VQ_HD int vq_padded_d(int D) {
+    if (D > 512) return D <= 768 ? 768 : 1024;
     int p = 32;
     while (p < D) p <<= 1;
     return p;
 }
-VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 512 && (D % 8) == 0; }
-// tiles (32 codes) staged per LDS stage = number of candidate slots per lane
-VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 16 ? 4 : 2; }
+VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 1024 && (D % 8) == 0; }
+// tiles (32 codes) staged per LDS stage
+VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 16 ? 4 : (nstep <= 32 ? 2 : 1); }
 
 struct VqCbLayout {
     int64_t K, Kp;          // codes, codes padded to a whole stage
