@@ -84,6 +84,18 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     return VQHIP_OK;
 }
 
+template <int NSTEP, int TT, int WAVES, int TPS>
+static int launch_rescan_cfg(const char *rimg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
+                             const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
+    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS>;
+    static size_t lds_set[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
+    kern<<<256, WAVES * 64, LDS, s>>>(rimg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
+    VQ_CHECK_LAUNCH("rescan_kernel");
+    return VQHIP_OK;
+}
+
 static int pick_slices(int64_t ntb, int64_t nstages) {
     if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
     // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
@@ -231,8 +243,8 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     int nslices = 1, rc;
     char *ximg = w + W.off_ximg;
     const int xgrid = (int)((N + 31) / 32);
-    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
-    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
+    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
     VQ_CHECK_LAUNCH("x_prep_kernel");
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
     if (rc) return rc;
@@ -248,50 +260,45 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         default: return fail(VQHIP_EINVAL, "vqhip_argmin: bad slice count");
     }
     VQ_CHECK_LAUNCH("refine_decide_kernel");
-    // re-rank kernels: one wave per queued row; LDS per wave = (1 + VQ_RR_BATCH) rows of D floats
-    int wpb = 4;
-    size_t per_wave = (size_t)(VQ_RR_BATCH + 1) * ((D + 3) & ~3) * sizeof(float);
-    while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
-    if (per_wave * wpb > 160 * 1024) return fail(VQHIP_EINVAL, "vqhip_argmin: D too large for the re-rank kernel");
-    const size_t rr_lds = per_wave * wpb;
+    // exact re-rank of the rows with several identified candidates: one lane per (row, record slot)
+    float *xnorm = (float *)(w + W.off_xn);
     {
-        static size_t lds_set[4][16] = {{0}};
-        const void *kerns[4] = {(const void *)refine_rerank_kernel<0, 0>, (const void *)refine_rerank_kernel<1, 0>,
-                                (const void *)refine_rerank_kernel<0, 1>, (const void *)refine_rerank_kernel<1, 1>};
-        for (int i = 0; i < 4; ++i)
-            if (int rc2 = ensure_dyn_lds(kerns[i], rr_lds, lds_set[i])) return rc2;
+        const int S = 2 * nslices;
+        if (x_dtype == VQHIP_DTYPE_F32)
+            refine_rerank_kernel<0, 0><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
+                                                           hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
+        else
+            refine_rerank_kernel<1, 0><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
+                                                           hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
+        VQ_CHECK_LAUNCH("refine_rerank_kernel");
     }
-    if (x_dtype == VQHIP_DTYPE_F32)
-        refine_rerank_kernel<0, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
-                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
-                                                                  nullptr, nullptr);
-    else
-        refine_rerank_kernel<1, 0><<<1024, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
-                                                                  idx, hist, multi_list, counters, nullptr, nullptr,
-                                                                  nullptr, nullptr);
-    VQ_CHECK_LAUNCH("refine_rerank_kernel");
     // second-chance proposals for rows with a possibly unidentified candidate, then their exact re-rank
     {
         const char *frag = c + L.off_frag;
+        char *rimg = w + W.off_rimg;
+        rescan_pack_kernel<<<512, 256, 0, s>>>(ximg, rescan_list, counters, L.nstep / 2, 1, rimg);
+        VQ_CHECK_LAUNCH("rescan_pack_kernel");
+        int rrc = VQHIP_OK;
         switch (L.nstep) {
-#define VQ_RESCAN(NS, TPS) case NS: rescan_kernel<NS, TPS><<<1024, 256, 0, s>>>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list); break;
-            VQ_RESCAN(2, 4) VQ_RESCAN(4, 4) VQ_RESCAN(8, 4) VQ_RESCAN(16, 4) VQ_RESCAN(32, 2) VQ_RESCAN(48, 1) VQ_RESCAN(64, 1)
+#define VQ_RESCAN(NS, TT, TPS) case NS: rrc = launch_rescan_cfg<NS, TT, 8, TPS>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
+            VQ_RESCAN(2, 2, 4) VQ_RESCAN(4, 2, 4) VQ_RESCAN(8, 2, 4) VQ_RESCAN(16, 2, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }
+        if (rrc) return rrc;
         VQ_CHECK_LAUNCH("rescan_kernel");
     }
     if (x_dtype == VQHIP_DTYPE_F32)
-        refine_rerank_kernel<0, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
-                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
-                                                                 exact_list, keys);
+        refine_rerank_kernel<0, 1><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
+                                                       Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
+                                                       keys);
     else
-        refine_rerank_kernel<1, 1><<<256, wpb * 64, rr_lds, s>>>(x, e_exact, c, L, D, metric, nslices, rec, xh2, rho2, Np,
-                                                                 idx, hist, rescan_list, counters, rescan_cnt, cand_list,
-                                                                 exact_list, keys);
+        refine_rerank_kernel<1, 1><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
+                                                       Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
+                                                       keys);
     VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
-    rc = run_exact_rows(x, x_dtype, e_exact, en, nullptr, N, K, D, metric, exact_list, counters + 2, keys, s);
+    rc = run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, s);
     if (rc) return rc;
     finalize_kernel<<<16, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
     VQ_CHECK_LAUNCH("finalize_kernel");
@@ -585,8 +592,8 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2);
     char *ximg = w + W.off_ximg;
     const int xgrid = (int)((N + 31) / 32);
-    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
-    else if (x_dtype == VQHIP_DTYPE_BF16) x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, counters, (char *)cb, L);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
+    else if (x_dtype == VQHIP_DTYPE_BF16) x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
     else return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: x_dtype");
     VQ_CHECK_LAUNCH("x_prep_kernel");
     const char *frag = c + L.off_frag;

@@ -333,9 +333,10 @@ __device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L,
 template <int DT>
 __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
                                                      char *__restrict__ ximg, float *__restrict__ xh2,
-                                                     float *__restrict__ rho2, int *__restrict__ counters, char *cb,
-                                                     VqCbLayout L) {
+                                                     float *__restrict__ rho2, float *__restrict__ xn,
+                                                     int *__restrict__ counters, char *cb, VqCbLayout L) {
     __shared__ float red[2][8][32];
+    __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
     __shared__ float red4[4];
     if (blockIdx.x == 0) {   // housekeeping for the later kernels of this call (stream-ordered)
         if (threadIdx.x < 8) counters[threadIdx.x] = 0;
@@ -348,6 +349,11 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
     const int64_t trow = tvalid ? t : (N - 1);
     const int ns32 = nstep >> 1;
     float s_h = 0.0f, s_r = 0.0f;
+    // thread g sees exactly the dims with d mod 64 in [8g, 8g+8), in increasing d: partial j = 8g + jj of the oracle's
+    // |x|^2 (64 interleaved fma chains, then the halving tree)
+    float pn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pn[j] = 0.0f;
     for (int piece = g; piece < ns32 * 4; piece += 8) {
         const int s = piece >> 2, q4 = piece & 3;
         const int d0 = 32 * s + 8 * q4;
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
                 _Float16 q = to_f16_ftz(v[j]);
                 float b = (float)q, res = v[j] - b;
                 s_h = fmaf(b, b, s_h); s_r = fmaf(res, res, s_r);
+                pn[j] = fmaf(v[j], v[j], pn[j]);
                 f[j] = q;
             }
         } else {
@@ -369,12 +376,25 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
         *(half8 *)(ximg + ((blk * 2 + (r >> 4)) * ns32 + s) * (int64_t)VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = f;
     }
     red[0][g][r] = s_h; red[1][g][r] = s_r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[8 * g + j][r] = pn[j];
     __syncthreads();
     if (g == 0 && tvalid) {
         float a = 0.0f, b = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { a += red[0][i][r]; b += red[1][i][r]; }
         xh2[t] = a; rho2[t] = b;
+    }
+    if (g == 1 && tvalid) {          // halving tree 32, 16, ..., 1 over the partials
+        float q[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) q[j] = part[j][r] + part[j + 32][r];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < off) q[j] = q[j] + q[j + off];
+        xn[t] = q[0];
     }
 }
 
@@ -482,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
             for (int t = 0; t < TT; ++t) old[t] = __float_as_uint(b1[t]);
             // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets);
             // chunk ch = 2*s32 + c feeds the TT MFMAs of code half c at k-step s32
-            constexpr int PF = 1;
+            constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);   // deeper where a chunk feeds fewer MFMAs
             half8 af[PF + 1];
 #pragma unroll
             for (int i = 0; i < PF; ++i)
@@ -705,185 +725,240 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     }
 }
 
+// Packs the fp16 fragments of the rows on rescan_list into a dense fragment-major image in list order, so that the
+// second proposal pass reads whole 1 KiB chunks instead of one 16-byte piece per cache line.
+__global__ __launch_bounds__(256) void rescan_pack_kernel(const char *__restrict__ ximg, const int *__restrict__ rescan_list,
+                                                          const int *__restrict__ counters, int ns32, int group_tiles, char *__restrict__ rimg) {
+    const int nrows = counters[0];
+    const int64_t ntiles = (nrows + 16 * group_tiles - 1) / (16 * group_tiles) * group_tiles;   // whole groups of the rescan kernel
+    const int64_t total = ntiles * ns32 * 64;            // 16-byte pieces
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i & 63);
+        const int64_t c = i >> 6;                        // chunk = tile * ns32 + s
+        const int64_t tile = c / ns32;
+        const int s = (int)(c % ns32);
+        const int64_t slot = tile * 16 + (p & 15);
+        const int64_t tk = rescan_list[slot < nrows ? slot : nrows - 1];   // pad the last tile with a valid row
+        const uint4 v = *(const uint4 *)(ximg + ((tk >> 4) * ns32 + s) * (int64_t)VQ_CHUNK_BYTES + ((p >> 4) * 16 + (int)(tk & 15)) * 16);
+        *(uint4 *)(rimg + i * 16) = v;
+    }
+}
+
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
 // operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
-// candidate list.  One wave per (64 queued rows, codebook stage); fragments come straight from the L2-resident images,
-// each A chunk feeds four MFMAs.
-template <int NSTEP, int TPS>
-__global__ __launch_bounds__(256) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
-                                                     int64_t nstages, const int *__restrict__ rescan_list,
-                                                     const int *__restrict__ counters, const float *__restrict__ thr,
-                                                     int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+// candidate list.  Same machinery as coarse_kernel — the rows' fragments (from the packed image) stay in registers,
+// codebook stages arrive by double-buffered LDS-DMA and are shared by the 8 waves — as a persistent grid over
+// (block of WAVES*TT*16 queued rows, slice of stages) items, the slice count chosen on the device from the queue
+// length so that every workgroup gets an item.
+template <int NSTEP, int TT, int WAVES, int TPS>
+__global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restrict__ rimg, const char *__restrict__ frag,
+                                                            int64_t nstages, const int *__restrict__ rescan_list,
+                                                            const int *__restrict__ counters, const float *__restrict__ thr,
+                                                            int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + 1;
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
-    constexpr int TR = (NSTEP <= 16) ? 4 : (NSTEP <= 48 ? 2 : 1);   // 16-row sub-tiles per item (register budget)
+    constexpr int BM = WAVES * TT * 16;
+    constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
-    const int64_t ngroups = (nrows + 16 * TR - 1) / (16 * TR);
-    const int64_t nitems = ngroups * nstages;
-    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < nitems; item += (int64_t)gridDim.x * 4) {
-        const int64_t fg = item / nstages, st = item % nstages;
-        half8 xf[TR][NS32];
-        float mythr[TR];
-        int slot[TR];
+    if (nrows <= 0) return;
+    const int64_t ntiles = (nrows + 15) / 16;            // 16-row tiles of the packed image
+    const int64_t ntb = (nrows + BM - 1) / BM;
+    int64_t ns = 1;
+    while (ntb * ns < (int64_t)gridDim.x && ns * 2 <= nstages) ns <<= 1;
+
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+
+    for (int64_t item = blockIdx.x; item < ntb * ns; item += gridDim.x) {
+        const int64_t sl = item % ns, tb = item / ns;
+        const int64_t st0 = (nstages * sl) / ns, st1 = (nstages * (sl + 1)) / ns;
+        issue_stage(st0, 0);
+        half8 xf[TT][NS32];
+        float mythr[TT];
+        int slot[TT];
 #pragma unroll
-        for (int t = 0; t < TR; ++t) {
-            slot[t] = (int)(fg * 16 * TR + t * 16 + (lane & 15));
+        for (int t = 0; t < TT; ++t) {
+            int64_t tt = tb * (BM / 16) + wave * TT + t;
+            slot[t] = (int)(tt * 16 + (lane & 15));
             const bool valid = slot[t] < nrows;
-            const int64_t tk = rescan_list[valid ? slot[t] : 0];
-            mythr[t] = valid ? thr[tk] : INFINITY;
-            const char *xsrc = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
+            mythr[t] = valid ? thr[rescan_list[slot[t]]] : INFINITY;   // padding repeats a queued row: never emitted
+            tt = tt < ntiles ? tt : ntiles - 1;
+            const char *src = rimg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
 #pragma unroll
-            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(xsrc + s * VQ_CHUNK_BYTES);
+            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
         }
-        const char *base = frag + st * (int64_t)STAGE_BYTES;
-        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
-#pragma unroll 2
-        for (int ti = 0; ti < TPS; ++ti) {
-            f32x4 acc[2][TR];
+        __syncthreads();   // stage st0 landed
+        for (int64_t st = st0; st < st1; ++st) {
+            const int buf = (int)((st - st0) & 1);
+            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+            const char *base = lds + buf * STAGE_BYTES;
+            const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+            for (int ti = 0; ti < TPS; ++ti) {
+                f32x4 acc[2][TT];
 #pragma unroll
-                for (int t = 0; t < TR; ++t) acc[c][t] = a4;
-            }
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
 #pragma unroll
-            for (int ch = 0; ch < NSTEP; ++ch) {
-                half8 a = *(const half8 *)(base + (ti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
+                    for (int t = 0; t < TT; ++t) acc[c][t] = a4;
+                }
+                half8 af[PF + 1];
 #pragma unroll
-                for (int t = 0; t < TR; ++t)
-                    acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
-            }
-            uint32_t hits = 0;      // bit 8t + e
+                for (int i = 0; i < PF; ++i)
+                    if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
-            for (int t = 0; t < TR; ++t)
+                for (int ch = 0; ch < NSTEP; ++ch) {
+                    if (ch + PF < NSTEP)
+                        af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
-            if (__any(hits != 0)) {
-                while (hits) {
-                    const int b = __ffs((int)hits) - 1;
-                    hits &= hits - 1;
-                    const int t = b >> 3, e = b & 7;
-                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
-                    int sl_t = slot[0];
+                    for (int t = 0; t < TT; ++t)
+                        acc[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], acc[ch & 1][t], 0, 0, 0);
+                }
+                uint32_t hits = 0;      // bit 8t + e
 #pragma unroll
-                    for (int i = 1; i < TR; ++i) sl_t = (t == i) ? slot[i] : sl_t;
-                    const int pos = atomicAdd(&rescan_cnt[sl_t], 1);
-                    if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)sl_t * VQ_RESCAN_CAP + pos] = (int)code;
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+                if (__any(hits != 0)) {
+                    while (hits) {
+                        const int b = __ffs((int)hits) - 1;
+                        hits &= hits - 1;
+                        const int t = b >> 3, e = b & 7;
+                        const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
+                        int sl_t = slot[0];
+#pragma unroll
+                        for (int i = 1; i < TT; ++i) sl_t = (t == i) ? slot[i] : sl_t;
+                        const int pos = atomicAdd(&rescan_cnt[sl_t], 1);
+                        if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)sl_t * VQ_RESCAN_CAP + pos] = (int)code;
+                    }
                 }
             }
+            __syncthreads();   // next stage landed and everybody is done reading this one
         }
     }
 }
 
-// wave per queued row (persistent): exact fp32 evaluation of its candidates.  The row and (up to VQ_RR_BATCH at
-// a time) candidate code rows are staged in LDS with coalesced loads; lane j then runs the fma chain of the j-th
-// candidate in d order.
-#define VQ_RR_BATCH 8
+// Exact fp32 evaluation of the candidates of the queued rows, one LANE per (row, candidate slot): the row's S slots
+// sit in S neighbouring lanes (S a power of two), 64/S rows per wave, so every row of the wave advances at once and
+// the dependent global round trips per row are list entry -> record -> streamed operands.  Each lane streams its own
+// two operand rows from L2 in 16-dim blocks through a register ring RING blocks deep and runs the oracle's fma chain
+// in d order; the S lanes then agree on the smallest (distance, code) key.
+// SRC 0: rows of multi_list, slots = the 2*nslices (value, code) fields of the proposal records within the margin.
+// SRC 1: rows of rescan_list, slots = the first VQ_RESCAN_CAP emitted candidates; longer lists go to the fp32 pass.
 template <int DT, int SRC>
-__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *x, const float *e_exact, const char *cb,
-                                                            VqCbLayout L, int D, int metric, int nslices,
-                                                            const float *rec, const float *xh2, const float *rho2,
-                                                            int64_t Np, int64_t *idx, int32_t *hist,
-                                                            const int *multi_list, int *counters,
-                                                            const int *rescan_cnt, const int *cand_list, int *exact_list,
-                                                            u64 *keys) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
-    const int Dq = (D + 3) & ~3;                                  // rows padded to 16 bytes
-    float *xs = (float *)lds + (size_t)wave * (VQ_RR_BATCH + 1) * Dq;   // [Dq] row, then [BATCH][Dq] candidate rows
-    float *es = xs + Dq;
+__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restrict__ x, const float *__restrict__ e_exact,
+                                                            const char *__restrict__ cb, VqCbLayout L, int D, int metric,
+                                                            int nslices, int S, const float *__restrict__ rec,
+                                                            const float *__restrict__ xh2, const float *__restrict__ rho2,
+                                                            const float *__restrict__ xnorm, int64_t Np,
+                                                            int64_t *__restrict__ idx, int32_t *__restrict__ hist,
+                                                            const int *__restrict__ row_list, int *__restrict__ counters,
+                                                            const int *__restrict__ rescan_cnt,
+                                                            const int *__restrict__ cand_list, int *__restrict__ exact_list,
+                                                            u64 *__restrict__ keys) {
+    constexpr int RING = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float *en = (const float *)(cb + L.off_en);
     const int nrows = counters[SRC == 0 ? 1 : 0];
-    for (int item = blockIdx.x * nwaves + wave; item < nrows; item += gridDim.x * nwaves) {
-        const int64_t n = multi_list[item];
-        bool cand;
+    const int rpw = 64 / S;                                   // rows per wave
+    const int j = lane & (S - 1);                             // this lane's slot
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+    for (int64_t base = gwave * rpw; base < nrows; base += nwaves * rpw) {
+        const int64_t item = base + lane / S;
+        const bool rvalid = item < nrows;
+        const int64_t n = rvalid ? row_list[item] : 0;
+        bool cand = false;
         uint32_t code = 0xFFFFFFFFu;
         if (SRC == 0) {
-            // lane i < 2*nslices owns candidate slot (slice i/2, field i%2) of the proposal records
-            const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
             float v = -INFINITY;
-            if (lane < 2 * nslices) {
-                const float *rp = rec + (int64_t)(lane >> 1) * VQ_REC_FIELDS * Np + n;
-                v = rp[(2 * (lane & 1)) * Np];
-                code = __float_as_uint(rp[(2 * (lane & 1) + 1) * Np]);
+            if (rvalid && j < 2 * nslices) {
+                const float *rp = rec + (int64_t)(j >> 1) * VQ_REC_FIELDS * Np + n;
+                v = rp[(2 * (j & 1)) * Np];
+                code = __float_as_uint(rp[(2 * (j & 1) + 1) * Np]);
             }
-            const float gbest = wave_max((lane & 1) ? -INFINITY : v);
-            cand = (lane < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
+            float gbest = (j & 1) ? -INFINITY : v;            // best first-field value over the row's slices
+            for (int off = 1; off < S; off <<= 1) gbest = fmaxf(gbest, __shfl_xor(gbest, off, 64));
+            const float m = rvalid ? row_margin(st, L.Dp, metric, xh2[n], rho2[n]) : 0.0f;
+            cand = rvalid && (j < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
         } else {
-            // rescanned row: lane j owns the j-th emitted candidate; an overflowing list goes to the fp32 pass
-            const int cnt = rescan_cnt[item];
-            if (cnt > VQ_RESCAN_CAP || cnt <= 0) {
-                if (lane == 0) {
+            const int cnt = rvalid ? rescan_cnt[item] : 0;
+            if (rvalid && (cnt > VQ_RESCAN_CAP || cnt <= 0)) {
+                if (j == 0) {
                     int pos = atomicAdd(&counters[2], 1);
                     exact_list[pos] = (int)n;
                     keys[n] = ~0ull;
                 }
-                continue;
+            } else if (rvalid && j < cnt) {
+                cand = true;
+                code = (uint32_t)cand_list[item * VQ_RESCAN_CAP + j];
             }
-            cand = lane < cnt;
-            if (cand) code = (uint32_t)cand_list[(int64_t)item * VQ_RESCAN_CAP + lane];
         }
-        u64 cmask = __ballot(cand);
-        const int ncand = __popcll(cmask);
-        // stage x (oracle-order |x|^2 on the way)
-        float p = 0.0f;
-        for (int d = lane; d < Dq; d += 64) {
-            float a = d < D ? load_elem<DT>(x, n * D + d) : 0.0f;
-            xs[d] = a; p = fmaf(a, a, p);
-        }
-        const float xn = wave_sum_tree(p);
         u64 key = ~0ull;
-        for (int b0 = 0; b0 < ncand; b0 += VQ_RR_BATCH) {
-            // j-th candidate of this batch = (b0+j)-th set bit of cmask
-            uint32_t mycode = 0xFFFFFFFFu;
-            u64 mm = cmask;
-            for (int j = 0; j < VQ_RR_BATCH && mm; ++j) {
-                const int src = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const uint32_t k = __shfl(code, src, 64);
-                if (lane == j) mycode = k;
-                const float *er = e_exact + (int64_t)k * D;
-                for (int d = lane; d < Dq; d += 64) es[j * Dq + d] = d < D ? er[d] : 0.0f;
-            }
-            cmask = mm;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (mycode != 0xFFFFFFFFu) {
-                const float4 *xr = (const float4 *)xs;
-                const float4 *er = (const float4 *)(es + lane * Dq);
-                float c = 0.0f;
-                const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
-#pragma unroll 4
-                for (int q = 0; q < Dq / 4; ++q) {
-                    float4 a = xr[q], bb = er[q];
-                    c = fmaf(sx * a.x, bb.x, c); c = fmaf(sx * a.y, bb.y, c);
-                    c = fmaf(sx * a.z, bb.z, c); c = fmaf(sx * a.w, bb.w, c);
+        if (cand) {
+            const float *er = e_exact + (int64_t)code * D;
+            typename RawVec<DT>::type xb[RING][2];
+            float4 eb[RING][4];
+            auto load_blk = [&](int slot, int d0) {
+                if (d0 < D) {
+                    xb[slot][0] = RawVec<DT>::load(x, n * D + d0);
+                    eb[slot][0] = *(const float4 *)(er + d0); eb[slot][1] = *(const float4 *)(er + d0 + 4);
                 }
-                float dist;
-                if (VQ_IS_L2(metric)) {
-                    float t = VQ_SWAPPED(metric) ? (c + en[mycode]) + xn : (c + xn) + en[mycode];
-                    t = (t < 0.0f) ? 0.0f : t;
-                    dist = sqrtf(t);
-                } else {
-                    dist = 1.0f - c;
+                if (d0 + 8 < D) {
+                    xb[slot][1] = RawVec<DT>::load(x, n * D + d0 + 8);
+                    eb[slot][2] = *(const float4 *)(er + d0 + 8); eb[slot][3] = *(const float4 *)(er + d0 + 12);
                 }
-                u64 kk = dist_key(dist, mycode);
-                key = kk < key ? kk : key;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+            };
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { u64 o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
-        if (lane == 0) {
+            for (int i = 0; i < RING; ++i) load_blk(i, 16 * i);
+            float c = 0.0f;
+            for (int d0 = 0; d0 < D; d0 += 16 * RING) {
+#pragma unroll
+                for (int i = 0; i < RING; ++i) {
+                    const int dd = d0 + 16 * i;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (dd + 8 * h < D) {
+                            float xv[8];
+                            RawVec<DT>::unpack(xb[i][h], xv);
+                            const float4 e0 = eb[i][2 * h], e1 = eb[i][2 * h + 1];
+                            c = fmaf(sx * xv[0], e0.x, c); c = fmaf(sx * xv[1], e0.y, c);
+                            c = fmaf(sx * xv[2], e0.z, c); c = fmaf(sx * xv[3], e0.w, c);
+                            c = fmaf(sx * xv[4], e1.x, c); c = fmaf(sx * xv[5], e1.y, c);
+                            c = fmaf(sx * xv[6], e1.z, c); c = fmaf(sx * xv[7], e1.w, c);
+                        }
+                    }
+                    load_blk(i, dd + 16 * RING);
+                }
+            }
+            float dist;
+            if (VQ_IS_L2(metric)) {
+                const float xn = xnorm[n];
+                float t = VQ_SWAPPED(metric) ? (c + en[code]) + xn : (c + xn) + en[code];
+                t = (t < 0.0f) ? 0.0f : t;
+                dist = sqrtf(t);
+            } else {
+                dist = 1.0f - c;
+            }
+            key = dist_key(dist, code);
+        }
+        for (int off = 1; off < S; off <<= 1) { u64 o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
+        if (j == 0 && key != ~0ull) {
             const uint32_t best = (uint32_t)(key & 0xFFFFFFFFull);
             idx[n] = (int64_t)best;
             if (hist) atomicAdd(&hist[best], 1);
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -69,7 +69,7 @@ struct VqCbStats {
 
 struct VqWsLayout {
     int64_t N;
-    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_ximg, total;
+    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_ximg, off_rimg, total;
 };
 
 // counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
@@ -91,7 +91,10 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_rlist = W.off_rcnt + Np * 4;       // [Np][32] candidate codes of rescanned rows
     W.off_keys = (W.off_rlist + Np * 4 * 32 + 255) / 256 * 256;
     W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
-    W.off_ximg = (W.off_en + (K + 63) / 64 * 64 * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
-    W.total = W.off_ximg + (vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0);
+    W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
+    W.off_ximg = (W.off_xn + Np * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
+    const int64_t img = vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0;
+    W.off_rimg = W.off_ximg + img;           // the rescanned rows' fragments, packed in list order
+    W.total = W.off_rimg + img + 4 * (int64_t)(vq_padded_d(D) / 32) * VQ_CHUNK_BYTES;   // whole groups of up to 4 tiles
     return W;
 }
