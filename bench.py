@@ -172,7 +172,7 @@ def main():
                          'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             'loss': loss, 'used_codes': int((hist > 0).sum().item()),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported once, at N=1 (rank 0's host cores)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
