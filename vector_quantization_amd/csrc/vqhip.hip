@@ -263,12 +263,12 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     // exact re-rank of the rows with several identified candidates: one lane per (row, record slot)
     float *xnorm = (float *)(w + W.off_xn);
     {
-        const int S = 2 * nslices;
+        const int S = 2 * nslices < 4 ? 4 : 2 * nslices;      // slot lanes per row (power of two, >= 4)
         if (x_dtype == VQHIP_DTYPE_F32)
-            refine_rerank_kernel<0, 0><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
+            refine_rerank_kernel<0, 0><<<2048, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
                                                            hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
         else
-            refine_rerank_kernel<1, 0><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
+            refine_rerank_kernel<1, 0><<<2048, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
                                                            hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
         VQ_CHECK_LAUNCH("refine_rerank_kernel");
     }
@@ -289,11 +289,11 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("rescan_kernel");
     }
     if (x_dtype == VQHIP_DTYPE_F32)
-        refine_rerank_kernel<0, 1><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
+        refine_rerank_kernel<0, 1><<<1024, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
                                                        Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
                                                        keys);
     else
-        refine_rerank_kernel<1, 1><<<512, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
+        refine_rerank_kernel<1, 1><<<1024, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
                                                        Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
                                                        keys);
     VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");

@@ -847,13 +847,16 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
     }
 }
 
-// Exact fp32 evaluation of the candidates of the queued rows, one LANE per (row, candidate slot): the row's S slots
-// sit in S neighbouring lanes (S a power of two), 64/S rows per wave, so every row of the wave advances at once and
-// the dependent global round trips per row are list entry -> record -> streamed operands.  Each lane streams its own
-// two operand rows from L2 in 16-dim blocks through a register ring RING blocks deep and runs the oracle's fma chain
-// in d order; the S lanes then agree on the smallest (distance, code) key.
+// Exact fp32 evaluation of the candidates of the queued rows.  A wave owns P = max(8, S) (row, candidate slot) pairs:
+// the S slots of a row sit in S neighbouring lanes (S a power of two, 4..32), lane p < P runs the oracle's fma chain
+// (d order) of pair p, and all 64 lanes move the operands: per 32-dim segment the wave fetches the 128-byte piece of
+// every pair's code row (8 lanes x 16 bytes per piece, whole cache lines) and of its latent rows one segment ahead
+// into registers, parks them in a small wave-private padded LDS tile, and the chain lanes read their rows from it.
+// Few pairs per wave means many waves: the operand latency is hidden by occupancy rather than by deep per-lane
+// prefetch.  The S lanes of a row finally agree on the smallest (distance, code) key.
 // SRC 0: rows of multi_list, slots = the 2*nslices (value, code) fields of the proposal records within the margin.
 // SRC 1: rows of rescan_list, slots = the first VQ_RESCAN_CAP emitted candidates; longer lists go to the fp32 pass.
+#define VQ_RR_STRIDE 36      // floats per LDS tile row: 32 dims + 4 pad (conflict-free b128 reads of 16 rows)
 template <int DT, int SRC>
 __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restrict__ x, const float *__restrict__ e_exact,
                                                             const char *__restrict__ cb, VqCbLayout L, int D, int metric,
@@ -865,33 +868,43 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
                                                             const int *__restrict__ rescan_cnt,
                                                             const int *__restrict__ cand_list, int *__restrict__ exact_list,
                                                             u64 *__restrict__ keys) {
-    constexpr int RING = 8;
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float tile_e[4][32 * VQ_RR_STRIDE];
+    __shared__ __attribute__((aligned(16))) float tile_x[4][8 * VQ_RR_STRIDE];
+    constexpr int XL = DT == 0 ? 8 : 4;                       // lanes per 32-dim latent row piece (16 bytes each)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *te = tile_e[wave], *tx = tile_x[wave];
     const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float *en = (const float *)(cb + L.off_en);
     const int nrows = counters[SRC == 0 ? 1 : 0];
-    const int rpw = 64 / S;                                   // rows per wave
+    const int P = S < 8 ? 8 : S;                              // pairs per wave (8, 16 or 32)
+    const int ne = P >> 3;                                    // load instructions per code segment
+    const int rpw = P / S;                                    // rows per wave (<= 2)
+    const bool chain = lane < P;
     const int j = lane & (S - 1);                             // this lane's slot
     const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+    const int nseg = (D + 31) >> 5;
+    const float *myx = tx + (lane / S) * VQ_RR_STRIDE, *mye = te + (lane & 31) * VQ_RR_STRIDE;
     for (int64_t base = gwave * rpw; base < nrows; base += nwaves * rpw) {
         const int64_t item = base + lane / S;
-        const bool rvalid = item < nrows;
+        const bool rvalid = chain && item < nrows;
         const int64_t n = rvalid ? row_list[item] : 0;
         bool cand = false;
-        uint32_t code = 0xFFFFFFFFu;
+        uint32_t code = 0;
         if (SRC == 0) {
             float v = -INFINITY;
+            uint32_t cd = 0xFFFFFFFFu;
             if (rvalid && j < 2 * nslices) {
                 const float *rp = rec + (int64_t)(j >> 1) * VQ_REC_FIELDS * Np + n;
                 v = rp[(2 * (j & 1)) * Np];
-                code = __float_as_uint(rp[(2 * (j & 1) + 1) * Np]);
+                cd = __float_as_uint(rp[(2 * (j & 1) + 1) * Np]);
             }
             float gbest = (j & 1) ? -INFINITY : v;            // best first-field value over the row's slices
             for (int off = 1; off < S; off <<= 1) gbest = fmaxf(gbest, __shfl_xor(gbest, off, 64));
             const float m = rvalid ? row_margin(st, L.Dp, metric, xh2[n], rho2[n]) : 0.0f;
-            cand = rvalid && (j < 2 * nslices) && (v >= gbest - m) && code != 0xFFFFFFFFu;
+            cand = rvalid && (j < 2 * nslices) && (v >= gbest - m) && cd != 0xFFFFFFFFu;
+            if (cand) code = cd;
         } else {
             const int cnt = rvalid ? rescan_cnt[item] : 0;
             if (rvalid && (cnt > VQ_RESCAN_CAP || cnt <= 0)) {
@@ -905,43 +918,93 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
                 code = (uint32_t)cand_list[item * VQ_RESCAN_CAP + j];
             }
         }
-        u64 key = ~0ull;
-        if (cand) {
-            const float *er = e_exact + (int64_t)code * D;
-            typename RawVec<DT>::type xb[RING][2];
-            float4 eb[RING][4];
-            auto load_blk = [&](int slot, int d0) {
-                if (d0 < D) {
-                    xb[slot][0] = RawVec<DT>::load(x, n * D + d0);
-                    eb[slot][0] = *(const float4 *)(er + d0); eb[slot][1] = *(const float4 *)(er + d0 + 4);
+        // who loads what (every lane takes part in the shuffles): instruction i of a code segment covers pairs
+        // 8i + (lane>>3), 16-byte piece lane&7; the latent segment is one instruction: wave row lane/XL, piece lane%XL
+        const float *ep0, *ep1, *ep2, *ep3;
+        bool ok0, ok1, ok2, ok3;
+        {
+            const int q = lane >> 3, pc = 4 * (lane & 7);
+            const uint32_t c0 = __shfl(code, q, 64), c1 = __shfl(code, 8 + q, 64), c2 = __shfl(code, 16 + q, 64),
+                           c3 = __shfl(code, 24 + q, 64);
+            const int k0 = __shfl((int)cand, q, 64), k1 = __shfl((int)cand, 8 + q, 64), k2 = __shfl((int)cand, 16 + q, 64),
+                      k3 = __shfl((int)cand, 24 + q, 64);
+            ep0 = e_exact + (int64_t)c0 * D + pc; ep1 = e_exact + (int64_t)c1 * D + pc;
+            ep2 = e_exact + (int64_t)c2 * D + pc; ep3 = e_exact + (int64_t)c3 * D + pc;
+            ok0 = k0 != 0; ok1 = k1 != 0 && ne > 1; ok2 = k2 != 0 && ne > 2; ok3 = k3 != 0 && ne > 2;
+        }
+        const int xr_row = lane / XL;
+        const int xsrc = xr_row * S;
+        const int64_t xn_row = __shfl(n, xsrc < 64 ? xsrc : 0, 64);
+        const int xrv = __shfl((int)rvalid, xsrc < 64 ? xsrc : 0, 64);
+        const bool xok = xr_row < rpw && xrv != 0;
+        const int64_t xoff = xn_row * D + (DT == 0 ? 4 : 8) * (lane % XL);
+        const int epiece = 4 * (lane & 7), xpiece = (DT == 0 ? 4 : 8) * (lane % XL);
+
+        // register ring PD segments deep: at step g the wave fetches segment g+PD, runs the chains over segment g (in
+        // the tile) and parks segment g+1; LDS operations of one wave execute in order, so one tile is enough
+        constexpr int PD = 2;
+        float4 r[PD][4];
+        float4 rxf[PD];                                        // latent piece: fp32 (DT 0) or 8 bf16 (DT 1)
+        uint4 rxb[PD];
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            rxf[u] = make_float4(0, 0, 0, 0); rxb[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[u][i] = make_float4(0, 0, 0, 0);
+        }
+        float c = 0.0f;
+        for (int g0 = -PD; g0 < nseg; g0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int g = g0 + u;
+                if (g + PD < nseg) {                           // fetch segment g+PD into ring slot u
+                    const int d0 = 32 * (g + PD);
+                    const bool ein = d0 + epiece < D;
+                    if (ok0 && ein) r[u][0] = *(const float4 *)(ep0 + d0);
+                    if (ok1 && ein) r[u][1] = *(const float4 *)(ep1 + d0);
+                    if (ok2 && ein) r[u][2] = *(const float4 *)(ep2 + d0);
+                    if (ok3 && ein) r[u][3] = *(const float4 *)(ep3 + d0);
+                    if (xok && d0 + xpiece < D) {
+                        if constexpr (DT == 0) rxf[u] = *(const float4 *)((const float *)x + xoff + d0);
+                        else rxb[u] = *(const uint4 *)((const uint16_t *)x + xoff + d0);
+                    }
                 }
-                if (d0 + 8 < D) {
-                    xb[slot][1] = RawVec<DT>::load(x, n * D + d0 + 8);
-                    eb[slot][2] = *(const float4 *)(er + d0 + 8); eb[slot][3] = *(const float4 *)(er + d0 + 12);
-                }
-            };
+                if (g >= 0 && g < nseg && chain) {             // chains over segment g from the tile
 #pragma unroll
-            for (int i = 0; i < RING; ++i) load_blk(i, 16 * i);
-            float c = 0.0f;
-            for (int d0 = 0; d0 < D; d0 += 16 * RING) {
-#pragma unroll
-                for (int i = 0; i < RING; ++i) {
-                    const int dd = d0 + 16 * i;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (dd + 8 * h < D) {
-                            float xv[8];
-                            RawVec<DT>::unpack(xb[i][h], xv);
-                            const float4 e0 = eb[i][2 * h], e1 = eb[i][2 * h + 1];
-                            c = fmaf(sx * xv[0], e0.x, c); c = fmaf(sx * xv[1], e0.y, c);
-                            c = fmaf(sx * xv[2], e0.z, c); c = fmaf(sx * xv[3], e0.w, c);
-                            c = fmaf(sx * xv[4], e1.x, c); c = fmaf(sx * xv[5], e1.y, c);
-                            c = fmaf(sx * xv[6], e1.z, c); c = fmaf(sx * xv[7], e1.w, c);
+                    for (int k = 0; k < 8; ++k) {
+                        if (32 * g + 4 * k < D) {
+                            const float4 a = *(const float4 *)(myx + 4 * k), bq = *(const float4 *)(mye + 4 * k);
+                            c = fmaf(sx * a.x, bq.x, c); c = fmaf(sx * a.y, bq.y, c);
+                            c = fmaf(sx * a.z, bq.z, c); c = fmaf(sx * a.w, bq.w, c);
                         }
                     }
-                    load_blk(i, dd + 16 * RING);
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (g + 1 >= 0 && g + 1 < nseg) {              // park segment g+1 (ring slot (u+1) % PD)
+                    constexpr int PDm = PD;
+                    const int v = (u + 1) % PDm;
+                    float *dst = te + (lane >> 3) * VQ_RR_STRIDE + epiece;
+                    *(float4 *)dst = r[v][0];
+                    if (ne > 1) *(float4 *)(dst + 8 * VQ_RR_STRIDE) = r[v][1];
+                    if (ne > 2) { *(float4 *)(dst + 16 * VQ_RR_STRIDE) = r[v][2]; *(float4 *)(dst + 24 * VQ_RR_STRIDE) = r[v][3]; }
+                    if (xr_row < 8) {
+                        if constexpr (DT == 0) {
+                            *(float4 *)(tx + xr_row * VQ_RR_STRIDE + xpiece) = rxf[v];
+                        } else {
+                            float xv[8];
+                            RawVec<1>::unpack(rxb[v], xv);
+                            float *dx = tx + xr_row * VQ_RR_STRIDE + xpiece;
+                            *(float4 *)dx = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                            *(float4 *)(dx + 4) = make_float4(xv[4], xv[5], xv[6], xv[7]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
+        }
+        u64 key = ~0ull;
+        if (cand) {
             float dist;
             if (VQ_IS_L2(metric)) {
                 const float xn = xnorm[n];
@@ -954,7 +1017,7 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
             key = dist_key(dist, code);
         }
         for (int off = 1; off < S; off <<= 1) { u64 o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
-        if (j == 0 && key != ~0ull) {
+        if (chain && j == 0 && key != ~0ull) {
             const uint32_t best = (uint32_t)(key & 0xFFFFFFFFull);
             idx[n] = (int64_t)best;
             if (hist) atomicAdd(&hist[best], 1);
