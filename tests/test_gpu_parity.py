@@ -456,3 +456,20 @@ def test_cluster_shape_d768(ops):
     np.testing.assert_array_equal(idx.cpu().numpy(), co.cos_argmin(x, w))
     col = ops.col_argmin(dev(xo), dev(wo), 'Cosine')
     np.testing.assert_array_equal(col.cpu().numpy(), co.col_argmin(co.cos_dist(x, w)))
+
+
+@pytest.mark.parametrize('D,K', [(64, 4096), (256, 2048), (768, 1024)])
+def test_near_duplicate_codebook_floods_second_pass(ops, D, K):
+    """Every code has three near-copies (relative perturbation 1e-3): most rows have >= 4 near-tied candidates, more
+    than the proposal pass can identify, so thousands of rows take the packed second proposal pass (several row
+    blocks and several items per workgroup) and the list re-rank.  Indices stay exact."""
+    N = 20000
+    rng = np.random.default_rng(4242 + D)
+    base = rng.standard_normal((K // 4, D)).astype(np.float32)
+    w = np.concatenate([base * np.float32(1.0 + 1e-3 * i) for i in range(4)], 0)
+    w = w[rng.permutation(K)].copy()
+    x = (base[rng.integers(0, K // 4, N)] + 0.05 * rng.standard_normal((N, D))).astype(np.float32)
+    cb = ops.prepare_codebook(dev(w), 'L2')
+    idx, st = ops.argmin(dev(x), cb, return_stats=True)
+    assert int(st[0]) > 2000, f'expected a flooded second pass, got {int(st[0])} rows'
+    np.testing.assert_array_equal(idx.cpu().numpy(), co.l2_argmin(x, w))
