@@ -72,3 +72,75 @@ def test_rearrange_quantize_and_metrics(tmp_path):
     assert abs(s['codebook_usage'] - counts.bool().sum().item() / K) < 1e-12
     ent = torch.distributions.Categorical(counts / counts.sum()).entropy().item()
     assert abs(s['codebook_ppl'] - ent) < 1e-5
+
+
+def test_channels_last_map_is_the_token_matrix_zero_copy():
+    """a channels-last latent map is rearranged to tokens and back without moving a byte (CPU
+    tensors are enough: no kernel runs on this path)."""
+    from vector_quantization_amd import tokenization as T
+    B, C, H, W = 2, 12, 3, 5
+    x = torch.randn(B, C, H, W).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert T.is_token_major(x) and not T.is_token_major(torch.randn(B, C, H, W))
+    t = T.to_tokens(x)
+    assert t.shape == (B * H * W, C) and t.data_ptr() == x.data_ptr() and t.is_contiguous()
+    assert torch.equal(t, x.permute(0, 2, 3, 1).reshape(-1, C))
+    m = T.to_map(t, B, H, W, token_major=True)
+    assert m.shape == x.shape and m.data_ptr() == x.data_ptr() and torch.equal(m, x)
+    assert m.is_contiguous(memory_format=torch.channels_last)
+    m.square().sum().backward()                      # plain autograd through the views
+    assert torch.allclose(x.grad, 2 * x.detach())
+
+
+def test_conv_connector_mirror_builds_and_emits_token_major_maps():
+    """connectors/conv.py: same config keys and state-dict; the 1x1 conv output is channels-last so the quantizer side
+    gets its token matrix as a view.  Values equal the NCHW conv up to the GEMM summation order."""
+    from vector_quantization_amd import Config
+    from vector_quantization_amd import tokenization as T
+    from vector_quantization_amd.connectors import BaseConnector, ConvConnector
+    from vector_quantization_amd.registries import VQITConnectorRegistry
+    torch.manual_seed(0)
+    c = VQITConnectorRegistry.build(Config(type='ConvConnector'), in_channels=16, out_channels=8)
+    assert isinstance(c, ConvConnector) and (c.in_channels, c.out_channels) == (16, 8)
+    assert sorted(c.state_dict()) == ['_conv.bias', '_conv.weight'] and c.state_dict()['_conv.weight'].shape == (8, 16, 1, 1)
+    x = torch.randn(2, 16, 4, 4)
+    y, memo = c(x, {'k': 1})
+    assert memo == {'k': 1} and y.shape == (2, 8, 4, 4) and T.is_token_major(y)
+    ref = torch.nn.functional.conv2d(x, c._conv.weight, c._conv.bias)
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert T.to_tokens(y).data_ptr() == y.data_ptr()
+    ident = VQITConnectorRegistry.build(Config(type='BaseConnector'), in_channels=8, out_channels=8)
+    assert isinstance(ident, BaseConnector) and ident(y, {})[0] is y
+    plain = VQITConnectorRegistry.build(Config(type='ConvConnector', channels_last=False, conv=dict(kernel_size=3, padding=1)),
+                                        in_channels=16, out_channels=8)
+    assert plain(x, {})[0].is_contiguous() and plain._conv.kernel_size == (3, 3)
+
+
+@pytest.mark.gpu
+def test_quantize_token_major_equals_nchw():
+    """The channels-last route (views only) and the NCHW route (HIP transposes) give identical z, loss, tokens and
+    input gradients."""
+    from vector_quantization_amd import build_quantizer, Config
+    from vector_quantization_amd import tokenization as T
+    B, C, H, W, K = 4, 64, 16, 16, 1024
+    g = synth.rng(11)
+    x = torch.from_numpy(g.standard_normal((B, C, H, W), dtype=np.float32)).cuda()
+    q = build_quantizer(dict(type='VQGANQuantizer',
+                             embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=C),
+                             distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+    q.init_weights(Config(type='vqgan'))
+    q = q.cuda().train()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g.standard_normal((K, C), dtype=np.float32)))
+    outs = []
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        xi = x.clone().contiguous(memory_format=fmt).requires_grad_(True)
+        q.zero_grad()
+        z, loss, memo = T.quantize(q, xi, {})
+        (loss + (z * z).sum()).backward()
+        outs.append((z.detach().clone(), loss.detach().clone(), memo['quantizer']['quant'].clone(), xi.grad.clone(),
+                     q.embedding.weight.grad.clone()))
+        if fmt is torch.channels_last:
+            assert T.is_token_major(z)
+    for a, b in list(zip(*outs))[:4]:
+        assert torch.equal(a, b)
+    assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-5, atol=1e-6)     # codebook grad: atomic scatter-add order

@@ -43,3 +43,17 @@ t = timeit(lambda: ops.col_argmin(x, w, 'L2'), reps=5); print(f'col_argmin (Near
 idx = ops.argmin(x, ops.prepare_codebook(w, 'L2'))
 t = timeit(lambda: ops.scatter_add_rows(x, idx, K)); print(f'scatter_add_rows: {t*1e3:.3f} ms')
 t = timeit(lambda: ops.hist(idx, K)); print(f'hist: {t*1e3:.3f} ms')
+
+# model-level quantize(): NCHW latent map (HIP transposes either side) vs channels-last (views)
+from vector_quantization_amd import build_quantizer, Config, tokenization as T
+B, C, H, W, K = 256, 256, 16, 16, 16384
+q = build_quantizer(dict(type='VQGANQuantizer', embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=C),
+                         distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+q.init_weights(Config(type='vqgan')); q = q.cuda().eval()
+with torch.no_grad():
+    q.embedding.weight.copy_(torch.randn(K, C, device='cuda', generator=g))
+    xm = torch.randn(B, C, H, W, device='cuda', generator=g).bfloat16()
+    for name, fmt in (('NCHW', torch.contiguous_format), ('channels-last', torch.channels_last)):
+        xi = xm.contiguous(memory_format=fmt)
+        t = timeit(lambda: T.quantize(q, xi, {}))
+        print(f'quantize() {name:14s} B={B} {C}x{H}x{W} K={K}: {t*1e3:.3f} ms  {B*H*W/t/1e6:.1f} Mtok/s')

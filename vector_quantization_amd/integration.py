@@ -12,6 +12,7 @@ REPLACED = {
     'VQITQuantizerLossRegistry': ('CodebookLoss', 'CommitmentLoss', 'VQGANLoss', 'EntropyLoss'),
     'VQITQuantizerCallbackRegistry': ('ComposedCallback', 'NormalizeCallback', 'VQKDCallback', 'CVQVAECallback'),
     'AnchorRegistry': ('NearestAnchor', 'MultinomialAnchor', 'CachedAnchor'),
+    'VQITConnectorRegistry': ('BaseConnector', 'ConvConnector'),
 }
 
 
@@ -21,17 +22,19 @@ def register_into_reference() -> dict:
     from vq.algorithms.vq.distances import VQITQuantizerDistanceRegistry  # type: ignore
     from vq.tasks.image_tokenization.models.quantizers.registries import (  # type: ignore
         VQITQuantizerCallbackRegistry, VQITQuantizerLossRegistry)
-    from vq.tasks.image_tokenization.models.registries import VQITQuantizerRegistry  # type: ignore
+    from vq.tasks.image_tokenization.models.registries import (  # type: ignore
+        VQITConnectorRegistry, VQITQuantizerRegistry)
 
-    from . import quantizers as Q
+    from . import connectors as C, quantizers as Q
 
     registries = dict(VQITQuantizerRegistry=VQITQuantizerRegistry,
                       VQITQuantizerDistanceRegistry=VQITQuantizerDistanceRegistry,
                       VQITQuantizerLossRegistry=VQITQuantizerLossRegistry,
-                      VQITQuantizerCallbackRegistry=VQITQuantizerCallbackRegistry, AnchorRegistry=AnchorRegistry)
+                      VQITQuantizerCallbackRegistry=VQITQuantizerCallbackRegistry, AnchorRegistry=AnchorRegistry,
+                      VQITConnectorRegistry=VQITConnectorRegistry)
     done = {}
     for reg_name, names in REPLACED.items():
         for n in names:
-            registries[reg_name].register_(n, force=True)(getattr(Q, n))
+            registries[reg_name].register_(n, force=True)(getattr(C if reg_name == 'VQITConnectorRegistry' else Q, n))
         done[reg_name] = list(names)
     return done

@@ -24,6 +24,10 @@ class VQITQuantizerRegistry(VQModelRegistry):
     pass
 
 
+class VQITConnectorRegistry(VQModelRegistry):
+    pass
+
+
 class VQITQuantizerDistanceRegistry(VQITQuantizerRegistry):
     pass
 

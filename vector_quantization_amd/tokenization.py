@@ -52,13 +52,27 @@ class _ToMap(Function):
         return ops.transpose_last2(g.reshape(b, c, h * w)).reshape(b * h * w, c), None, None, None
 
 
+def is_token_major(x: torch.Tensor) -> bool:
+    """True when a [B,C,H,W] tensor is stored channels-last, i.e. its memory already is the [(B H W), C] token matrix."""
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
 def to_tokens(x: torch.Tensor) -> torch.Tensor:
-    """einops 'b c h w -> (b h w) c' (models/base.py:124,140)."""
+    """einops 'b c h w -> (b h w) c' (models/base.py:124,140).  A channels-last map (what a 1x1 connector conv
+    produces when it runs in ``torch.channels_last``) already IS the token matrix: returned as a zero-copy view;
+    an NCHW-contiguous map goes through the HIP transpose."""
+    if is_token_major(x):
+        b, c, h, w = x.shape
+        return x.permute(0, 2, 3, 1).reshape(b * h * w, c)
     return _ToTokens.apply(x)
 
 
-def to_map(z: torch.Tensor, b: int, h: int, w: int) -> torch.Tensor:
-    """einops '(b h w) c -> b c h w' (models/base.py:126)."""
+def to_map(z: torch.Tensor, b: int, h: int, w: int, token_major: bool = False) -> torch.Tensor:
+    """einops '(b h w) c -> b c h w' (models/base.py:126).  ``token_major=True`` returns the [B,C,H,W] map as a
+    zero-copy channels-last view of ``z`` (logical shape and values identical to the NCHW result; the reference's
+    trailing ``.contiguous()`` exists only to give the decoder-side conv dense memory, which channels-last is)."""
+    if token_major:
+        return z.reshape(b, h, w, z.shape[-1]).permute(0, 3, 1, 2)
     return _ToMap.apply(z, b, h, w)
 
 
@@ -68,8 +82,9 @@ def quantize(quantizer, x: torch.Tensor, memo: dict):
     b, _, h, w = x.shape
     quantizer_memo = get_memo(memo, 'quantizer')
     quantizer_memo['x_shape'] = x.shape
+    token_major = is_token_major(x)
     z, q_loss, memo['quantizer'] = quantizer(to_tokens(x), quantizer_memo)
-    return to_map(z, b, h, w), q_loss, memo
+    return to_map(z, b, h, w, token_major), q_loss, memo
 
 
 def encode_to_quant(quantizer, x: torch.Tensor, memo: dict):
@@ -84,13 +99,13 @@ def encode_to_quant(quantizer, x: torch.Tensor, memo: dict):
     return quant.reshape(b, h, w), memo
 
 
-def decode_from_quant(quantizer, quant: torch.Tensor, memo: dict):
+def decode_from_quant(quantizer, quant: torch.Tensor, memo: dict, token_major: bool = False):
     """BaseModel.decode_from_quant before the decoder (image_reconstruction/models.py:97-106): quant [B,H,W] →
-    z [B,C,H,W]."""
+    z [B,C,H,W] (``token_major=True``: as a zero-copy channels-last view of the gathered rows)."""
     from .quantizers.base import get_memo
     b, h, w = quant.shape
     z, memo['quantizer'] = quantizer.decode(quant.reshape(-1), get_memo(memo, 'quantizer'))
-    return to_map(z, b, h, w), memo
+    return to_map(z, b, h, w, token_major), memo
 
 
 # ---- on-disk token formats ---------------------------------------------------------------------------------------------
