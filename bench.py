@@ -4,7 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--images B]
 
 Workload (BASELINE.json configs[1]): VQGAN quantizer, K=16384 codes, D=256, 256x256 images -> 16x16 tokens,
-latents bf16-valued as under autocast.  One step = one quantizer forward over one synthetic batch that is
+latents bf16-valued as under autocast, 2048 images (524 288 tokens) per GPU and step (SURVEY.md §8d lists
+B in {32, 256, 2048} for this config; --images selects another batch).  One step = one quantizer forward over one synthetic batch that is
 already resident in HBM: codebook preparation, fused distance+argmin (+ code histogram), embedding gather,
 straight-through output and the VQGAN loss sums (the reference's VQGAN forward computes no histogram: vqgan/model.py:230).  Ranks are independent (tokens shard embarrassingly:
 SURVEY.md §8e), so N>1 is weak scaling with no data-path collective; the only collectives are the timing
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--images', type=int, default=256, help='images per GPU per step (256 tokens each)')
+    ap.add_argument('--images', type=int, default=2048, help='images per GPU per step (256 tokens each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -152,7 +153,9 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('coarse_kernel_hbm_bytes_per_launch')
+                rec = json.load(open(pmc))
+                if int(rec.get('tokens_per_launch', -1)) == N:      # counters are per launch of THIS workload
+                    traffic = rec.get('coarse_kernel_hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         out = {

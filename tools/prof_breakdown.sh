@@ -12,6 +12,6 @@ rows=list(csv.DictReader(open(f)))
 tot=0
 for r in rows[:13]:
     if 'at::native' in r['Name'] and 'FillFunctor<double>' not in r['Name']: continue
-    print(f"  {r['Name'][:44]:46s} avg_us={float(r['AverageNs'])/1e3*int(r['Calls'])/23:8.1f}")
+    print(f"  {r['Name'][:44]:46s} calls={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:8.1f}")
 PY
 grep -o '"value": [0-9.]*' /root/repo/gpurun_out/$tag.log
