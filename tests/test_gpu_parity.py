@@ -389,10 +389,10 @@ def test_randomised_shapes_sweep(ops):
     rows, scaled data."""
     g = synth.rng(2024)
     kinds = ['normal', 'planted', 'vqgan_init', 'int', 'unit']
-    for trial in range(24):
-        N = int(g.integers(1, 600))
-        K = int(g.integers(1, 900))
-        D = int(g.choice([8, 16, 24, 32, 40, 64, 96, 128, 200, 256]))
+    for trial in range(40):
+        N = int(g.integers(1, 600)) if trial % 4 else int(g.integers(600, 2500))
+        K = int(g.integers(1, 900)) if trial % 3 else int(g.integers(900, 3000))
+        D = int(g.choice([8, 16, 24, 32, 40, 64, 96, 128, 200, 256, 320, 512, 520, 768, 1000]))
         metric = 'L2' if g.random() < 0.6 else 'Cosine'
         kind = kinds[int(g.integers(0, len(kinds)))]
         x, w = synth.make_inputs(kind, 500 + trial, N, K, D)
