@@ -67,7 +67,6 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
 static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
-static int g_tune_gather_grid = 0, g_tune_gather_nt = 0;   // gather kernel knobs (keys 3, 4)
 
 template <int NSTEP, int TT, int WAVES, int TPS>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
@@ -447,17 +446,11 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
     if (!x || !e || !idx || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: bad argument");
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
-    // outputs beyond the Infinity Cache (256 MiB) are streamed: non-temporal accesses and twice the waves in flight
-    const int64_t out_bytes = (int64_t)N * D * 4 * ((z ? 1 : 0) + (z_ste ? 1 : 0));
-    const bool streamed = g_tune_gather_nt ? g_tune_gather_nt == 1 : out_bytes > (192ll << 20);
-    int cap = g_tune_gather_grid > 0 ? g_tune_gather_grid : (streamed ? 512 : 256);      // blocks of 16 waves
-    int grid = (int)((N + 15) / 16);
-    grid = grid > cap ? cap : grid;
-#define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse)
-    if (x_dtype == VQHIP_DTYPE_F32) { if (streamed) VQ_GATHER(0, 1); else VQ_GATHER(0, 0); }
-    else if (x_dtype == VQHIP_DTYPE_BF16) { if (streamed) VQ_GATHER(1, 1); else VQ_GATHER(1, 0); }
+    int grid = (int)((N + 3) / 4);
+    grid = grid > 2048 ? 2048 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32) gather_ste_loss_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_ste_loss_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, z, z_ste, sse);
     else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");
-#undef VQ_GATHER
     VQ_CHECK_LAUNCH("gather_ste_loss_kernel");
     return VQHIP_OK;
 }
@@ -618,8 +611,6 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
 
 int vqhip_set_tuning(int key, int value) {
     if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
-    else if (key == 3) g_tune_gather_grid = value > 0 ? value : 0;
-    else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

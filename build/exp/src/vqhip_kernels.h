@@ -1350,17 +1350,15 @@ __device__ __forceinline__ void nt_store4(float *q, float a, float b, float c, f
     __builtin_nontemporal_store(c, q + 2); __builtin_nontemporal_store(d, q + 3);   // merged into one dwordx4 ... nt
 }
 
-// NT: the outputs (and the latents) are larger than the Infinity Cache and are streamed with non-temporal accesses;
-// smaller batches keep normal stores so that the consumer of z finds it in cache.
-template <int DT, int NT>
-__global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
+template <int DT>
+__global__ __launch_bounds__(256) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
                                                               int D, float *z, float *zste, double *sse) {
-    __shared__ double red[16];                                // 16 waves per block: one atomic per 16 waves
+    __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0;
     const bool vec = (D % 4) == 0;
-    const int64_t stride = (int64_t)gridDim.x * 16;
-    int64_t n = (int64_t)blockIdx.x * 16 + wave;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t n = (int64_t)blockIdx.x * 4 + wave;
     for (; n < N; n += stride) {
         const float *er = e + idx[n] * D;
         if (vec) {
@@ -1372,20 +1370,13 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
                     xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
                 } else {
                     const uint32_t *px = (const uint32_t *)((const uint16_t *)x + n * D + d);
-                    uint2 t;
-                    if (NT) { t.x = __builtin_nontemporal_load(px); t.y = __builtin_nontemporal_load(px + 1); }
-                    else t = *(const uint2 *)px;
+                    uint2 t; t.x = __builtin_nontemporal_load(px); t.y = __builtin_nontemporal_load(px + 1);
                     xv[0] = __uint_as_float(t.x << 16); xv[1] = __uint_as_float(t.x & 0xFFFF0000u);
                     xv[2] = __uint_as_float(t.y << 16); xv[3] = __uint_as_float(t.y & 0xFFFF0000u);
                 }
                 float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
-                if (NT) {
-                    if (z) nt_store4(z + n * D + d, zv.x, zv.y, zv.z, zv.w);
-                    if (zste) nt_store4(zste + n * D + d, xv[0] + d0, xv[1] + d1, xv[2] + d2, xv[3] + d3);
-                } else {
-                    if (z) *(float4 *)(z + n * D + d) = zv;
-                    if (zste) *(float4 *)(zste + n * D + d) = make_float4(xv[0] + d0, xv[1] + d1, xv[2] + d2, xv[3] + d3);
-                }
+                if (z) nt_store4(z + n * D + d, zv.x, zv.y, zv.z, zv.w);
+                if (zste) nt_store4(zste + n * D + d, xv[0] + d0, xv[1] + d1, xv[2] + d2, xv[3] + d3);
                 s += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             }
         } else {
@@ -1403,12 +1394,7 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) t += red[i];
-            atomicAdd(sse, t);
-        }
+        if (threadIdx.x == 0) atomicAdd(sse, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
 

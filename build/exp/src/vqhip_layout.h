@@ -1,0 +1,100 @@
+// Buffer layouts shared by host entry points and device kernels (gfx950 only).
+#pragma once
+#include <stdint.h>
+
+#define VQ_WAVE 64
+#define VQ_TILE_CODES 32           // codes per tile (two v_mfma_f32_16x16x32_f16 row blocks)
+#define VQ_CHUNK_BYTES 1024        // one wave-instruction of global_load_lds_dwordx4
+#define VQ_MAX_SLICES 16
+#define VQ_REC_FIELDS 5            // v1, c1, v2, c2, v3
+
+#if defined(__HIPCC__)
+#define VQ_HD __host__ __device__ inline
+#else
+#define VQ_HD inline
+#endif
+
+// Padded inner dimension for the fp16 proposal pass (k-steps of 32): next power of two >= max(D,32) up to 512,
+// then 768 and 1024 (one tile per LDS stage).
+VQ_HD int vq_padded_d(int D) {
+    if (D > 512) return D <= 768 ? 768 : 1024;
+    int p = 32;
+    while (p < D) p <<= 1;
+    return p;
+}
+VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 1024 && (D % 8) == 0; }
+// tiles (32 codes) staged per LDS stage
+VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 16 ? 4 : (nstep <= 32 ? 2 : 1); }
+
+struct VqCbLayout {
+    int64_t K, Kp;          // codes, codes padded to a whole stage
+    int D, Dp, nstep, tps;  // dims, padded dims, k-steps of 16, tiles per stage
+    int64_t nstages;
+    int64_t stage_bytes;    // (tps*nstep + 1) KiB: fragment chunks + one aux chunk (-se*|e|^2/2)
+    int64_t off_stats, off_part1, off_part2, off_en, off_eexact, off_frag, total;
+    int64_t nblk1, nblk2;   // blocks of the statistics / image kernels (their partial-result arrays)
+};
+
+VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
+    VqCbLayout L;
+    L.K = K; L.D = D;
+    L.Dp = vq_padded_d(D); L.nstep = L.Dp / 16; L.tps = vq_tiles_per_stage(L.nstep);
+    int64_t cps = (int64_t)L.tps * VQ_TILE_CODES;
+    L.nstages = (K + cps - 1) / cps;
+    L.Kp = L.nstages * cps;
+    L.stage_bytes = ((int64_t)L.tps * L.nstep + 1) * VQ_CHUNK_BYTES;
+    L.off_stats = 0;
+    L.nblk1 = (K + 15) / 16;                 // cb_stats_kernel: 16 codes per block
+    L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
+    L.off_part1 = 256;                       // float4 {max|e|, max e2, max en, bad} per stats block
+    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // float4 {max r2, max eh2, bad, 0} per image block
+    L.off_en = (L.off_part2 + L.nblk2 * 16 + 255) / 256 * 256;
+    L.off_eexact = (L.off_en + L.Kp * 4 + 255) / 256 * 256;
+    L.off_frag = (L.off_eexact + K * (int64_t)D * 4 + 1023) / 1024 * 1024;
+    L.total = L.off_frag + L.nstages * L.stage_bytes;
+    return L;
+}
+
+// Device-resident statistics of a prepared codebook (first 256 bytes of the image).
+struct VqCbStats {
+    uint32_t maxabs_bits;   // max |e_kd| (of the normalised codebook for COS), float bits
+    uint32_t e2max_bits;    // max_k sum_d e_kd^2                (upper-bounds |e_k|^2)
+    uint32_t r2max_bits;    // max_k sum_d (e_kd - ehat_kd)^2    (fp16 residual)
+    uint32_t eh2max_bits;   // max_k sum_d ehat_kd^2
+    uint32_t enmax_bits;    // max_k oracle |e_k|^2 (0 for COS)
+    uint32_t nonfinite;     // !=0: some entry is NaN/Inf (or overflows the fp16 image)
+    int32_t metric;
+    uint32_t finalized;     // r2max/eh2max folded in from the image kernel's partials (first consumer call does it)
+};
+
+struct VqWsLayout {
+    int64_t N;
+    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_ximg, off_rimg, total;
+};
+
+// counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
+VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
+    VqWsLayout W;
+    W.N = N;
+    int64_t M = N > K ? N : K;      // col_argmin keys are per code
+    int64_t Np = (N + 63) / 64 * 64;
+    int64_t Mp = (M + 63) / 64 * 64;
+    W.off_counters = 0;
+    W.off_xh2 = 256;
+    W.off_rho2 = W.off_xh2 + Np * 4;
+    W.off_rec = W.off_rho2 + Np * 4;
+    W.off_flag = W.off_rec + (int64_t)VQ_MAX_SLICES * VQ_REC_FIELDS * Np * 4;
+    W.off_multi = W.off_flag + Np * 4;       // off_flag: rescan list
+    W.off_exact = W.off_multi + Np * 4;
+    W.off_thr = W.off_exact + Np * 4;
+    W.off_rcnt = W.off_thr + Np * 4;
+    W.off_rlist = W.off_rcnt + Np * 4;       // [Np][32] candidate codes of rescanned rows
+    W.off_keys = (W.off_rlist + Np * 4 * 32 + 255) / 256 * 256;
+    W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
+    W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
+    W.off_ximg = (W.off_xn + Np * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
+    const int64_t img = vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0;
+    W.off_rimg = W.off_ximg + img;           // the rescanned rows' fragments, packed in list order
+    W.total = W.off_rimg + img + 4 * (int64_t)(vq_padded_d(D) / 32) * VQ_CHUNK_BYTES;   // whole groups of up to 4 tiles
+    return W;
+}

@@ -168,8 +168,9 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
  * around that launch (bench.py's roofline leg).  enable(1) starts collecting, collect() synchronises on the
  * recorded events, returns the summed kernel milliseconds and launch count (HOST pointers) and resets. */
 int vqhip_profile_enable(int on);
-/* Knob for A/B measurements (results never change): key 2 = number of codebook slices (1,2,4,8,16; 0 = automatic).
- * Keys 0 and 1 are retired no-ops. */
+/* Knobs for A/B measurements (results never change): key 2 = number of codebook slices (1,2,4,8,16; 0 = automatic);
+ * key 3 = workgroup cap of the gather kernel (0 = automatic); key 4 = its streaming mode (1 on, 2 off, 0 = automatic:
+ * on when the outputs exceed 192 MiB).  Keys 0 and 1 are retired no-ops. */
 int vqhip_set_tuning(int key, int value);
 int vqhip_profile_collect(double *ms_sum, int64_t *launches);
 
