@@ -88,7 +88,7 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
 template <int NSTEP, int TT, int WAVES, int TPS>
 static int launch_rescan_cfg(const char *rimg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
                              const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
-    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
     auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS>;
     static size_t lds_set[16] = {0};
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;

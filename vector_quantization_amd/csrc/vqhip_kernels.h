@@ -655,6 +655,7 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
 }
 
 #define VQ_RESCAN_CAP 32     // candidate slots per rescanned row
+#define VQ_RESCAN_LOCAL 8    // ... of which one (row block, slice) item of the second pass may contribute
 
 // thread per token: merge the slice records under the margin.  Outcomes:
 //   one candidate                         -> idx written here
@@ -761,6 +762,10 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     constexpr int BM = WAVES * TT * 16;
     constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);
+    // hits are collected per row in LDS (LDS atomics) and appended to the global lists once per item, one global
+    // atomic per (row, item): a returning global atomic inside the MFMA loop stalls its wave for a memory round trip
+    int *lcnt = (int *)(lds + 2 * STAGE_BYTES);                       // [BM]
+    uint32_t *lcand = (uint32_t *)(lds + 2 * STAGE_BYTES) + BM;        // [BM][VQ_RESCAN_LOCAL]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
     if (nrows <= 0) return;
@@ -782,6 +787,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
         const int64_t sl = item % ns, tb = item / ns;
         const int64_t st0 = (nstages * sl) / ns, st1 = (nstages * (sl + 1)) / ns;
         issue_stage(st0, 0);
+        for (int i = threadIdx.x; i < BM; i += WAVES * 64) lcnt[i] = 0;
         half8 xf[TT][NS32];
         float mythr[TT];
         int slot[TT];
@@ -828,22 +834,31 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
-                if (__any(hits != 0)) {
-                    while (hits) {
-                        const int b = __ffs((int)hits) - 1;
-                        hits &= hits - 1;
-                        const int t = b >> 3, e = b & 7;
-                        const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
-                        int sl_t = slot[0];
-#pragma unroll
-                        for (int i = 1; i < TT; ++i) sl_t = (t == i) ? slot[i] : sl_t;
-                        const int pos = atomicAdd(&rescan_cnt[sl_t], 1);
-                        if (pos < VQ_RESCAN_CAP) cand_list[(int64_t)sl_t * VQ_RESCAN_CAP + pos] = (int)code;
-                    }
+                while (hits) {
+                    const int b = __ffs((int)hits) - 1;
+                    hits &= hits - 1;
+                    const int t = b >> 3, e = b & 7;
+                    const uint32_t code = (uint32_t)((st * TPS + ti) * 32 + tile_row16(e, lane));
+                    const int row = (wave * TT + t) * 16 + (lane & 15);
+                    const int pos = atomicAdd(&lcnt[row], 1);
+                    if (pos < VQ_RESCAN_LOCAL) lcand[row * VQ_RESCAN_LOCAL + pos] = code;
                 }
             }
             __syncthreads();   // next stage landed and everybody is done reading this one
         }
+        // flush: thread r owns local row r
+        for (int r = threadIdx.x; r < BM; r += WAVES * 64) {
+            const int c = lcnt[r];
+            const int64_t gs = tb * BM + r;
+            if (c > 0 && gs < nrows) {
+                // a local list that overflowed lost candidates: push the row's count past the cap (fp32 pass)
+                const int base = atomicAdd(&rescan_cnt[gs], c > VQ_RESCAN_LOCAL ? VQ_RESCAN_CAP + 1 : c);
+                const int m = c > VQ_RESCAN_LOCAL ? VQ_RESCAN_LOCAL : c;
+                for (int i = 0; i < m; ++i)
+                    if (base + i < VQ_RESCAN_CAP) cand_list[gs * VQ_RESCAN_CAP + base + i] = (int)lcand[r * VQ_RESCAN_LOCAL + i];
+            }
+        }
+        __syncthreads();       // lists are re-zeroed by the next item
     }
 }
 
