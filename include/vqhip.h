@@ -57,7 +57,9 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
  *        pass the output of vqhip_normalize_rows; the codebook is normalised by codebook_prepare)
  * evaluated with k-ordered fp32 fma chains (see DESIGN.md "Arithmetic contract").  A fp16 MFMA pass
  * proposes candidates under a rigorous error bound and an exact fp32 re-rank decides; rows the bound
- * cannot settle are re-evaluated over the whole codebook in fp32.  Optional outputs (nullable):
+ * cannot settle are re-evaluated over the whole codebook in fp32.  The proposal pass exists for D <= 1024 with
+ * D % 8 == 0 (every shipped config: 8, 32, 256, 768); any other D takes the all-fp32 route of vqhip_argmin_exact.
+ * Optional outputs (nullable):
  *   hist[K] int32 += code-hit histogram (quant.bincount, vq/algorithms/vq/utils.py:42);
  * `ws` = vqhip_workspace_bytes(N,K,D) of scratch. */
 int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D,
