@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Randomised campaign on the GPU: vqhip_argmin (fp16 proposals + exact re-rank) against vqhip_argmin_exact (all-fp32
+MFMA, itself bit-equal to the CPU oracle in tests/) at sizes the CPU oracle cannot reach.  Any mismatch is a bug.
+usage: fuzz_vs_exact.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vector_quantization_amd import ops
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+g = torch.Generator(device='cuda').manual_seed(20261003)
+def ri(lo, hi): return int(torch.randint(lo, hi, (1,), generator=g, device='cuda').item())
+t_end = time.time() + budget
+trials = bad = 0
+while time.time() < t_end:
+    D = [8, 16, 32, 64, 128, 256, 256, 256, 512, 768, 1024][ri(0, 11)]
+    K = [ri(1, 64), ri(64, 4096), 8192, 16384, ri(4096, 20000)][ri(0, 5)]
+    N = [ri(1, 512), ri(512, 70000), 65536, ri(70000, 300000)][ri(0, 4)]
+    if N * K * D > 3e12: N = max(1, int(3e12 / (K * D)))
+    metric = 'L2' if ri(0, 3) else 'Cosine'
+    kind = ri(0, 6)
+    scale = 10.0 ** ri(-4, 5)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    if kind == 1:   # latents near codes
+        x = w[torch.randint(0, K, (N,), device='cuda', generator=g)] + 0.02 * x
+    elif kind == 2:  # duplicated / near-duplicated codes
+        w[K // 2:] = w[:K - K // 2] * (1 + 1e-4 * ri(0, 3))
+    elif kind == 3:  # tiny uniform init
+        w = (torch.rand(K, D, device='cuda', generator=g) * 2 - 1) / K
+    elif kind == 4:  # heavy-tailed
+        x = x * torch.exp(2 * torch.randn(N, 1, device='cuda', generator=g)); w = w * torch.exp(torch.randn(K, 1, device='cuda', generator=g))
+    elif kind == 5:  # integer grid (exact ties)
+        x = torch.randint(-3, 4, (N, D), device='cuda', generator=g).float(); w = torch.randint(-3, 4, (K, D), device='cuda', generator=g).float()
+    x, w = x * scale, w * scale
+    xd = x.bfloat16() if ri(0, 3) == 0 else x
+    if metric == 'Cosine':
+        xq = ops.normalize_rows(xd); wq = ops.normalize_rows(w)
+        got = ops.argmin(xq, ops.prepare_codebook(w, metric))
+        ref = ops.argmin_exact(xq, wq, metric)
+    else:
+        got = ops.argmin(xd, ops.prepare_codebook(w, metric))
+        ref = ops.argmin_exact(xd, w, metric)
+    nb = int((got != ref).sum().item())
+    trials += 1
+    if nb:
+        bad += 1
+        print(f'MISMATCH trial {trials}: N={N} K={K} D={D} {metric} kind={kind} scale={scale} bf16={xd.dtype} rows={nb}', flush=True)
+print(f'{trials} trials, {bad} with mismatches')
+sys.exit(1 if bad else 0)
