@@ -42,6 +42,15 @@ while time.time() < t_end:
         got = ops.argmin(xd, ops.prepare_codebook(w, metric))
         ref = ops.argmin_exact(xd, w, metric)
     nb = int((got != ref).sum().item())
+    # NearestAnchor's column argmin (role-swapped pipeline) against the materialised fp32 distance matrix
+    if N * K <= 1.5e8 and ri(0, 2) == 0:
+        if metric == 'Cosine':
+            d = ops.distance(xq, wq, metric); col = ops.col_argmin(xq, wq, metric)
+        else:
+            d = ops.distance(xd, w, metric); col = ops.col_argmin(xd, w, metric)
+        rows = torch.arange(N, device='cuda')[:, None].expand(N, K)
+        cref = torch.where(d == d.min(0, keepdim=True).values, rows, N).min(0).values
+        nb += int((col != cref).sum().item())
     trials += 1
     if nb:
         bad += 1
