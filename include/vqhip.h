@@ -144,6 +144,27 @@ int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out,
 int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv,
                              void *stream);
 
+/* ---- deterministic (ordered) codebook-side sums  (SURVEY.md §7 hard part 9) ---------------------------------------
+ * vqhip_scatter_add_rows and the grad_w leg of vqhip_vq_backward add with floating-point atomics, i.e. in arrival
+ * order.  The ordered route fixes the order instead: vqhip_token_order sorts the token ids by code (stable counting
+ * sort, integer arithmetic only): counts[K] = bincount, offsets[K+1] = its exclusive scan, order[N] = token ids, code
+ * by code, ascending within a code.  K <= 32768.  `ws` = vqhip_order_workspace_bytes(N, K).
+ * Sums: the sorted order is cut into ranges of 64 positions; rows are added in order inside a range; a code whose
+ * tokens span several ranges is the sum of its range pieces in range order — an association fixed by the counts alone.
+ * vqhip_segsum_rows: dst[k] = that sum of src[order[p]], p in [offsets[k], offsets[k+1]) (all K rows are written, zero
+ * for unused codes) — the centroid sums of callbacks.py:60-64.  vqhip_vq_backward_w_ordered: grad_w[k] = the same sum
+ * of g_cb * 2/(N*D) * (e_k - x_n) — the codebook gradient of vqhip_vq_backward (call that one with grad_w = NULL).
+ * `ws` of the two sums = vqhip_segsum_workspace_bytes(N, D). */
+int64_t vqhip_order_workspace_bytes(int64_t N, int64_t K);
+int64_t vqhip_segsum_workspace_bytes(int64_t N, int D);
+int vqhip_token_order(const int64_t *idx, int64_t N, int64_t K, int32_t *counts, int32_t *offsets, int32_t *order, void *ws,
+                      void *stream);
+int vqhip_segsum_rows(const float *src, const int64_t *idx, const int32_t *order, const int32_t *offsets, int64_t N, int64_t K,
+                      int D, float *dst, void *ws, void *stream);
+int vqhip_vq_backward_w_ordered(const void *x, int x_dtype, const float *e, const int64_t *idx, const int32_t *order,
+                                const int32_t *offsets, int64_t N, int64_t K, int D, const float *g_cb, float *grad_w, void *ws,
+                                void *stream);
+
 /* ---- callers either side of the path ------------------------------------------------------
  * vqhip_transpose: in[B][R][C] -> out[B][C][R] for 2- or 4-byte elements.  With R = channels, C = h*w it is
  *   'b c h w -> (b h w) c' (vq/tasks/image_tokenization/models/base.py:124,140); with R = h*w, C = channels the

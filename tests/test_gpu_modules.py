@@ -217,3 +217,39 @@ def test_entropy_loss_fallback_runs():
     loss_memo = dict(distance=memo['encode']['distance'])                   # the reference reads memo['distance']
     val = q._losses['entropy'](None, x2, loss_memo)
     assert torch.isfinite(val)
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_reproducible_codebook_gradient():
+    """torch.use_deterministic_algorithms(True) routes the codebook-side sums through the ordered kernels: two
+    identical training steps give bit-identical weight gradients (the atomic route differs in the last bits)."""
+    from vector_quantization_amd import build_quantizer, Config
+    N, K, D = 20000, 256, 64
+    g = synth.rng(21)
+    q = build_quantizer(dict(type='VQGANQuantizer',
+                             embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=D),
+                             distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+    q.init_weights(Config(type='vqgan'))
+    q = q.cuda().train()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g.standard_normal((K, D), dtype=np.float32)))
+    x = torch.from_numpy(g.standard_normal((N, D), dtype=np.float32)).cuda()
+    prev = torch.are_deterministic_algorithms_enabled()
+    grads = []
+    try:
+        torch.use_deterministic_algorithms(True)
+        for _ in range(3):
+            q.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            z, loss, _ = q(xi, {})
+            (loss + (z * z).mean()).backward()
+            grads.append((q.embedding.weight.grad.clone(), xi.grad.clone()))
+    finally:
+        torch.use_deterministic_algorithms(prev)
+    for gw, gx in grads[1:]:
+        assert torch.equal(gw, grads[0][0]) and torch.equal(gx, grads[0][1])
+    q.zero_grad()
+    xi = x.clone().requires_grad_(True)
+    z, loss, _ = q(xi, {})
+    (loss + (z * z).mean()).backward()                  # default policy at this size: atomics
+    assert torch.allclose(q.embedding.weight.grad, grads[0][0], rtol=1e-4, atol=1e-7)

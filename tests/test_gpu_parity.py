@@ -473,3 +473,77 @@ def test_near_duplicate_codebook_floods_second_pass(ops, D, K):
     idx, st = ops.argmin(dev(x), cb, return_stats=True)
     assert int(st[0]) > 2000, f'expected a flooded second pass, got {int(st[0])} rows'
     np.testing.assert_array_equal(idx.cpu().numpy(), co.l2_argmin(x, w))
+
+
+def _ordered_sum_reference(rows_of, idx, K, D):
+    """The ordered route's association restated sequentially: the stable code-sorted token order is cut into ranges of
+    64 positions; inside a range rows are added in order; a code spanning ranges is its range pieces added in range
+    order (include/vqhip.h).  rows_of(n, k) -> fp32 row contributed by token n to code k."""
+    order = np.argsort(idx, kind='stable')
+    out = np.zeros((K, D), np.float32)
+    pieces = {}
+    for r0 in range(0, len(order), 64):
+        cur, acc = None, None
+        for n in order[r0:r0 + 64]:
+            k = int(idx[n])
+            if k != cur:
+                if cur is not None:
+                    pieces.setdefault(cur, []).append(acc)
+                cur, acc = k, np.zeros(D, np.float32)
+            acc = acc + rows_of(n, k)
+        if cur is not None:
+            pieces.setdefault(cur, []).append(acc)
+    for k, ps in pieces.items():
+        acc = ps[0]
+        for q in ps[1:]:
+            acc = acc + q
+        out[k] = acc
+    return order, out
+
+
+@pytest.mark.parametrize('N,K,D', [(5000, 300, 64), (1, 1, 8), (1024, 16384, 256), (3001, 7, 32), (70000, 4096, 16)])
+def test_ordered_codebook_sums(ops, N, K, D):
+    """SURVEY.md §7 hard part 9: the ordered route — stable counting sort of the tokens by code, then sums in a fixed
+    order — is integer-exact for the order and bit-exact for the sums against a sequential numpy restatement, and
+    agrees with the atomic route within rounding."""
+    g = synth.rng(77 + N)
+    idx = g.integers(0, K, N)
+    if K > 4:
+        idx[idx == 3] = 2                                   # an unused code among used ones
+    src = g.standard_normal((N, D), dtype=np.float32)
+    counts, offsets, order = ops.token_order(dev(idx.astype(np.int64)), K)
+    ref_order, ref = _ordered_sum_reference(lambda n, k: src[n], idx, K, D)
+    np.testing.assert_array_equal(order.cpu().numpy(), ref_order)
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.bincount(idx, minlength=K))
+    np.testing.assert_array_equal(offsets.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=K))]))
+    got = ops.scatter_add_rows(dev(src), dev(idx.astype(np.int64)), K, ordered=True).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    atom = ops.scatter_add_rows(dev(src), dev(idx.astype(np.int64)), K, ordered=False).cpu().numpy()
+    np.testing.assert_allclose(atom, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', [None, torch.bfloat16])
+def test_ordered_codebook_gradient(ops, dtype):
+    """grad_W of the fused backward on the ordered route: bit-equal to the sequential restatement of
+    sum_n kw*(e_k - x_n), bit-reproducible run to run, and within rounding of the atomic route.  The planted inputs
+    give codes with a handful of tokens and, through the repeated block, one code with hundreds (several ranges)."""
+    N, K, D = 6000, 512, 64
+    x, w = synth.make_inputs('planted', 9, N, K, D)
+    x[1000:1700] = x[1000] + np.float32(1e-3) * synth.normal(3, 700, D)      # 700 tokens on one code
+    if dtype is not None:
+        x = synth.bf16_round(x)
+    idx = co.l2_argmin(x, w)
+    assert np.bincount(idx).max() >= 700
+    g_cb = np.float32(0.7)
+    xd, wd, idd = dev(x, dtype), dev(w), dev(idx.astype(np.int64))
+    gcb = torch.tensor(float(g_cb), device='cuda')
+    gz = dev(synth.normal(5, N, D))
+    gx1, gw1 = ops.vq_backward(xd, wd, idd, gz, gcb, gcb, True, True, ordered=True)
+    gx2, gw2 = ops.vq_backward(xd, wd, idd, gz, gcb, gcb, True, True, ordered=True)
+    assert torch.equal(gw1, gw2) and torch.equal(gx1, gx2)
+    gx3, gw3 = ops.vq_backward(xd, wd, idd, gz, gcb, gcb, True, True, ordered=False)
+    assert torch.equal(gx1, gx3)
+    np.testing.assert_allclose(gw1.cpu().numpy(), gw3.cpu().numpy(), rtol=2e-4, atol=1e-7)
+    kw = np.float32(g_cb * np.float32(np.float32(2.0) / (np.float32(N) * np.float32(D))))
+    _, ref = _ordered_sum_reference(lambda n, k: kw * (w[k] - x[n]), idx, K, D)
+    np.testing.assert_array_equal(gw1.cpu().numpy(), ref)

@@ -99,3 +99,22 @@ def test_integration_table_names_exist():
             assert hasattr(connectors if reg == 'VQITConnectorRegistry' else Q, n), n
     with pytest.raises(ImportError):           # the reference package is not in this image
         integration.register_into_reference()
+
+
+def test_ordered_sum_policy():
+    """ops.use_ordered: explicit request, torch's deterministic flag, size-based default, environment override."""
+    import torch
+    from vector_quantization_amd import ops
+    assert ops.use_ordered(16384, 256, True) and not ops.use_ordered(16384, 256, False)
+    assert not ops.use_ordered(16384, 256, None, 3072) and ops.use_ordered(16384, 256, None, 524288)
+    assert ops.use_ordered(1024, 256, None, 65536) and not ops.use_ordered(65536, 256, None, 524288)
+    with pytest.raises(ValueError):
+        ops.use_ordered(65536, 256, True)
+    prev = torch.are_deterministic_algorithms_enabled()
+    try:
+        torch.use_deterministic_algorithms(True)
+        assert ops.use_ordered(16384, 256, None, 16)
+        with pytest.raises(RuntimeError):
+            ops.use_ordered(16384, 6, None, 16)
+    finally:
+        torch.use_deterministic_algorithms(prev)

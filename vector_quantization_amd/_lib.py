@@ -44,6 +44,11 @@ SIGNATURES = {
     'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vqhip_codebook_metrics': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_argmin_stats': (_i32, [_vp, _vp, _vp]),
+    'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),
+    'vqhip_token_order': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_segsum_workspace_bytes': (_i64, [_i64, _i32]),
+    'vqhip_segsum_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    'vqhip_vq_backward_w_ordered': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     'vqhip_debug_proposal_scores': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_profile_enable': (_i32, [_i32]),
     'vqhip_set_tuning': (_i32, [_i32, _i32]),

@@ -164,6 +164,22 @@ static int run_exact_rows(const void *x, int x_dtype, const float *e, const floa
     return VQHIP_OK;
 }
 
+template <int MODE>
+static int run_segsum(const void *src, int x_dtype, const float *e, const int64_t *idx, const int32_t *order,
+                      const int32_t *offsets, int64_t N, int64_t K, int D, const float *g_cb, float *dst, void *ws,
+                      hipStream_t s) {
+    float *partial = (float *)ws;
+    const int64_t nranges = (N + VQ_SEG_RANGE - 1) / VQ_SEG_RANGE;
+    int grid = (int)((nranges + 3) / 4); grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+    if (x_dtype == VQHIP_DTYPE_F32) segsum_rows_kernel<MODE, 0><<<grid, 256, 0, s>>>(src, e, idx, order, offsets, N, (int)K, D, g_cb, dst, partial);
+    else segsum_rows_kernel<MODE, 1><<<grid, 256, 0, s>>>(src, e, idx, order, offsets, N, (int)K, D, g_cb, dst, partial);
+    VQ_CHECK_LAUNCH("segsum_rows_kernel");
+    int fgrid = (int)((K + 3) / 4); fgrid = fgrid > 2048 ? 2048 : fgrid;
+    segsum_fixup_kernel<<<fgrid, 256, 0, s>>>(offsets, (int)K, D, partial, dst);
+    VQ_CHECK_LAUNCH("segsum_fixup_kernel");
+    return VQHIP_OK;
+}
+
 extern "C" {
 
 int vqhip_version(void) { return VQHIP_VERSION; }
@@ -541,6 +557,61 @@ int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t 
     else return fail(VQHIP_EINVAL, "vqhip_vq_backward: x_dtype");
     VQ_CHECK_LAUNCH("vq_backward_kernel");
     return VQHIP_OK;
+}
+
+// ---- deterministic (ordered) codebook-side sums -----------------------------------------------------------------
+int64_t vqhip_order_workspace_bytes(int64_t N, int64_t K) {
+    if (N < 0 || K <= 0) return 0;
+    const int64_t nchunks = (N + VQ_SORT_CHUNK - 1) / VQ_SORT_CHUNK;
+    return (nchunks > 0 ? nchunks : 1) * K * 4;
+}
+
+int vqhip_token_order(const int64_t *idx, int64_t N, int64_t K, int32_t *counts, int32_t *offsets, int32_t *order, void *ws,
+                      void *stream) {
+    if (!idx || !counts || !offsets || !order || !ws || N < 0 || K <= 0) return fail(VQHIP_EINVAL, "vqhip_token_order: bad argument");
+    if (K > 32768) return fail(VQHIP_EINVAL, "vqhip_token_order: K > 32768 (per-chunk histogram must fit in LDS)");
+    if (N >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_token_order: N too large");
+    const int64_t nchunks = (N + VQ_SORT_CHUNK - 1) / VQ_SORT_CHUNK;
+    if (nchunks * K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_token_order: N*K too large for the ordered route");
+    hipStream_t s = (hipStream_t)stream;
+    int *blockhist = (int *)ws;
+    const size_t lds = (size_t)K * 4;
+    static size_t lds_set[16] = {0};
+    if (int rc = ensure_dyn_lds((const void *)sort_hist_kernel, lds, lds_set)) return rc;
+    if (nchunks > 0) {
+        sort_hist_kernel<<<(int)nchunks, VQ_SORT_CHUNK, lds, s>>>(idx, N, (int)K, blockhist);
+        VQ_CHECK_LAUNCH("sort_hist_kernel");
+    }
+    sort_colscan_kernel<<<(int)((K + 255) / 256), 256, 0, s>>>(blockhist, (int)nchunks, (int)K, counts);
+    VQ_CHECK_LAUNCH("sort_colscan_kernel");
+    sort_offsets_kernel<<<1, 1024, 0, s>>>(counts, (int)K, offsets);
+    VQ_CHECK_LAUNCH("sort_offsets_kernel");
+    if (nchunks > 0) {
+        sort_place_kernel<<<(int)nchunks, VQ_SORT_CHUNK, 0, s>>>(idx, N, (int)K, blockhist, offsets, order);
+        VQ_CHECK_LAUNCH("sort_place_kernel");
+    }
+    return VQHIP_OK;
+}
+
+int64_t vqhip_segsum_workspace_bytes(int64_t N, int D) {
+    if (N < 0 || D <= 0) return 0;
+    return ((N + VQ_SEG_RANGE - 1) / VQ_SEG_RANGE + 1) * 2 * (int64_t)D * 4;
+}
+
+int vqhip_segsum_rows(const float *src, const int64_t *idx, const int32_t *order, const int32_t *offsets, int64_t N, int64_t K,
+                      int D, float *dst, void *ws, void *stream) {
+    if (!src || !idx || !order || !offsets || !dst || !ws || N < 0 || K <= 0 || D <= 0 || (D % 4) != 0)
+        return fail(VQHIP_EINVAL, "vqhip_segsum_rows: bad argument (D must be a multiple of 4)");
+    return run_segsum<0>(src, VQHIP_DTYPE_F32, nullptr, idx, order, offsets, N, K, D, nullptr, dst, ws, (hipStream_t)stream);
+}
+
+int vqhip_vq_backward_w_ordered(const void *x, int x_dtype, const float *e, const int64_t *idx, const int32_t *order,
+                                const int32_t *offsets, int64_t N, int64_t K, int D, const float *g_cb, float *grad_w, void *ws,
+                                void *stream) {
+    if (!x || !e || !idx || !order || !offsets || !grad_w || !ws || N < 0 || K <= 0 || D <= 0 || (D % 4) != 0)
+        return fail(VQHIP_EINVAL, "vqhip_vq_backward_w_ordered: bad argument (D must be a multiple of 4)");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_vq_backward_w_ordered: x_dtype");
+    return run_segsum<1>(x, x_dtype, e, idx, order, offsets, N, K, D, g_cb, grad_w, ws, (hipStream_t)stream);
 }
 
 int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream) {

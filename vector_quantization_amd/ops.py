@@ -4,6 +4,7 @@ the HIP library.  torch is used only for device memory and the current HIP strea
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -195,10 +196,71 @@ def hist(idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch
     return out
 
 
-def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+ORDERED_MAX_K = 32768     # the ordered (deterministic) route keeps one code histogram per 1024-token chunk in LDS
+
+
+def use_ordered(K: int, D: int, ordered: Optional[bool] = None, N: Optional[int] = None) -> bool:
+    """Policy of the codebook-side sums (k-means centroid sums, codebook gradient).  The ordered route — tokens sorted
+    by code, sums in a fixed order, bit-reproducible — is taken when asked for explicitly, under
+    ``torch.use_deterministic_algorithms(True)``, and by default where it is also the faster one on MI355X (measured,
+    tools/bench_ordered.py): large batches (N >= 262144) or contended small codebooks (K <= 4096, N >= 32768).
+    Otherwise fp32 atomics.  It needs K <= 32768 and D % 4 == 0.  ``VQHIP_ORDERED=0/1`` overrides the default."""
+    ok = K <= ORDERED_MAX_K and D % 4 == 0
+    if ordered is None:
+        if torch.are_deterministic_algorithms_enabled():
+            if not ok:
+                raise RuntimeError(f'vector_quantization_amd: no deterministic codebook-side sum for K={K}, D={D} '
+                                   f'(needs K <= {ORDERED_MAX_K} and D % 4 == 0)')
+            return True
+        env = os.environ.get('VQHIP_ORDERED')
+        if env is not None:
+            return env != '0' and ok
+        return ok and N is not None and (N >= 262144 or (K <= 4096 and N >= 32768))
+    if ordered and not ok:
+        raise ValueError(f'ordered sums need K <= {ORDERED_MAX_K} and D % 4 == 0 (got K={K}, D={D})')
+    return bool(ordered)
+
+
+def token_order(idx: torch.Tensor, K: int):
+    """Stable counting sort of the token ids by code: (counts int32[K], offsets int32[K+1], order int32[N])."""
+    _require_cuda(idx)
+    idx = idx.reshape(-1).contiguous()
+    assert idx.dtype == torch.int64
+    N = idx.numel()
+    L = _lib.lib()
+    counts = torch.empty(K, dtype=torch.int32, device=idx.device)
+    offsets = torch.empty(K + 1, dtype=torch.int32, device=idx.device)
+    order = torch.empty(max(N, 1), dtype=torch.int32, device=idx.device)
+    ws = _bytes(L.vqhip_order_workspace_bytes(N, K), idx.device)
+    check(L.vqhip_token_order(_ptr(idx), N, K, _ptr(counts), _ptr(offsets), _ptr(order), _ptr(ws), _stream()),
+          'vqhip_token_order')
+    return counts, offsets, order[:N]
+
+
+def segsum_rows(src: torch.Tensor, idx: torch.Tensor, offsets: torch.Tensor, order: torch.Tensor, K: int) -> torch.Tensor:
+    """out[k] = sum of src[order[p]] for p in [offsets[k], offsets[k+1]) in the fixed blocked order of the ordered route
+    (fp32; see include/vqhip.h)."""
+    _require_cuda(src, idx, offsets, order)
+    src = src.float().contiguous()
+    N, D = src.shape
+    L = _lib.lib()
+    out = torch.empty(K, D, dtype=torch.float32, device=src.device)
+    ws = _bytes(L.vqhip_segsum_workspace_bytes(N, D), src.device)
+    check(L.vqhip_segsum_rows(_ptr(src), _ptr(idx), _ptr(order), _ptr(offsets), N, K, D, _ptr(out), _ptr(ws), _stream()),
+          'vqhip_segsum_rows')
+    return out
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None,
+                     ordered: Optional[bool] = None) -> torch.Tensor:
+    """out[idx[n]] += src[n] (centroid sums / dense embedding backward).  Ordered route (see ``use_ordered``) when no
+    accumulator is passed in; fp32 atomics otherwise."""
     _require_cuda(src, idx)
     src = src.float().contiguous()
     idx = idx.reshape(-1).contiguous()
+    if out is None and use_ordered(K, src.shape[1], ordered, src.shape[0]):
+        _, offsets, order = token_order(idx, K)
+        return segsum_rows(src, idx, offsets, order, K)
     if out is None:
         out = torch.zeros(K, src.shape[1], dtype=torch.float32, device=src.device)
     check(_lib.lib().vqhip_scatter_add_rows(_ptr(src), _ptr(idx), src.shape[0], K, src.shape[1], _ptr(out), _stream()),
@@ -300,22 +362,36 @@ def normalize_rows_bwd(v: torch.Tensor, g: torch.Tensor, eps: float = 1e-12) -> 
 
 
 def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Optional[torch.Tensor],
-                g_cb: Optional[torch.Tensor], g_cm: Optional[torch.Tensor], need_x: bool, need_w: bool):
-    """Fused backward of the quantizer forward; returns (grad_x fp32 or None, grad_w fp32 [K, D] or None)."""
+                g_cb: Optional[torch.Tensor], g_cm: Optional[torch.Tensor], need_x: bool, need_w: bool,
+                ordered: Optional[bool] = None):
+    """Fused backward of the quantizer forward; returns (grad_x fp32 or None, grad_w fp32 [K, D] or None).  The
+    codebook gradient is summed code by code in token order (``use_ordered``) or with fp32 atomics."""
     _require_cuda(x, e, idx)
     x, dt = _latents(x)
     e = _codebook(e)
     idx = idx.reshape(-1).contiguous()
     N, D = x.shape
-    gx = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_x else None
-    gw = torch.zeros(e.shape, dtype=torch.float32, device=x.device) if need_w else None
-    if gx is None and gw is None:
+    K = e.shape[0]
+    if not need_x and not need_w:
         return None, None
+    L = _lib.lib()
+    gx = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_x else None
     if g_zste is not None:
         g_zste = g_zste.float().contiguous()
     scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cb, g_cm)]
-    check(_lib.lib().vqhip_vq_backward(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
-                                       _ptr(gx), _ptr(gw), _stream()), 'vqhip_vq_backward')
+    ordered_w = need_w and use_ordered(K, D, ordered, N)
+    gw = None
+    if need_w:
+        gw = torch.empty(e.shape, dtype=torch.float32, device=x.device) if ordered_w else \
+            torch.zeros(e.shape, dtype=torch.float32, device=x.device)
+    if need_x or (need_w and not ordered_w):
+        check(L.vqhip_vq_backward(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
+                                  _ptr(gx), None if ordered_w else _ptr(gw), _stream()), 'vqhip_vq_backward')
+    if ordered_w:
+        _, offsets, order = token_order(idx, K)
+        ws = _bytes(L.vqhip_segsum_workspace_bytes(N, D), x.device)
+        check(L.vqhip_vq_backward_w_ordered(_ptr(x), dt, _ptr(e), _ptr(idx), _ptr(order), _ptr(offsets), N, K, D,
+                                            _ptr(scal[0]), _ptr(gw), _ptr(ws), _stream()), 'vqhip_vq_backward_w_ordered')
     return gx, gw
 
 
