@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised campaign on the GPU: vqhip_argmin (fp16 proposals + exact re-rank) against vqhip_argmin_exact (all-fp32
 MFMA, itself bit-equal to the CPU oracle in tests/) at sizes the CPU oracle cannot reach.  Any mismatch is a bug.
-usage: fuzz_vs_exact.py [seconds]"""
+usage: fuzz_vs_exact.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vector_quantization_amd import ops
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-g = torch.Generator(device='cuda').manual_seed(20261003)
+g = torch.Generator(device='cuda').manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 20261003)
 def ri(lo, hi): return int(torch.randint(lo, hi, (1,), generator=g, device='cuda').item())
 t_end = time.time() + budget
 trials = bad = 0
@@ -51,6 +51,13 @@ while time.time() < t_end:
         rows = torch.arange(N, device='cuda')[:, None].expand(N, K)
         cref = torch.where(d == d.min(0, keepdim=True).values, rows, N).min(0).values
         nb += int((col != cref).sum().item())
+    # ordered (deterministic) centroid sums against a float64 index_add, and bit-reproducibility
+    if K <= 32768 and D % 4 == 0 and ri(0, 8) == 0:
+        a = ops.scatter_add_rows(x, ref, K, ordered=True); b = ops.scatter_add_rows(x, ref, K, ordered=True)
+        r64 = torch.zeros(K, D, dtype=torch.float64, device='cuda').index_add_(0, ref, x.double())
+        tol = 1e-5 * float(x.abs().max()) * max(1.0, N / K) + 1e-30
+        if not torch.equal(a, b) or float((a.double() - r64).abs().max()) > tol * 50:
+            nb += 1
     trials += 1
     if nb:
         bad += 1
