@@ -107,7 +107,8 @@ def test_ordered_sum_policy():
     from vector_quantization_amd import ops
     assert ops.use_ordered(16384, 256, True) and not ops.use_ordered(16384, 256, False)
     assert not ops.use_ordered(16384, 256, None, 3072) and ops.use_ordered(16384, 256, None, 524288)
-    assert ops.use_ordered(1024, 256, None, 65536) and not ops.use_ordered(65536, 256, None, 524288)
+    assert ops.use_ordered(16384, 256, None, 65536) and not ops.use_ordered(16384, 256, None, 65536, backward=True)
+    assert ops.use_ordered(1024, 256, None, 65536, backward=True) and not ops.use_ordered(65536, 256, None, 524288)
     with pytest.raises(ValueError):
         ops.use_ordered(65536, 256, True)
     prev = torch.are_deterministic_algorithms_enabled()

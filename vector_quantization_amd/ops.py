@@ -199,11 +199,12 @@ def hist(idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch
 ORDERED_MAX_K = 32768     # the ordered (deterministic) route keeps one code histogram per 1024-token chunk in LDS
 
 
-def use_ordered(K: int, D: int, ordered: Optional[bool] = None, N: Optional[int] = None) -> bool:
+def use_ordered(K: int, D: int, ordered: Optional[bool] = None, N: Optional[int] = None, backward: bool = False) -> bool:
     """Policy of the codebook-side sums (k-means centroid sums, codebook gradient).  The ordered route — tokens sorted
     by code, sums in a fixed order, bit-reproducible — is taken when asked for explicitly, under
     ``torch.use_deterministic_algorithms(True)``, and by default where it is also the faster one on MI355X (measured,
-    tools/bench_ordered.py): large batches (N >= 262144) or contended small codebooks (K <= 4096, N >= 32768).
+    tools/bench_ordered.py): centroid sums from N >= 32768; the fused backward (``backward=True``) from N >= 131072, or
+    from N >= 32768 on contended small codebooks (K <= 4096).
     Otherwise fp32 atomics.  It needs K <= 32768 and D % 4 == 0.  ``VQHIP_ORDERED=0/1`` overrides the default."""
     ok = K <= ORDERED_MAX_K and D % 4 == 0
     if ordered is None:
@@ -215,7 +216,11 @@ def use_ordered(K: int, D: int, ordered: Optional[bool] = None, N: Optional[int]
         env = os.environ.get('VQHIP_ORDERED')
         if env is not None:
             return env != '0' and ok
-        return ok and N is not None and (N >= 262144 or (K <= 4096 and N >= 32768))
+        if not ok or N is None:
+            return False
+        if backward:
+            return N >= 131072 or (K <= 4096 and N >= 32768)
+        return N >= 32768
     if ordered and not ok:
         raise ValueError(f'ordered sums need K <= {ORDERED_MAX_K} and D % 4 == 0 (got K={K}, D={D})')
     return bool(ordered)
@@ -379,7 +384,7 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
     if g_zste is not None:
         g_zste = g_zste.float().contiguous()
     scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cb, g_cm)]
-    ordered_w = need_w and use_ordered(K, D, ordered, N)
+    ordered_w = need_w and use_ordered(K, D, ordered, N, backward=True)
     gw = None
     if need_w:
         gw = torch.empty(e.shape, dtype=torch.float32, device=x.device) if ordered_w else \
