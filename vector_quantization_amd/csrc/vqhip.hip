@@ -484,8 +484,16 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
 int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream) {
     if (!idx || !hist || N < 0 || K <= 0) return fail(VQHIP_EINVAL, "vqhip_hist: bad argument");
     if (N == 0) return VQHIP_OK;
-    int grid = (int)((N + 255) / 256); grid = grid > 2048 ? 2048 : grid;
-    hist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, N, K, hist);
+    if (K <= 32768 && N >= 16384) {
+        // enough tokens per block that the K-bin flush pays: at most 256 blocks, >= 2048 tokens each
+        static size_t lds_set[16] = {0};
+        if (int rc = ensure_dyn_lds((const void *)hist_lds_kernel, (size_t)K * 4, lds_set)) return rc;
+        int grid = (int)((N + 2047) / 2048); grid = grid > 256 ? 256 : grid;
+        hist_lds_kernel<<<grid, 1024, (size_t)K * 4, (hipStream_t)stream>>>(idx, N, (int)K, hist);
+    } else {
+        int grid = (int)((N + 255) / 256); grid = grid > 2048 ? 2048 : grid;
+        hist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(idx, N, K, hist);
+    }
     VQ_CHECK_LAUNCH("hist_kernel");
     return VQHIP_OK;
 }

@@ -1434,6 +1434,25 @@ __global__ void hist_kernel(const int64_t *idx, int64_t N, int64_t K, int32_t *h
     }
 }
 
+// K <= 32768: block-private histogram in LDS, flushed with lane-contiguous atomics (a wave-instruction covers 64
+// neighbouring bins = 256 bytes) instead of 64 scattered ones per wave-instruction
+__global__ __launch_bounds__(1024) void hist_lds_kernel(const int64_t *__restrict__ idx, int64_t N, int K,
+                                                        int32_t *__restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int *h = (int *)lds;
+    for (int k = threadIdx.x; k < K; k += 1024) h[k] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 1024) {
+        const int64_t k = idx[i];
+        if (k >= 0 && k < K) atomicAdd(&h[k], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const int v = h[k];
+        if (v) atomicAdd(&hist[k], v);
+    }
+}
+
 // wave per source row; lanes sweep the row so each atomic wave-instruction adds 256 contiguous bytes
 __global__ void scatter_add_rows_kernel(const float *src, const int64_t *idx, int64_t N, int64_t K, int D, float *dst) {
     int64_t n = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
