@@ -1,4 +1,6 @@
 """rearrangement around the quantizer, on-disk token formats, codebook metrics."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -144,3 +146,19 @@ def test_quantize_token_major_equals_nchw():
     for a, b in list(zip(*outs))[:4]:
         assert torch.equal(a, b)
     assert torch.allclose(outs[0][4], outs[1][4], rtol=1e-5, atol=1e-6)     # codebook grad: atomic scatter-add order
+
+
+@pytest.mark.gpu
+def test_bulk_tokenization_loop_single_rank(tmp_path):
+    """tools/tokenize_synthetic.py (BASELINE configs[4] in miniature) at world size 1: token files in the reference's
+    layout, histogram-based metrics at the end."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('tokenize_synthetic', os.path.join(os.path.dirname(__file__), '..', 'tools', 'tokenize_synthetic.py'))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    summary = mod.main(['--work-dir', str(tmp_path), '--iters', '2', '--images', '8', '--codes', '512', '--dim', '32'])
+    files = sorted(p.name for p in (tmp_path / 'tokens').iterdir())
+    assert files == ['1_0.pth', '2_0.pth']
+    from vector_quantization_amd import tokenization as T
+    tok = T.load_tokens(tmp_path / 'tokens' / '1_0.pth')
+    assert tok['tokens'].shape == (8, 16, 16) and tok['tokens'].dtype == torch.int64 and len(tok['id_']) == 8
+    assert 0.0 < summary['codebook_usage'] <= 1.0 and summary['codebook_ppl'] > 0.0
