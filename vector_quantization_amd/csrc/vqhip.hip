@@ -69,12 +69,12 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
 static int g_tune_gather_grid = 0, g_tune_gather_nt = 0;   // gather kernel knobs (keys 3, 4)
 
-template <int NSTEP, int TT, int WAVES, int TPS>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, hipStream_t s) {
     constexpr int BM = WAVES * TT * 16;
-    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS>;
+    constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
     static size_t lds_set[16] = {0};
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
@@ -117,18 +117,18 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
-#define VQ_CFG(NS, TT, W, TPS)                                                                      \
+#define VQ_CFG(NS, TT, W, ...)                                                                      \
     {                                                                                               \
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
         int ns = pick_slices(ntb, L.nstages);                                                       \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TT, W, TPS>(ximg, N, frag, L.nstages, ns, rec, Np, s);         \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, s); \
     }
     switch (nstep) {
-        case 2: if (small) VQ_CFG(2, 2, 8, 4) else VQ_CFG(2, 4, 8, 4)
-        case 4: if (small) VQ_CFG(4, 2, 8, 4) else VQ_CFG(4, 4, 8, 4)
-        case 8: if (small) VQ_CFG(8, 2, 8, 4) else VQ_CFG(8, 4, 8, 4)
-        case 16: if (small) VQ_CFG(16, 2, 8, 4) else VQ_CFG(16, 4, 8, 4)
+        case 2: if (small) VQ_CFG(2, 2, 8, 4, 4) else VQ_CFG(2, 4, 8, 4, 4)
+        case 4: if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4)
+        case 8: if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4)
+        case 16: if (small) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
         case 32: VQ_CFG(32, 2, 8, 2)
         case 48: VQ_CFG(48, 2, 8, 1)
         case 64: VQ_CFG(64, 1, 8, 1)
@@ -301,7 +301,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         int rrc = VQHIP_OK;
         switch (L.nstep) {
 #define VQ_RESCAN(NS, TT, TPS) case NS: rrc = launch_rescan_cfg<NS, TT, 8, TPS>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
-            VQ_RESCAN(2, 2, 4) VQ_RESCAN(4, 2, 4) VQ_RESCAN(8, 2, 4) VQ_RESCAN(16, 2, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
+            VQ_RESCAN(2, 2, 4) VQ_RESCAN(4, 2, 4) VQ_RESCAN(8, 2, 4) VQ_RESCAN(16, 2, VQ_TPS16) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }
@@ -688,7 +688,7 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
     const char *frag = c + L.off_frag;
     switch (L.nstep) {
 #define VQ_DBG(NS, TPS) case NS: debug_scores_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, N, K, scores); break;
-        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, 4) VQ_DBG(32, 2) VQ_DBG(48, 1) VQ_DBG(64, 1)
+        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, VQ_TPS16) VQ_DBG(32, 2) VQ_DBG(48, 1) VQ_DBG(64, 1)
 #undef VQ_DBG
         default: return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: unsupported padded D");
     }

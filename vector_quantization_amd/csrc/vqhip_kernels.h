@@ -427,7 +427,7 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
 // MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
 // The epilogue of tile t-1 (3 VALU per element) is spread over the MFMAs of tile t (two accumulator sets ping-pong).
-template <int NSTEP, int TT, int WAVES, int TPS>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
 __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np) {
@@ -470,7 +470,14 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                 (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
     };
 
+    // NBUF == 4: ring of four stages filled two ahead, and the second half of the waves (the SIMD partners of the
+    // first half) runs one stage behind.  Measured at D = 256 against the double-buffered form with stages twice the
+    // size: ring and look-ahead -6 %, the lag another -2 % (lagging the odd waves instead: -1 % less; three ahead
+    // without lag: +9 % slower) — MI355X guide, 'Two waves per SIMD', item 9
+    constexpr int AHEAD = NBUF >= 4 ? 2 : 1;
+    const int lag = (NBUF >= 4 && wave >= WAVES / 2) ? 1 : 0;
     if (st0 < st1) issue_stage(st0, 0);
+    if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
 
     f32x4 accA[2][TT], accB[2][TT];
@@ -481,9 +488,11 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) accB[c][t][q] = -3.0e38f;   // "previous tile" of the very first tile: never wins
 
-    for (int64_t st = st0; st < st1; ++st) {
-        const int buf = (int)((st - st0) & 1);
-        if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+    for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
+        if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+        const int64_t st = it - lag;
+        if (st < st0 || st >= st1) { __syncthreads(); continue; }
+        const int buf = (int)((st - st0) % NBUF);
         const char *base = lds + buf * STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll

@@ -24,7 +24,9 @@ VQ_HD int vq_padded_d(int D) {
 }
 VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 1024 && (D % 8) == 0; }
 // tiles (32 codes) staged per LDS stage
-VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 16 ? 4 : (nstep <= 32 ? 2 : 1); }
+// (the proposal kernel keeps a ring of four stages up to D = 256: 4 x 33 KiB at D = 256, hence two tiles per stage there)
+#define VQ_TPS16 2
+VQ_HD int vq_tiles_per_stage(int nstep) { return nstep < 16 ? 4 : (nstep <= 32 ? 2 : 1); }
 
 struct VqCbLayout {
     int64_t K, Kp;          // codes, codes padded to a whole stage
