@@ -85,11 +85,11 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     return VQHIP_OK;
 }
 
-template <int NSTEP, int TT, int WAVES, int TPS>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
 static int launch_rescan_cfg(const char *rimg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
                              const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
-    constexpr int LDS = 2 * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
-    auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS>;
+    constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
+    auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
     static size_t lds_set[16] = {0};
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     kern<<<256, WAVES * 64, LDS, s>>>(rimg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
@@ -300,8 +300,8 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("rescan_pack_kernel");
         int rrc = VQHIP_OK;
         switch (L.nstep) {
-#define VQ_RESCAN(NS, TT, TPS) case NS: rrc = launch_rescan_cfg<NS, TT, 8, TPS>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
-            VQ_RESCAN(2, 2, 4) VQ_RESCAN(4, 2, 4) VQ_RESCAN(8, 2, 4) VQ_RESCAN(16, 2, VQ_TPS16) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
+#define VQ_RESCAN(NS, TT, ...) case NS: rrc = launch_rescan_cfg<NS, TT, 8, __VA_ARGS__>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
+            VQ_RESCAN(2, 2, 4, 4) VQ_RESCAN(4, 2, 4, 4) VQ_RESCAN(8, 2, 4, 4) VQ_RESCAN(16, 2, VQ_TPS16, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }

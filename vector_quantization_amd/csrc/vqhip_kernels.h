@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void rescan_pack_kernel(const char *__restrict
 // codebook stages arrive by double-buffered LDS-DMA and are shared by the 8 waves — as a persistent grid over
 // (block of WAVES*TT*16 queued rows, slice of stages) items, the slice count chosen on the device from the queue
 // length so that every workgroup gets an item.
-template <int NSTEP, int TT, int WAVES, int TPS>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
 __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restrict__ rimg, const char *__restrict__ frag,
                                                             int64_t nstages, const int *__restrict__ rescan_list,
                                                             const int *__restrict__ counters, const float *__restrict__ thr,
@@ -773,8 +773,9 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
     constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);
     // hits are collected per row in LDS (LDS atomics) and appended to the global lists once per item, one global
     // atomic per (row, item): a returning global atomic inside the MFMA loop stalls its wave for a memory round trip
-    int *lcnt = (int *)(lds + 2 * STAGE_BYTES);                       // [BM]
-    uint32_t *lcand = (uint32_t *)(lds + 2 * STAGE_BYTES) + BM;        // [BM][VQ_RESCAN_LOCAL]
+    int *lcnt = (int *)(lds + NBUF * STAGE_BYTES);                    // [BM]
+    uint32_t *lcand = (uint32_t *)(lds + NBUF * STAGE_BYTES) + BM;     // [BM][VQ_RESCAN_LOCAL]
+    constexpr int AHEAD = NBUF >= 4 ? 2 : 1;                          // ring of four stages, filled two ahead
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
     if (nrows <= 0) return;
@@ -796,6 +797,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
         const int64_t sl = item % ns, tb = item / ns;
         const int64_t st0 = (nstages * sl) / ns, st1 = (nstages * (sl + 1)) / ns;
         issue_stage(st0, 0);
+        if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
         for (int i = threadIdx.x; i < BM; i += WAVES * 64) lcnt[i] = 0;
         half8 xf[TT][NS32];
         float mythr[TT];
@@ -813,8 +815,8 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
         }
         __syncthreads();   // stage st0 landed
         for (int64_t st = st0; st < st1; ++st) {
-            const int buf = (int)((st - st0) & 1);
-            if (st + 1 < st1) issue_stage(st + 1, buf ^ 1);
+            const int buf = (int)((st - st0) % NBUF);
+            if (st + AHEAD < st1) issue_stage(st + AHEAD, (int)((st + AHEAD - st0) % NBUF));
             const char *base = lds + buf * STAGE_BYTES;
             const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
 #pragma unroll
