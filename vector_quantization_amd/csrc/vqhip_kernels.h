@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
     // first half) runs one stage behind.  Measured at D = 256 against the double-buffered form with stages twice the
     // size: ring and look-ahead -6 %, the lag another -2 % (lagging the odd waves instead: -1 % less; three ahead
     // without lag: +9 % slower) — MI355X guide, 'Two waves per SIMD', item 9
-    constexpr int AHEAD = NBUF >= 4 ? 2 : 1;
+    constexpr int AHEAD = NBUF >= 3 ? 2 : 1;                 // NBUF == 3 (large D): two ahead, no lag
     const int lag = (NBUF >= 4 && wave >= WAVES / 2) ? 1 : 0;
     if (st0 < st1) issue_stage(st0, 0);
     if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
