@@ -39,7 +39,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--images', type=int, default=2048, help='images per GPU per step (256 tokens each)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
