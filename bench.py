@@ -92,13 +92,21 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU path)'
+    # VQ_BENCH_SHARE_GPU=1 is a plumbing check for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
+    # two timing collectives run over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    share_gpu = os.environ.get('VQ_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', device_id=dev)
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from vector_quantization_amd import _lib, ops
 
@@ -137,7 +145,7 @@ def main():
     _lib.check(L.vqhip_profile_collect(ctypes.byref(ms_sum), ctypes.byref(launches)), 'vqhip_profile_collect')
     L.vqhip_profile_enable(0)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device='cpu' if share_gpu else dev)
     if distributed:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
