@@ -119,3 +119,25 @@ def test_ordered_sum_policy():
             ops.use_ordered(16384, 6, None, 16)
     finally:
         torch.use_deterministic_algorithms(prev)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The JSON line bench.py printed on the MI355X (committed under profiles/) carries every field of the driver's
+    contract, the roofline object and the CPU baseline object."""
+    import glob
+    import json
+    import os
+    root = os.path.join(os.path.dirname(__file__), '..', 'profiles')
+    path = sorted(glob.glob(os.path.join(root, 'r01_*_bench.json')))[-1]
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in line, key
+    assert line['scaling'] == 'weak' and line['vs_baseline'] is None and line['data'] == 'synthetic'
+    assert 'workload' in line['config'] and 'model' not in line['config']
+    roof = line['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in roof, key
+    assert roof['bound'] in ('hbm', 'mfma') and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9
+    tokens = line['config']['tokens_per_gpu_per_step'] * line['n_gpus'] * 1e3 / line['ms_per_step']
+    assert abs(tokens - line['value']) / line['value'] < 1e-6
