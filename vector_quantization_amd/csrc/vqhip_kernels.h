@@ -873,7 +873,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
     }
 }
 
-// Exact fp32 evaluation of the candidates of the queued rows.  A wave owns P = max(8, S) (row, candidate slot) pairs:
+// Exact fp32 evaluation of the candidates of the queued rows.  A wave owns P = max(16, S) (row, candidate slot) pairs:
 // the S slots of a row sit in S neighbouring lanes (S a power of two, 4..32), lane p < P runs the oracle's fma chain
 // (d order) of pair p, and all 64 lanes move the operands: per 32-dim segment the wave fetches the 128-byte piece of
 // every pair's code row (8 lanes x 16 bytes per piece, whole cache lines) and of its latent rows one segment ahead
@@ -904,9 +904,9 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float *en = (const float *)(cb + L.off_en);
     const int nrows = counters[SRC == 0 ? 1 : 0];
-    const int P = S < 8 ? 8 : S;                              // pairs per wave (8, 16 or 32)
+    const int P = S < 16 ? 16 : S;                            // pairs per wave (16 or 32)
     const int ne = P >> 3;                                    // load instructions per code segment
-    const int rpw = P / S;                                    // rows per wave (<= 2)
+    const int rpw = P / S;                                    // rows per wave (<= 4)
     const bool chain = lane < P;
     const int j = lane & (S - 1);                             // this lane's slot
     const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
