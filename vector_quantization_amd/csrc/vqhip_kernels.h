@@ -422,7 +422,8 @@ __device__ __forceinline__ void top_merge_lane(Top2 &t, int xor_mask) {   // fol
 __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); }
 
 // One workgroup = WAVES waves x TT token tiles of 16 tokens held in registers as MFMA B fragments for the whole kernel;
-// it streams one slice of the codebook image through a double-buffered LDS ring (global_load_lds, one stage ahead) and
+// it streams one slice of the codebook image through an LDS ring of NBUF stages (global_load_lds; four stages filled two
+// ahead up to D = 256, a double buffer above) and
 // keeps, per lane and token, the best score with its tile / register and the runner-up value.
 // Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
 // MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(256) void rescan_pack_kernel(const char *__restrict
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
 // operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
 // candidate list.  Same machinery as coarse_kernel — the rows' fragments (from the packed image) stay in registers,
-// codebook stages arrive by double-buffered LDS-DMA and are shared by the 8 waves — as a persistent grid over
+// codebook stages arrive by LDS-DMA through the same ring and are shared by the 8 waves — as a persistent grid over
 // (block of WAVES*TT*16 queued rows, slice of stages) items, the slice count chosen on the device from the queue
 // length so that every workgroup gets an item.
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
