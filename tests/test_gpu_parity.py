@@ -547,3 +547,22 @@ def test_ordered_codebook_gradient(ops, dtype):
     kw = np.float32(g_cb * np.float32(np.float32(2.0) / (np.float32(N) * np.float32(D))))
     _, ref = _ordered_sum_reference(lambda n, k: kw * (w[k] - x[n]), idx, K, D)
     np.testing.assert_array_equal(gw1.cpu().numpy(), ref)
+
+
+def test_c_abi_standalone_program():
+    """examples/abi_argmin.cpp: a C++ program that links libvqhip.so directly (HIP runtime only: no Python, no torch in
+    the process) — compiled with hipcc on the GPU box, it quantizes, cross-checks against the fp32 entry point and a host
+    nearest-neighbour, and reports the path counters."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    libdir = os.path.join(root, 'vector_quantization_amd')
+    exe = os.path.join('/tmp', f'abi_argmin_{os.getpid()}')
+    build = subprocess.run([hipcc, '--offload-arch=gfx950', '-I' + os.path.join(root, 'include'),
+                            os.path.join(root, 'examples', 'abi_argmin.cpp'), '-L' + libdir, '-lvqhip',
+                            '-Wl,-rpath,' + libdir, '-o', exe], capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(run.stdout)
+    assert run.returncode == 0 and 'ABI OK' in run.stdout, run.stdout + run.stderr
