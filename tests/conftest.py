@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The built libraries are git-ignored: a fresh checkout builds them once (hipcc cross-compiles gfx950 without a GPU;
+    # gcc builds the CPU oracle).  An existing build is used as is.
+    from vector_quantization_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    from oracle import c_oracle
+    c_oracle.build(force=False)
 
 
 def _has_gpu() -> bool:
