@@ -37,6 +37,11 @@ ENCODE_CASES = [
     ('cos_int_small',          'int',          3,    64,   48,    16,  'Cosine', False, 'commitment_norm'),
     ('norml2_llamagen_d8',     'normal',       3407, 2048, 16384, 8,   'L2',     True,  'vqgan'),
     ('normcos_vqkd_d32',       'normal',       11,   1024, 2048,  32,  'Cosine', True,  'commitment_norm'),
+    # configs/cluster (CLIP/DINO/MAE/ViT features): D=768, K=8192, cosine, two 14x14 token maps
+    ('cos_cluster_d768',       'normal',       768,  392,  8192,  768, 'Cosine', False, 'commitment_norm'),
+    # the remaining proposal-kernel instantiations (D=512: 32 k-steps, D=1024: 64) and a ragged codebook
+    ('l2_d512_ragged',         'normal',       512,  333,  1001,  512, 'L2',     False, 'vqgan'),
+    ('l2_d1024',               'planted',      1024, 257,  700,   1024, 'L2',    False, 'vqgan'),
 ]
 
 
