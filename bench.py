@@ -170,7 +170,8 @@ def main():
             'metric': 'quantized tokens/sec, VQGAN quantizer forward K=16384 D=256',
             'value': tokens / elapsed, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16-mfma proposals + f32 exact decision',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16+f32',
+            'dtype_note': 'f16 MFMA (f32 accumulate) proposes candidates under a rigorous bound; the decision is exact f32',
             'data': 'synthetic',
             'config': {'workload': 'VQGAN K=16384 D=256, 256x256 images -> 16x16 tokens, bf16 latents, '
                                    'full quantizer forward (prepare+argmin+gather+STE+loss)',
