@@ -1,5 +1,6 @@
 from .anchors import BaseAnchor, CachedAnchor, MultinomialAnchor, NearestAnchor
-from .base import BaseQuantizer, ModuleDict, build_module_dict, get_memo
+from .memo import ModuleDict, build_module_dict, get_memo
+from .quantizer_api import BaseQuantizer
 from .callbacks import (BaseCallback, ComposedCallback, CVQVAECallback, LazyInitWeightsMixin, NormalizeCallback,
                         QuantizerHolderMixin, UpdateMixin, VQKDCallback)
 from .distances import BaseDistance, CosineDistance, L2Distance, LazyDistance, as_distance_tensor

@@ -13,7 +13,7 @@ from .. import ops
 from ..config import Config
 from ..registries import AnchorRegistry
 from ..utils import Store, get_world_size, is_sync
-from .base import Memo
+from .memo import Memo
 from .distances import LazyDistance, as_distance_tensor
 
 

@@ -17,7 +17,8 @@ from .. import ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
 from ..utils import EMA, PriorityQueue, Store, all_reduce_statistics, get_rank, get_world_size, is_sync
-from .base import BaseQuantizer, Memo
+from .memo import Memo
+from .quantizer_api import BaseQuantizer
 from .statistics import QuantStatistics
 
 if TYPE_CHECKING:

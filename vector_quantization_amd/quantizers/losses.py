@@ -11,7 +11,7 @@ from torch import nn
 from .. import functional as VF
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import VQITQuantizerLossRegistry
-from .base import Memo
+from .memo import Memo
 from .distances import as_distance_tensor
 
 

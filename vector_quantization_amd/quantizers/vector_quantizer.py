@@ -11,7 +11,8 @@ from .. import functional as VF
 from .. import ops
 from ..config import Config, Item, RegistryMeta
 from ..registries import InitRegistry, ModelRegistry, VQITQuantizerDistanceRegistry, VQITQuantizerRegistry
-from .base import BaseQuantizer, Memo, get_memo
+from .memo import Memo, get_memo
+from .quantizer_api import BaseQuantizer
 from .distances import BaseDistance, LazyDistance
 from .losses import CodebookLoss, CommitmentLoss, VQGANLoss
 

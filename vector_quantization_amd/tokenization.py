@@ -78,7 +78,7 @@ def to_map(z: torch.Tensor, b: int, h: int, w: int, token_major: bool = False) -
 
 def quantize(quantizer, x: torch.Tensor, memo: dict):
     """BaseModel.quantize (models/base.py:116-128): returns (z [B,C,H,W], q_loss, memo)."""
-    from .quantizers.base import get_memo
+    from .quantizers.memo import get_memo
     b, _, h, w = x.shape
     quantizer_memo = get_memo(memo, 'quantizer')
     quantizer_memo['x_shape'] = x.shape
@@ -89,7 +89,7 @@ def quantize(quantizer, x: torch.Tensor, memo: dict):
 
 def encode_to_quant(quantizer, x: torch.Tensor, memo: dict):
     """BaseModel.encode_to_quant after the encoder (models/base.py:135-146): returns (quant [B,H,W], memo)."""
-    from .quantizers.base import get_memo
+    from .quantizers.memo import get_memo
     b, _, h, w = x.shape
     quantizer_memo = get_memo(memo, 'quantizer')
     quantizer_memo['x_shape'] = x.shape
@@ -102,7 +102,7 @@ def encode_to_quant(quantizer, x: torch.Tensor, memo: dict):
 def decode_from_quant(quantizer, quant: torch.Tensor, memo: dict, token_major: bool = False):
     """BaseModel.decode_from_quant before the decoder (image_reconstruction/models.py:97-106): quant [B,H,W] →
     z [B,C,H,W] (``token_major=True``: as a zero-copy channels-last view of the gathered rows)."""
-    from .quantizers.base import get_memo
+    from .quantizers.memo import get_memo
     b, h, w = quant.shape
     z, memo['quantizer'] = quantizer.decode(quant.reshape(-1), get_memo(memo, 'quantizer'))
     return to_map(z, b, h, w, token_major), memo
