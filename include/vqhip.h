@@ -120,6 +120,16 @@ int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t 
  *        2 = update w only from the current p, 3 = both. */
 int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
                      const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage, void *stream);
+/* The same update for a subset of the codes.  decay_k == 1.0f (every code with p_k above ~1e-6 at K = 16384) multiplies
+ * the code's anchor by exactly 0, so only the codes with decay_k < 1 need an anchor at all: vqhip_cvq_decay writes
+ * decay[K] with the update's own expression (bit for bit), the caller selects rows = {k : decay_k < 1}, computes /
+ * all-reduces anchors for those M codes only, and vqhip_cvq_update_rows applies
+ *   w[rows[i]] = w[rows[i]]*decay + anchors_sub[i]*(1-decay).
+ * Identical to stage 2 of vqhip_cvq_update on every finite input (a skipped code keeps w_k instead of w_k*1 + a*0: only a
+ * negative-zero weight or a non-finite anchor could tell the difference). */
+int vqhip_cvq_decay(const float *p, int64_t K, float ema_decay, float eps, float *decay, void *stream);
+int vqhip_cvq_update_rows(float *w, const float *p, const int64_t *rows, const float *anchors_sub, int64_t M, int64_t K, int D,
+                          float ema_decay, float eps, void *stream);
 /* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
 int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
                       void *stream);

@@ -253,3 +253,32 @@ def test_deterministic_mode_reproducible_codebook_gradient():
     z, loss, _ = q(xi, {})
     (loss + (z * z).mean()).backward()                  # default policy at this size: atomics
     assert torch.allclose(q.embedding.weight.grad, grads[0][0], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dist', ['L2', 'Cosine'])
+def test_cvq_sparse_anchor_exchange_same_result(dist):
+    """CVQVAECallback(sparse_anchors=True): anchors only for the codes whose decay is below 1 (the others are multiplied
+    by exactly 0).  Several training steps give bit-identical codebooks and probabilities to the dense data flow."""
+    N, K, D = 3000, 2048, 64
+    g = synth.rng(31)
+    w0 = synth.unit_rows(g.standard_normal((K, D), dtype=np.float32))
+    xs = [g.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + w0[g.integers(0, K // 8, N)] for _ in range(4)]
+    outs = []
+    for sparse in (False, True):
+        cfg = vqgan_cfg(K, D, dist, callbacks=[dict(type='CVQVAECallback', ema=dict(), sparse_anchors=sparse,
+                                                    anchor=dict(type='NearestAnchor'))])
+        q = build(cfg, train=True, init=dict(type='vqgan'))
+        set_weight(q, w0)
+        quants = []
+        for x in xs:                                     # most tokens sit on an eighth of the codes: the rest go stale
+            _, _, memo = q(torch.from_numpy(x).cuda(), {})
+            quants.append(memo['quant'].clone())
+        outs.append((q.embedding.weight.detach().clone(), q.get_buffer('_probability').clone(), quants))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    from vector_quantization_amd import ops
+    decay = ops.cvq_decay(outs[1][1].contiguous(), K, 0.99, 1e-3)
+    frac = float((decay < 1.0).float().mean())
+    assert 0.0 < frac < 1.0, frac                         # the test exercises both kinds of code

@@ -30,6 +30,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 run('CVQ-VAE', dict(type='VQGANQuantizer', embedding=emb(16384, 256), distance=dict(type='CosineDistance'),
                     losses=dict(vqgan_loss=dict(type='VQGANLoss')),
                     callbacks=[dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]), N, 16384, 256)
+run('CVQ-VAE sparse anchors', dict(type='VQGANQuantizer', embedding=emb(16384, 256), distance=dict(type='CosineDistance'),
+                    losses=dict(vqgan_loss=dict(type='VQGANLoss')),
+                    callbacks=[dict(type='CVQVAECallback', ema=dict(), sparse_anchors=True, anchor=dict(type='NearestAnchor'))]), N, 16384, 256)
 run('VQ-KD  ', dict(type='VQKDQuantizer', embedding=emb(8192, 32), distance=dict(type='CosineDistance'),
                     losses=dict(vqgan_loss=dict(type='VQGANLoss', mse=dict(norm=True))),
                     callbacks=[dict(type='VQKDCallback', ema=dict())]), 512 * 196 // 8, 8192, 32)

@@ -534,6 +534,23 @@ int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, con
     return VQHIP_OK;
 }
 
+int vqhip_cvq_decay(const float *p, int64_t K, float ema_decay, float eps, float *decay, void *stream) {
+    if (!p || !decay || K <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_decay: bad argument");
+    cvq_decay_kernel<<<(int)((K + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, K, ema_decay, eps, decay);
+    VQ_CHECK_LAUNCH("cvq_decay_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_update_rows(float *w, const float *p, const int64_t *rows, const float *anchors_sub, int64_t M, int64_t K, int D,
+                          float ema_decay, float eps, void *stream) {
+    if (!w || !p || K <= 0 || D <= 0 || M < 0 || (M > 0 && (!rows || !anchors_sub)))
+        return fail(VQHIP_EINVAL, "vqhip_cvq_update_rows: bad argument");
+    if (M == 0) return VQHIP_OK;
+    cvq_update_rows_kernel<<<waves_grid(M, 4), 256, 0, (hipStream_t)stream>>>(w, p, rows, anchors_sub, M, K, D, ema_decay, eps);
+    VQ_CHECK_LAUNCH("cvq_update_rows_kernel");
+    return VQHIP_OK;
+}
+
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
     if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
     VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));

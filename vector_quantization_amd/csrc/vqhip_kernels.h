@@ -1524,6 +1524,10 @@ __global__ void vqkd_update_kernel(float *w, const int64_t *hist, const float *s
 }
 
 // CVQ-VAE update, wave per code (quantizer_callback.py:94-102)
+__device__ __forceinline__ float cvq_decay_of(float pk, int64_t K, float ema_decay, float eps) {
+    return 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
+}
+
 __global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
                                   const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage) {
     int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
@@ -1537,11 +1541,29 @@ __global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64
         pk = pk * ema_decay + freq * (1.0f - ema_decay);
     }
     if (stage & 2) {
-        float decay = 1.0f - expf(-pk * (float)K * 10.0f / (1.0f - ema_decay) - eps);
+        float decay = cvq_decay_of(pk, K, ema_decay, eps);
         float om = 1.0f - decay;
         for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors[k * D + d] * om;
     }
     if (lane == 0 && (stage & 1)) p[k] = pk;
+}
+
+// decay_k of every code (the same expression, bit for bit): decay_k == 1.0f means the code's anchor is multiplied by 0
+__global__ void cvq_decay_kernel(const float *p, int64_t K, float ema_decay, float eps, float *decay) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) decay[k] = cvq_decay_of(p[k], K, ema_decay, eps);
+}
+
+// the w update restricted to the listed codes: w[rows[i]] = w[rows[i]]*decay + anchors_sub[i]*(1-decay)
+__global__ void cvq_update_rows_kernel(float *w, const float *p, const int64_t *rows, const float *anchors_sub, int64_t M,
+                                       int64_t K, int D, float ema_decay, float eps) {
+    int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (i >= M) return;
+    const int64_t k = rows[i];
+    if (k < 0 || k >= K) return;
+    const float decay = cvq_decay_of(p[k], K, ema_decay, eps), om = 1.0f - decay;
+    for (int d = lane; d < D; d += 64) w[k * D + d] = w[k * D + d] * decay + anchors_sub[i * D + d] * om;
 }
 
 // ------------------------------------------------------------------------------------------------

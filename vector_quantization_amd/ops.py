@@ -311,6 +311,29 @@ def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: Optional[torch.Tensor]
                                       _stream()), 'vqhip_cvq_update')
 
 
+def cvq_decay(p: torch.Tensor, K: int, ema_decay: float, eps: float) -> torch.Tensor:
+    """decay_k = 1 - exp(-p_k*K*10/(1-ema_decay) - eps) with the update kernel's own expression (fp32 [K])."""
+    _require_cuda(p)
+    assert p.dtype == torch.float32 and p.is_contiguous()
+    out = torch.empty(K, dtype=torch.float32, device=p.device)
+    check(_lib.lib().vqhip_cvq_decay(_ptr(p), K, ema_decay, eps, _ptr(out), _stream()), 'vqhip_cvq_decay')
+    return out
+
+
+def cvq_update_rows_(w: torch.Tensor, p: torch.Tensor, rows: torch.Tensor, anchors_sub: torch.Tensor, ema_decay: float,
+                     eps: float) -> None:
+    """In place: w[rows[i]] = w[rows[i]]*decay + anchors_sub[i]*(1-decay) — stage 2 of the CVQ-VAE update for the
+    listed codes only (the others have decay == 1 and would keep their weight anyway)."""
+    _require_cuda(w, p, rows, anchors_sub)
+    assert w.dtype == torch.float32 and w.is_contiguous() and p.dtype == torch.float32 and p.is_contiguous()
+    rows = rows.to(torch.int64).contiguous()
+    anchors_sub = anchors_sub.float().contiguous()
+    K, D = w.shape
+    assert anchors_sub.shape == (rows.numel(), D)
+    check(_lib.lib().vqhip_cvq_update_rows(_ptr(w), _ptr(p), _ptr(rows), _ptr(anchors_sub), rows.numel(), K, D, ema_decay,
+                                           eps, _stream()), 'vqhip_cvq_update_rows')
+
+
 def _any(t: torch.Tensor):
     """Flat contiguous fp32/bf16 view + dtype code for the elementwise kernels."""
     if t.dtype not in (torch.float32, torch.bfloat16):

@@ -17,6 +17,8 @@ from .. import ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
 from ..utils import EMA, PriorityQueue, Store, all_reduce_statistics, get_rank, get_world_size, is_sync
+from .anchors import NearestAnchor
+from .distances import LazyDistance
 from .memo import Memo
 from .quantizer_api import BaseQuantizer
 from .statistics import QuantStatistics
@@ -285,10 +287,16 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
 @VQITQuantizerCallbackRegistry.register_()
 class CVQVAECallback(UpdateMixin, BaseCallback):
 
-    def __init__(self, *args, anchor, eps: float = 1e-3, **kwargs) -> None:
+    def __init__(self, *args, anchor, eps: float = 1e-3, sparse_anchors: bool = False, **kwargs) -> None:
+        """``sparse_anchors`` (extension, default off = the reference's data flow): anchors are computed, all-reduced
+        and applied only for the codes whose decay is below 1 — every code in regular use has decay == 1.0f exactly
+        and its anchor is multiplied by 0.  Same result (see include/vqhip.h, vqhip_cvq_update_rows), a column argmin
+        over a fraction of the codebook and an [M, D] instead of a [K, D] all-reduce; costs one host synchronisation
+        per step (the number of such codes sizes the exchange).  NearestAnchor only."""
         super().__init__(*args, **kwargs)
         self._anchor = anchor
         self._eps = eps
+        self._sparse_anchors = sparse_anchors
 
     @classmethod
     def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
@@ -322,6 +330,16 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         p = self.probability.to(device=e.device, dtype=torch.float32).clone()
         ops.cvq_update_(e, p, hist, numel, None, self._ema.decay, self._eps, stage=1)      # p = ema(p, hist/numel)
         self._update_probability(p)
+        if self._sparse_anchors and isinstance(self._anchor, NearestAnchor) and isinstance(d, LazyDistance):
+            decay = ops.cvq_decay(p, K, self._ema.decay, self._eps)
+            rows = torch.nonzero(decay < 1.0).reshape(-1)      # host sync; the same set on every rank (p is synchronised)
+            if rows.numel():
+                e_sub = e.index_select(0, rows)
+                d_sub = LazyDistance(d._distance, x.detach(), e_sub)
+                anchors, memo = self._anchor(x.detach(), e_sub, d_sub, quant, p.index_select(0, rows), memo=memo)
+                ops.cvq_update_rows_(e, p, rows, anchors, self._ema.decay, self._eps)
+            self._update_embedding(e)
+            return quant
         anchors, memo = self._anchor(x.detach(), e, d, quant, p, memo=memo)
         # decay = 1 - exp(-p*K*10/(1-ema.decay) - eps); e = e*decay + anchors*(1-decay)
         ops.cvq_update_(e, p, None, None, anchors, self._ema.decay, self._eps, stage=2)
