@@ -1,23 +1,46 @@
-"""Generate tests/golden/*.npz — run in the BUILD CONTAINER (CPU torch), commit the outputs.
+"""Generate tests/golden/*.npz FROM THE REFERENCE'S OWN SOURCE FILES — run in the build container, commit the outputs.
 
-    python -m oracle.make_golden
+    python -m oracle.make_golden            # all fixtures (≈1 min on 8 cores)
 
-The reference package itself is not importable here (needs todd_ai + python>=3.11); the
-fixtures are produced by ``oracle/torch_ref.py``, which calls the same ATen ops in the same order as
-the reference's quantizer.  Inputs are regenerated from seeds by ``oracle/synth.py`` (their sha256 is
-stored); small known-answer cases store their inputs verbatim.  Fixtures hold data only.
+Every expected value below is produced by executing the reference's modules where they lie under /root/reference
+(``oracle/ref_import.py``: the real ``VQGANQuantizer`` / ``VQKDQuantizer`` built from the reference's config dicts
+through its own registries, with ``L2Distance``/``CosineDistance``, ``VQGANLoss``/``CommitmentLoss``,
+``NormalizeCallback``, ``VQKDCallback``, ``CVQVAECallback``, ``NearestAnchor``/``MultinomialAnchor``/``CachedAnchor``,
+``QuantStatistics``, ``ste``).  Each ``.npz`` carries ``spec['source'] == 'reference-import'`` and the reference
+file:line ranges that computed it.  The script also asserts, case by case, that the restatement
+``oracle/torch_ref.py`` (which travels to the GPU box as bench.py's CPU baseline and as the float reference of the GPU
+tests) gives byte-identical results; ``tests/test_reference_pin.py`` repeats that check in the CPU suite.
+
+What is NOT the reference's: ``todd.utils.ema/EMA`` and ``todd.models.losses.MSELoss(norm=)`` are un-vendored and
+follow SURVEY.md §8c (``ref_import._ToddArithmetic``).
+
+Inputs are regenerated from seeds by ``oracle/synth.py`` (their sha256 is stored); small known-answer cases store
+their inputs verbatim.  Fixtures hold data only.
 """
 from __future__ import annotations
 
 import json
 import os
+import random
+import sys
+import tempfile
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
-from . import synth, torch_ref as tr
+from . import ref_import, synth, torch_ref as tr
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+EMB = 'torch_nn_modules_sparse_Embedding'          # configs/vq/interface.py:7
+
+CITE_ENCODE = ['vq/tasks/image_tokenization/models/quantizers/base.py:123-182', 'vq/algorithms/vq/quantizers.py:92-117',
+               'vq/algorithms/vq/distances.py:28-46', 'vq/algorithms/vq/losses.py:41-127',
+               'vq/tasks/image_tokenization/models/quantizers/utils/ste.py:9-10', 'vq/algorithms/vq/utils.py:13-52',
+               'vq/algorithms/vq/callbacks/normalize.py:22-29', 'vq/algorithms/vq/callbacks/update.py:53-56']
+CITE_VQKD = ['vq/algorithms/vqkd/quantizers/callbacks.py:26-129', 'vq/algorithms/vq/callbacks/normalize.py:22-29']
+CITE_CVQ = ['vq/algorithms/cvqvae/quantizer_callback.py:60-105', 'vq/algorithms/cvqvae/anchors.py:41-166',
+            'vq/algorithms/vq/utils.py:13-52']
 
 # name, kind, seed, N, K, D, distance, normalize(NormalizeCallback), loss
 ENCODE_CASES = [
@@ -42,25 +65,84 @@ ENCODE_CASES = [
     # the remaining proposal-kernel instantiations (D=512: 32 k-steps, D=1024: 64) and a ragged codebook
     ('l2_d512_ragged',         'normal',       512,  333,  1001,  512, 'L2',     False, 'vqgan'),
     ('l2_d1024',               'planted',      1024, 257,  700,   1024, 'L2',    False, 'vqgan'),
+    # BASELINE configs[3] at full codebook size: CVQ-VAE default distance (cosine), per-rank batch 12x256 tokens
+    ('cos_c4_k16384_s3407',    'normal',       3408, 3072, 16384, 256, 'Cosine', False, 'vqgan'),
 ]
+
+
+# ---- the reference's quantizers, built from the reference's config dicts ----------------------------------------
+
+def quantizer_config(K, D, distance, loss, callbacks=()):
+    """configs/vqgan/model.py:19-23, configs/vqkd/model.py:20-26, configs/vq/{interface,distance,num_embeddings}.py."""
+    cfg = dict(embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D), distance=dict(type=f'{distance}Distance'),
+               callbacks=[dict(c) for c in callbacks])
+    if loss == 'vqgan':
+        cfg.update(type='VQGANQuantizer', losses=dict(vqgan_loss=dict(type='VQGANLoss')), init_weights=dict(type='vqgan'))
+    elif loss == 'commitment_norm':
+        cfg.update(type='VQKDQuantizer', losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True))))
+    else:
+        raise ValueError(loss)
+    return cfg
+
+
+def ref_quantizer(K, D, distance, loss, callbacks=(), w=None, train=False):
+    ref = ref_import.load()
+    q = ref.build_quantizer(quantizer_config(K, D, distance, loss, callbacks))
+    q.eval()
+    if any(c.get('type') == 'VQKDCallback' for c in callbacks):
+        # the one-shot lazy-init hook (lazy_init_weights.py:28-37) fires on the first forward; in eval mode it returns
+        # early (vqkd/quantizers/callbacks.py:84-85) and removes itself: the fixtures start from a GIVEN codebook
+        q(torch.zeros(2, D), {})
+        assert len(q._forward_pre_hooks) == 0
+    if w is not None:
+        q.embedding.weight.data = torch.as_tensor(w).clone()
+    q.train(train)
+    return q
+
+
+def ref_forward(x, w, distance, loss, normalize):
+    """One eval-mode BaseQuantizer.forward of the real reference module; returns the same dict as torch_ref.forward
+    plus the distance matrix and the histogram."""
+    K, D = w.shape
+    q = ref_quantizer(K, D, distance, loss, [dict(type='NormalizeCallback')] if normalize else (), w)
+    with torch.no_grad():
+        z_ste, l, memo = q(torch.as_tensor(x), {})
+        z, _ = q.decode(memo['quant'], {})
+    ref = ref_import.load()
+    hist = ref.QuantStatistics(quant=memo['quant'], codebook_size=K).bin_count()
+    return dict(x=memo['x'], w=q.embedding.weight.detach(), quant=memo['quant'], z=z, z_ste=z_ste, loss=l,
+                d=memo['encode']['distance'], hist=hist, loss_memo=dict(memo['loss']))
+
+
+def same(a, b) -> bool:
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return a.dtype == b.dtype and a.shape == b.shape and a.numpy().tobytes() == b.numpy().tobytes()
+
+
+def check_restatement(tag, got: dict, want: dict, keys):
+    for k in keys:
+        assert same(got[k], want[k]), f'{tag}: oracle/torch_ref.py differs from the reference import on {k!r}'
 
 
 def encode_case(name, kind, seed, N, K, D, distance, normalize, loss):
     x, w = synth.make_inputs(kind, seed, N, K, D)
-    out = tr.forward(torch.from_numpy(x), torch.from_numpy(w), distance, loss, normalize=normalize)
+    out = ref_forward(x, w, distance, loss, normalize)
+    rest = tr.forward(torch.from_numpy(x), torch.from_numpy(w), distance, loss, normalize=normalize)
+    check_restatement(name, rest, out, ('x', 'w', 'quant', 'z', 'z_ste', 'loss'))
+    assert same(tr.bin_count(rest['quant'], K), out['hist'])
     quant = out['quant'].numpy()
-    xe = out['x']
-    d = tr.DISTANCES[distance](xe, out['w'])
-    mind = d.gather(1, out['quant'].reshape(-1, 1)).reshape(-1).numpy()
+    mind = out['d'].gather(1, out['quant'].reshape(-1, 1)).reshape(-1).numpy()
     rec = dict(
         spec=json.dumps(dict(name=name, kind=kind, seed=seed, N=N, K=K, D=D, distance=distance,
-                             normalize=normalize, loss=loss, torch=torch.__version__)),
+                             normalize=normalize, loss=loss, torch=torch.__version__,
+                             source='reference-import', reference=CITE_ENCODE)),
         x_sha=synth.sha(x), w_sha=synth.sha(w),
         quant=quant.astype(np.int32), mind=mind.astype(np.float32),
         loss=np.float32(out['loss'].item()),
-        hist=tr.bin_count(out['quant'], K).numpy().astype(np.int32),
+        hist=out['hist'].numpy().astype(np.int32),
         z_sha=synth.sha(out['z'].numpy()), zste_sha=synth.sha(out['z_ste'].numpy()),
         z_head=out['z'].numpy()[:8], zste_head=out['z_ste'].numpy()[:8],
+        col_idx=out['d'].argmin(0).numpy().astype(np.int32),          # NearestAnchor._anchors (cvqvae/anchors.py:83)
     )
     if N * D + K * D <= 1 << 14:   # small KATs carry their inputs
         rec['x'] = x
@@ -70,7 +152,7 @@ def encode_case(name, kind, seed, N, K, D, distance, normalize, loss):
 
 
 def special_case():
-    """NaN / Inf handling of cdist + argmin (torch: NaN is the minimum, first NaN wins)."""
+    """NaN / Inf handling of cdist + argmin (torch: NaN is the minimum, first NaN wins) through the real _encode."""
     N, K, D = 32, 64, 32
     x, w = synth.make_inputs('normal', 21, N, K, D)
     x[3, 5] = np.nan
@@ -78,78 +160,298 @@ def special_case():
     x[9, 2] = -np.inf
     w2 = w.copy()
     w2[10, 1] = np.nan                      # a NaN code poisons its whole column
-    q1 = tr.encode(torch.from_numpy(x), torch.from_numpy(w), 'L2')[0].numpy()
-    q2 = tr.encode(torch.from_numpy(x), torch.from_numpy(w2), 'L2')[0].numpy()
-    q3 = tr.encode(torch.from_numpy(x), torch.from_numpy(w), 'Cosine')[0].numpy()
+    outs = []
+    for ww, dist in ((w, 'L2'), (w2, 'L2'), (w, 'Cosine')):
+        q = ref_quantizer(K, D, dist, 'vqgan', (), ww)
+        with torch.no_grad():
+            quant = q.encode(torch.from_numpy(x), {})[1]
+        assert same(quant, tr.encode(torch.from_numpy(x), torch.from_numpy(ww), dist)[0])
+        outs.append(quant.numpy().astype(np.int32))
     np.savez_compressed(os.path.join(OUT, 'special_nonfinite.npz'), x=x, w=w, w_nan=w2,
-                        quant_l2=q1.astype(np.int32), quant_l2_wnan=q2.astype(np.int32),
-                        quant_cos=q3.astype(np.int32))
+                        quant_l2=outs[0], quant_l2_wnan=outs[1], quant_cos=outs[2],
+                        spec=json.dumps(dict(source='reference-import', reference=CITE_ENCODE[1:3])))
+
+
+# ---- codebook updates: the real callbacks in train mode, one rank and two gloo ranks ----------------------------
+
+UPD = dict(N=2048, K=512, D=32, seed=31, ema_decay=0.99, eps=1e-3)
+VQKD_CB = [dict(type='VQKDCallback', ema=dict())]                                     # configs/vqkd/model.py:22
+
+
+def cvq_cb(anchor='NearestAnchor', sync=False):
+    return [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type=anchor, sync=sync))]  # configs/cvqvae/quantizer.py:1-5
+
+
+def update_inputs():
+    x, w = synth.make_inputs('normal', UPD['seed'], UPD['N'], UPD['K'], UPD['D'])
+    return x, synth.unit_rows(w)
+
+
+def trace_ema():
+    """Record the (anchors, decay) the reference hands to todd.utils.ema (quantizer_callback.py:102)."""
+    ref = ref_import.load()
+    calls = []
+    orig = ref.todd.utils.ema
+
+    def spy(a, b, decay):
+        calls.append((b.clone(), torch.as_tensor(decay).clone()))
+        return orig(a, b, decay)
+
+    ref.todd.utils.ema = spy
+    return calls, lambda: setattr(ref.todd.utils, 'ema', orig)
+
+
+def vqkd_step(x, w):
+    q = ref_quantizer(UPD['K'], UPD['D'], 'Cosine', 'commitment_norm', VQKD_CB, w, train=True)
+    xt = torch.as_tensor(x).clone().requires_grad_(True)
+    z, loss, memo = q(xt, {})
+    loss.backward()
+    return dict(quant=memo['quant'], w_new=q.embedding.weight.detach().clone(), loss=loss.detach(), grad_x=xt.grad,
+                z=z.detach())
+
+
+def cvq_steps(x, w, dist, anchor='NearestAnchor', sync=False, steps=2):
+    q = ref_quantizer(UPD['K'], UPD['D'], dist, 'vqgan', cvq_cb(anchor, sync), w, train=True)
+    calls, undo = trace_ema()
+    outs = []
+    try:
+        for _ in range(steps):
+            with torch.no_grad():
+                z, loss, memo = q(torch.as_tensor(x), {})
+            anchors, decay = calls[-1]
+            outs.append(dict(quant=memo['quant'], col_idx=memo['encode']['distance'].argmin(0),
+                             p=q.get_buffer('_probability').clone(), w_new=q.embedding.weight.detach().clone(),
+                             anchors=anchors, decay=decay))
+    finally:
+        undo()
+    return outs
+
+
+def _rank_worker(rank, world, port, outdir):
+    """One gloo rank running the REAL reference callbacks on rows rank::world (DistributedSampler-style shards)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DRY_RUN='1')   # DRY_RUN: the reference's is_sync asserts run
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(0)                  # identical nn.Embedding init on every rank (the reference's DDP broadcast)
+    x, w = update_inputs()
+    xr = x[rank::world]
+    rec = {}
+    o = vqkd_step(xr, w)
+    rec['vqkd_quant'], rec['vqkd_w_new'] = o['quant'].numpy(), o['w_new'].numpy()
+    for dname in ('L2', 'Cosine'):
+        for sync in (False, True):
+            o = cvq_steps(xr, w, dname, sync=sync, steps=1)[0]
+            tag = f'cvq_{dname.lower()}_{"sync" if sync else "avg"}'
+            rec[f'{tag}_w_new'], rec[f'{tag}_p'] = o['w_new'].numpy(), o['p'].numpy()
+            rec[f'{tag}_col_idx'] = o['col_idx'].numpy()
+            rec[f'{tag}_quant'] = o['quant'].numpy()
+    # lazy k-means init across ranks: gather to rank 0, Lloyd iterations there, broadcast (callbacks.py:77-112)
+    # (DRY_RUN off here: inside the Lloyd loop only rank 0 calls _update_embedding, whose DRY_RUN is_sync assert is a
+    #  collective — the reference itself would hang there in a multi-rank dry run)
+    os.environ['DRY_RUN'] = ''
+    random.seed(1234)
+    ref = ref_import.load()
+    q = ref.build_quantizer(quantizer_config(64, UPD['D'], 'Cosine', 'commitment_norm', VQKD_CB))
+    q.train()
+    q(torch.from_numpy(xr[:256]), {})
+    rec['lazy_w'] = q.embedding.weight.detach().numpy()
+    np.savez(os.path.join(outdir, f'rank{rank}.npz'), **rec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def two_rank_reference():
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rank_worker, args=(2, 29731, d), nprocs=2, join=True)
+        return [dict(np.load(os.path.join(d, f'rank{r}.npz'))) for r in range(2)]
 
 
 def update_cases():
-    """One VQ-KD k-means/EMA step and one CVQ-VAE step, single rank and emulated 2-rank sums (F4)."""
-    N, K, D = 2048, 512, 32
-    x, w = synth.make_inputs('normal', 31, N, K, D)
-    w = synth.unit_rows(w)
+    x, w = update_inputs()
     xt, wt = torch.from_numpy(x), torch.from_numpy(w)
-    # --- VQ-KD (cosine, NormalizeCallback semantics: x normalised before encode) ---
-    xn = torch.nn.functional.normalize(xt)
-    quant, _ = tr.encode(xn, wt, 'Cosine')
-    w1 = tr.vqkd_after_encode(xn, quant, wt, ema_decay=0.99)
-    # 2 ranks: rank r holds rows r::2 ; the all-reduced hist / sums are the sums of the per-rank ones
-    hs, ss = [], []
-    for r in range(2):
-        xr, qr = xn[r::2], quant[r::2]
-        hs.append(tr.bin_count(qr, K))
-        c = torch.zeros_like(wt)
-        c.scatter_add_(0, qr.reshape(-1, 1).expand(-1, D), torch.nn.functional.normalize(xr))
-        ss.append(c)
-    w1_2rank = tr.vqkd_after_encode(xn[0::2], quant[0::2], wt, 0.99, hs[0] + hs[1], ss[0] + ss[1])
-    np.savez_compressed(os.path.join(OUT, 'update_vqkd.npz'), x_sha=synth.sha(x), w_sha=synth.sha(w),
-                        quant=quant.numpy().astype(np.int32), w_new=w1.numpy(),
-                        w_new_2rank=w1_2rank.numpy(),
-                        spec=json.dumps(dict(N=N, K=K, D=D, seed=31, ema_decay=0.99)))
-    # --- CVQ-VAE (L2 and cosine variants), NearestAnchor, sync=False ---
+    ranks = two_rank_reference()
+    for k in ranks[0]:
+        if k.endswith('w_new') or k.endswith('_p') or k == 'lazy_w':
+            assert ranks[0][k].tobytes() == ranks[1][k].tobytes(), f'reference ranks disagree on {k}'
+    # --- VQ-KD: NormalizeCallback.before_encode + VQKDCallback.after_encode ---
+    o = vqkd_step(x, w)
+    r = tr.vqkd_train_step(xt, wt, UPD['ema_decay'])
+    check_restatement('update_vqkd', r, o, ('quant', 'w_new', 'loss', 'grad_x'))
+    r2 = tr.vqkd_train_step_2rank(xt, wt, UPD['ema_decay'])
+    assert same(r2['w_new'], ranks[0]['vqkd_w_new']), 'torch_ref 2-rank VQ-KD emulation differs from the 2-process reference run'
+    np.savez_compressed(
+        os.path.join(OUT, 'update_vqkd.npz'), x_sha=synth.sha(x), w_sha=synth.sha(w),
+        quant=o['quant'].numpy().astype(np.int32), w_new=o['w_new'].numpy(), loss=np.float32(o['loss'].item()),
+        grad_x_sha=synth.sha(o['grad_x'].numpy()), grad_x_head=o['grad_x'].numpy()[:8],
+        w_new_2rank=ranks[0]['vqkd_w_new'], quant_rank0=ranks[0]['vqkd_quant'].astype(np.int32),
+        quant_rank1=ranks[1]['vqkd_quant'].astype(np.int32),
+        spec=json.dumps(dict(UPD, source='reference-import', reference=CITE_VQKD,
+                             two_rank='two gloo processes running the reference callbacks on rows r::2')))
+    # --- CVQ-VAE (L2 and cosine), NearestAnchor ---
     for dist in ('L2', 'Cosine'):
-        quant, d = tr.encode(xt, wt, dist)
-        p0 = torch.zeros(K)
-        w_new, p1, anchors, indices, decay = tr.cvq_after_encode(xt, quant, d, wt, p0, 0.99, 1e-3)
-        # second step from the updated state (p no longer zero)
-        quant2, d2 = tr.encode(xt, w_new, dist)
-        w_new2, p2, _, indices2, _ = tr.cvq_after_encode(xt, quant2, d2, w_new, p1, 0.99, 1e-3)
-        # emulated 2 ranks (sync=False): stats all-reduced, anchors averaged
-        halves = []
-        for r in range(2):
-            xr = xt[r::2]
-            qr, dr = tr.encode(xr, wt, dist)
-            halves.append((xr, qr, dr))
-        hist = sum(tr.bin_count(h[1], K) for h in halves)
-        numel = torch.tensor(N)
-        a_other = tr.nearest_anchor(halves[1][0], halves[1][2])[0]
-        w_2r, p_2r, _, idx_r0, _ = tr.cvq_after_encode(
-            halves[0][0], halves[0][1], halves[0][2], wt, p0, 0.99, 1e-3,
-            world_hist=hist, world_numel=numel, world_size=2, other_anchors=[a_other])
+        s1, s2 = cvq_steps(x, w, dist)
+        r = tr.cvq_train_steps(xt, wt, dist, UPD['ema_decay'], UPD['eps'], steps=2)
+        for got, want, tag in ((r[0], s1, 'step1'), (r[1], s2, 'step2')):
+            check_restatement(f'update_cvq_{dist}.{tag}', got, want, ('quant', 'col_idx', 'p', 'w_new', 'anchors', 'decay'))
+        tag = f'cvq_{dist.lower()}'
+        r2 = tr.cvq_train_step_2rank(xt, wt, dist, UPD['ema_decay'], UPD['eps'])
+        assert same(r2['avg']['w_new'], ranks[0][f'{tag}_avg_w_new']) and same(r2['avg']['p'], ranks[0][f'{tag}_avg_p'])
+        assert same(r2['sync']['w_new'], ranks[0][f'{tag}_sync_w_new'])
         np.savez_compressed(
             os.path.join(OUT, f'update_cvq_{dist.lower()}.npz'), x_sha=synth.sha(x), w_sha=synth.sha(w),
-            quant=quant.numpy().astype(np.int32), col_idx=indices.numpy().astype(np.int32),
-            p1=p1.numpy(), decay=decay.numpy(), w_new=w_new.numpy(),
-            quant2=quant2.numpy().astype(np.int32), col_idx2=indices2.numpy().astype(np.int32),
-            p2=p2.numpy(), w_new2=w_new2.numpy(),
-            w_new_2rank=w_2r.numpy(), p_2rank=p_2r.numpy(), col_idx_rank0=idx_r0.numpy().astype(np.int32),
-            spec=json.dumps(dict(N=N, K=K, D=D, seed=31, ema_decay=0.99, eps=1e-3, distance=dist)))
+            quant=s1['quant'].numpy().astype(np.int32), col_idx=s1['col_idx'].numpy().astype(np.int32),
+            p1=s1['p'].numpy(), decay=s1['decay'].numpy(), w_new=s1['w_new'].numpy(),
+            quant2=s2['quant'].numpy().astype(np.int32), col_idx2=s2['col_idx'].numpy().astype(np.int32),
+            p2=s2['p'].numpy(), w_new2=s2['w_new'].numpy(),
+            w_new_2rank=ranks[0][f'{tag}_avg_w_new'], p_2rank=ranks[0][f'{tag}_avg_p'],
+            col_idx_rank0=ranks[0][f'{tag}_avg_col_idx'].astype(np.int32),
+            col_idx_rank1=ranks[1][f'{tag}_avg_col_idx'].astype(np.int32),
+            w_new_2rank_sync=ranks[0][f'{tag}_sync_w_new'], p_2rank_sync=ranks[0][f'{tag}_sync_p'],
+            col_idx_2rank_sync=ranks[0][f'{tag}_sync_col_idx'].astype(np.int32),
+            spec=json.dumps(dict(UPD, distance=dist, source='reference-import', reference=CITE_CVQ,
+                                 two_rank='two gloo processes running the reference callbacks on rows r::2; '
+                                          '"avg" = NearestAnchor(sync=False) (anchors.py:64-67), '
+                                          '"sync" = NearestAnchor(sync=True) (anchors.py:50-57)')))
+    np.savez_compressed(os.path.join(OUT, 'lazy_init_2rank.npz'), w=ranks[0]['lazy_w'],
+                        spec=json.dumps(dict(K=64, D=UPD['D'], N_per_rank=256, seed=1234, source='reference-import',
+                                             reference=['vq/algorithms/vqkd/quantizers/callbacks.py:26-35,77-112'])))
 
 
-def main():
+# ---- k-means lazy init (single rank), alternative anchors, EntropyLoss -------------------------------------------
+
+def lazy_init_case():
+    """VQKDCallback.lazy_init_weights (callbacks.py:77-112) with a seeded random.sample; per-iteration assignments are
+    recorded by wrapping the reference quantizer's _encode."""
+    N, K, D, seed = 4096, 256, 32, 1234
+    x, _ = synth.make_inputs('normal', 41, N, K, D)
+    ref = ref_import.load()
+    q = ref.build_quantizer(quantizer_config(K, D, 'Cosine', 'commitment_norm', VQKD_CB))
+    w0 = q.embedding.weight.detach().clone()
+    q.train()
+    quants, books = [], []
+    inner = q._encode
+
+    def spy(xx, memo):
+        quant, memo = inner(xx, memo)
+        quants.append(quant.clone())
+        books.append(q.embedding.weight.detach().clone())
+        return quant, memo
+
+    q._encode = spy
+    after_init = []
+    # registered after the one-shot lazy-init hook, so it sees the codebook exactly as lazy_init_weights left it
+    q.register_forward_pre_hook(lambda m, a: after_init.append(m.embedding.weight.detach().clone()))
+    random.seed(seed)
+    with torch.no_grad():
+        q(torch.from_numpy(x), {})
+    assert len(quants) == 11                                    # 10 Lloyd iterations + the forward's own encode
+    random.seed(seed)
+    r = tr.vqkd_lazy_init(torch.from_numpy(x), w0, iters=10)
+    assert same(r['indices'], torch.as_tensor(random.Random(seed).sample(range(N), K)))
+    for i in range(10):
+        assert same(r['quants'][i], quants[i]), f'lazy init: torch_ref differs from the reference at Lloyd iteration {i}'
+    assert same(r['w'], after_init[0])
+    np.savez_compressed(
+        os.path.join(OUT, 'lazy_init_vqkd.npz'), x_sha=synth.sha(x), indices=r['indices'].numpy().astype(np.int32),
+        quants=torch.stack(quants[:10]).numpy().astype(np.int16), books_first=books[0].numpy(), w_init=after_init[0].numpy(),
+        spec=json.dumps(dict(N=N, K=K, D=D, x_seed=41, seed=seed, iters=10, source='reference-import',
+                             reference=['vq/algorithms/vqkd/quantizers/callbacks.py:77-112'])))
+
+
+def anchor_cases():
+    """MultinomialAnchor (anchors.py:88-104) and CachedAnchor (:107-166) called directly, as CVQVAECallback does."""
+    ref = ref_import.load()
+    N, K, D = 256, 64, 32
+    x, w = synth.make_inputs('normal', 51, N, K, D)
+    xt, wt = torch.from_numpy(x), torch.from_numpy(synth.unit_rows(w))
+    d = ref.L2Distance()(xt, wt)
+    quant = d.argmin(-1)
+    p = torch.zeros(K)
+    rec = dict(x_sha=synth.sha(x), w_sha=synth.sha(wt.numpy()))
+    # Multinomial: the sampling distribution is the parity target (device RNG streams differ by design)
+    torch.manual_seed(7)
+    a, _ = ref.MultinomialAnchor()(xt, wt, d, quant, p)
+    torch.manual_seed(7)
+    idx = d.T.softmax(1).multinomial(1).reshape(-1)
+    assert same(a, xt[idx])
+    rec['multinomial_probs'] = d.T.softmax(1).numpy()
+    rec['multinomial_idx_cpu_seed7'] = idx.numpy().astype(np.int32)
+    # Cached: host-side RNG (random.sample / CPU randperm) => reproducible on any device
+    ca = ref.CachedAnchor()
+    random.seed(11)
+    a1, _ = ca(xt, wt, d, quant, p)                                  # N > K: random.sample(range(N), K)
+    rec['cached_big'] = a1.numpy()
+    assert same(ca.cache, a1)
+    torch.manual_seed(12)
+    a2, _ = ca(xt[:K], wt, d[:K], quant[:K], p)                      # N == K: torch.randperm(K) on the CPU generator
+    rec['cached_eq'] = a2.numpy()
+    torch.manual_seed(13)
+    a3, _ = ca(xt[:40], wt, d[:40], quant[:40], p)                   # N < K with a cache: cat([x, cache]) then random.sample
+    rec['cached_small_with_cache'] = a3.numpy()
+    rec['cached_small_seed'] = np.int32(13)
+    np.savez_compressed(os.path.join(OUT, 'anchors_alt.npz'), **rec,
+                        spec=json.dumps(dict(N=N, K=K, D=D, seed=51, python_seed_big=11, torch_seed_eq=12,
+                                             python_seed_small=None, source='reference-import',
+                                             reference=['vq/algorithms/cvqvae/anchors.py:88-166'])))
+
+
+def entropy_case():
+    """EntropyLoss (losses.py:130-153) over memo['distance'] with autograd through L2Distance / CosineDistance."""
+    ref = ref_import.load()
+    N, K, D = 128, 64, 16
+    x, w = synth.make_inputs('normal', 3, N, K, D)
+    rec = dict(x=x, w=w)
+    for dist in ('L2', 'Cosine'):
+        xt = torch.from_numpy(x).requires_grad_(True)
+        wt = torch.from_numpy(w).requires_grad_(True)
+        d = getattr(ref, f'{dist}Distance')()(xt, wt.clone())
+        # (not in losses.py's __all__; reachable the way a config reaches it: through the loss registry)
+        entropy = ref.VQITQuantizerLossRegistry.build(dict(type='EntropyLoss', temperature=0.5))
+        loss = entropy(None, xt, dict(distance=d))
+        loss.backward()
+        r = tr.entropy_loss(torch.from_numpy(x), torch.from_numpy(w), dist, 0.5)
+        assert same(r['loss'], loss.detach()) and same(r['grad_x'], xt.grad) and same(r['grad_w'], wt.grad)
+        rec[f'loss_{dist.lower()}'] = np.float32(loss.item())
+        rec[f'grad_x_{dist.lower()}'] = xt.grad.numpy()
+        rec[f'grad_w_{dist.lower()}'] = wt.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'entropy_loss.npz'), **rec,
+                        spec=json.dumps(dict(N=N, K=K, D=D, seed=3, temperature=0.5, source='reference-import',
+                                             reference=['vq/algorithms/vq/losses.py:130-153',
+                                                        'vq/algorithms/vq/distances.py:28-46'])))
+
+
+def main(only=(), out_dir=None, quiet=False):
+    global OUT
+    if not ref_import.available():
+        sys.exit('oracle/make_golden.py needs /root/reference (build container only)')
+    if out_dir is not None:
+        OUT = out_dir
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
+    only = set(only)
+    print_ = (lambda *a, **k: None) if quiet else print
     for c in ENCODE_CASES:
+        if only and c[0] not in only:
+            continue
         rec = encode_case(*c)
-        print(f'{c[0]:28s} loss={float(rec["loss"]):.6f} used={int((rec["hist"] > 0).sum())}/{c[4]}')
-    special_case()
-    update_cases()
-    print('fixtures written to', OUT)
+        print_(f'{c[0]:28s} loss={float(rec["loss"]):.6f} used={int((rec["hist"] > 0).sum())}/{c[4]}', flush=True)
+    if not only or 'special' in only:
+        special_case()
+    if not only or 'update' in only:
+        update_cases()
+    if not only or 'lazy' in only:
+        lazy_init_case()
+    if not only or 'anchors' in only:
+        anchor_cases()
+    if not only or 'entropy' in only:
+        entropy_case()
+    print_('fixtures written to', OUT, '— every value produced by the reference files:')
+    for n, f in ref_import.load().files.items():
+        print_('   ', f)
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1:])

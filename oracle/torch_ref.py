@@ -1,11 +1,12 @@
 """The reference path restated with the same ATen ops (TEST INFRASTRUCTURE ONLY — see oracle/__init__.py).
 
-The reference package cannot be imported in the build container (``import todd`` fails: todd_ai
-@ed2a3ae is un-vendored), but its quantizer adds no arithmetic of its own: every line on
-the path is a stock PyTorch op.  This module restates those lines one-to-one so that
-(a) ``oracle/make_golden.py`` can produce fixtures from the very ops the reference runs,
-(b) floating-point results (losses, STE output, codebook updates) have a tolerance reference, and
-(c) ``bench.py`` can time "the reference's CPU path" on the GPU box's host cores.
+The reference's quantizer adds no arithmetic of its own: every line on the path is a stock PyTorch op.  This
+module restates those lines one-to-one.  It is PINNED to the reference itself: ``oracle/make_golden.py`` and
+``tests/test_reference_pin.py`` execute the reference's own source files (``oracle/ref_import.py``, build
+container only) on every fixture case and assert that the functions below return byte-identical tensors.  Because
+/root/reference cannot travel, this restatement is what runs on the GPU box as
+(a) the floating-point tolerance reference of the GPU tests (losses, gradients, codebook updates), and
+(b) ``bench.py``'s timed "reference CPU path" on the GPU box's host cores.
 It is never imported by the product package.
 """
 from __future__ import annotations
@@ -169,3 +170,108 @@ def vqgan_init(K: int, D: int, generator=None) -> torch.Tensor:
     """VQGANQuantizer._init_weights {'type':'vqgan'} → uniform_(-1/K, 1/K) (vqgan/quantizer.py:14-21)."""
     w = torch.empty(K, D)
     return w.uniform_(-1.0 / K, 1.0 / K, generator=generator)
+
+
+# -- whole training steps, in the reference's hook order (pinned byte-for-byte by oracle/make_golden.py) ----------
+
+def _vqkd_before_encode(x, w):
+    """NormalizeCallback.before_encode (normalize.py:22-29) with VQKDCallback._update_embedding (callbacks.py:73-75):
+    the codebook is normalised twice."""
+    return F.normalize(x), F.normalize(F.normalize(w))
+
+
+def vqkd_train_step(x, w, ema_decay: float = 0.99, world=None):
+    """VQKDQuantizer.forward in train mode (configs/vqkd/model.py:20-26): before_encode -> cosine _encode ->
+    VQKDCallback.after_encode -> decode from the UPDATED codebook -> CommitmentLoss(norm=True) -> ste.
+    ``world`` = list of the other ranks' (x1, quant) emulates the all-reduces of hist and centroids."""
+    x = x.clone().requires_grad_(True)
+    x1, w0 = _vqkd_before_encode(x, w)
+    quant, _ = encode(x1.detach(), w0, 'Cosine')
+    x2 = F.normalize(x1.detach())
+    K, D = w0.shape
+    hist, sums = None, None
+    if world is not None:
+        hist = bin_count(quant, K)
+        sums = torch.zeros_like(w0).scatter_add_(0, quant.reshape(-1, 1).expand(-1, D), x2)
+        for ox2, oq in world:
+            hist = hist + bin_count(oq, K)
+            sums = sums + torch.zeros_like(w0).scatter_add_(0, oq.reshape(-1, 1).expand(-1, D), ox2)
+    w_new = vqkd_after_encode(x1.detach(), quant, w0, ema_decay, hist, sums)     # normalises x1 again (callbacks.py:124)
+    z = decode(quant, w_new)
+    loss = commitment_loss(z, x1, norm=True)
+    z_ste = ste(z, x1)
+    loss.backward()
+    return dict(quant=quant, w_new=w_new, loss=loss.detach(), grad_x=x.grad, z=z_ste.detach(), x2=x2)
+
+
+def vqkd_train_step_2rank(x, w, ema_decay: float = 0.99):
+    """Two ranks on rows r::2, rank 0's view (hist and centroid sums all-reduced: callbacks.py:52,63-64)."""
+    parts = []
+    for r in range(2):
+        x1, w0 = _vqkd_before_encode(x[r::2], w)
+        parts.append((F.normalize(x1), encode(x1, w0, 'Cosine')[0]))
+    return vqkd_train_step(x[0::2], w, ema_decay, world=[parts[1]])
+
+
+def cvq_train_steps(x, w, distance: str, ema_decay: float = 0.99, eps: float = 1e-3, steps: int = 2):
+    """CVQVAECallback training steps from p = 0 (quantizer_callback.py:60-73 then :75-105), NearestAnchor."""
+    p = torch.zeros(w.shape[0])
+    outs = []
+    for _ in range(steps):
+        quant, d = encode(x, w, distance)
+        w, p, anchors, indices, decay = cvq_after_encode(x, quant, d, w, p, ema_decay, eps)
+        outs.append(dict(quant=quant, col_idx=indices, p=p, w_new=w, anchors=anchors, decay=decay))
+    return outs
+
+
+def cvq_train_step_2rank(x, w, distance: str, ema_decay: float = 0.99, eps: float = 1e-3):
+    """Two ranks on rows r::2, first step.  'avg' = NearestAnchor(sync=False): per-rank anchors summed and divided by
+    the world size (anchors.py:64-67); 'sync' = NearestAnchor(sync=True): x and d all-gathered in rank order, one global
+    column argmin (anchors.py:50-57)."""
+    K = w.shape[0]
+    halves = [(x[r::2],) + encode(x[r::2], w, distance) for r in range(2)]
+    hist = bin_count(halves[0][1], K) + bin_count(halves[1][1], K)
+    numel = torch.tensor(halves[0][1].numel() + halves[1][1].numel())
+    p0 = torch.zeros(K)
+    out = {}
+    a_other = nearest_anchor(halves[1][0], halves[1][2])[0]
+    w_new, p, _, idx, _ = cvq_after_encode(halves[0][0], halves[0][1], halves[0][2], w, p0, ema_decay, eps,
+                                           world_hist=hist, world_numel=numel, world_size=2, other_anchors=[a_other])
+    out['avg'] = dict(w_new=w_new, p=p, col_idx=idx)
+    xs, ds = torch.cat([halves[0][0], halves[1][0]]), torch.cat([halves[0][2], halves[1][2]])
+    w_new, p, _, idx, _ = cvq_after_encode(xs, halves[0][1], ds, w, p0, ema_decay, eps, world_hist=hist, world_numel=numel)
+    out['sync'] = dict(w_new=w_new, p=p, col_idx=idx)
+    return out
+
+
+def vqkd_lazy_init(x, w, iters: int = 10):
+    """VQKDCallback.lazy_init_weights, single rank, N >= K branch (callbacks.py:92-106,112).  Consumes the global
+    ``random`` stream exactly like the reference (seed it first)."""
+    import random
+    x = F.normalize(x)
+    K = w.shape[0]
+    indices = random.sample(range(x.shape[0]), K)
+    e = x[indices]
+    quants = []
+    for _ in range(iters):
+        w = F.normalize(e)                                     # _update_embedding
+        quant, _ = encode(x, w, 'Cosine')
+        quants.append(quant)
+        e = kmeans(x, quant, w)
+    return dict(indices=torch.as_tensor(indices), quants=quants, w=F.normalize(e))
+
+
+def entropy_loss(x, w, distance: str, temperature: float):
+    """EntropyLoss.forward (losses.py:139-153) over the distance matrix of ``distance``; returns loss and gradients."""
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    a = DISTANCES[distance](x, w.clone())
+    a = a.reshape(-1, a.shape[-1]) / temperature
+    probs = a.softmax(-1)
+    log_probs = torch.log_softmax(a + 1e-5, -1)
+    avg = probs.mean(0)
+    avg_entropy = -torch.sum(avg * torch.log(avg + 1e-5))
+    sample_entropy = -torch.mean(torch.sum(probs * log_probs, -1))
+    loss = sample_entropy - avg_entropy
+    loss.backward()
+    return dict(loss=loss.detach(), grad_x=x.grad, grad_w=w.grad)

@@ -115,28 +115,58 @@ def test_nonfinite_semantics(golden_dir):
 
 
 def test_update_vqkd(golden_dir):
+    """One VQ-KD training step in the reference's hook order (fixture = the real VQKDQuantizer + VQKDCallback)."""
     z = np.load(os.path.join(golden_dir, 'update_vqkd.npz'))
     spec = json.loads(str(z['spec']))
     x, w = synth.make_inputs('normal', spec['seed'], spec['N'], spec['K'], spec['D'])
     w = synth.unit_rows(w)
     assert synth.sha(x) == str(z['x_sha']) and synth.sha(w) == str(z['w_sha'])
-    xn = co.normalize_rows(x)
-    quant = co.cos_argmin(xn, w)
+    xn = co.normalize_rows(x)                                # NormalizeCallback.before_encode (normalize.py:24)
+    w0 = co.normalize_rows(co.normalize_rows(w))             # normalize.py:27 then VQKDCallback._update_embedding (:73-75)
+    quant = co.cos_argmin(xn, w0)
     np.testing.assert_array_equal(quant, z['quant'].astype(np.int64))
 
     def step(xs, qs, hist=None, sums=None):
         xs = co.normalize_rows(xs)                           # callbacks.py:124
-        e = co.kmeans_centroids(xs, qs, w, hist, sums)       # :125
+        e = co.kmeans_centroids(xs, qs, w0, hist, sums)      # :125
         e = co.normalize_rows(e)                             # :126
-        e = co.ema(w, e, 0.99)                               # :127
+        e = co.ema(w0, e, 0.99)                              # :127
         return co.normalize_rows(e)                          # :73-75
 
     np.testing.assert_allclose(step(xn, quant), z['w_new'], rtol=0, atol=2e-6)
     K = spec['K']
-    hist = co.bincount(quant[0::2], K) + co.bincount(quant[1::2], K)
-    sums = co.scatter_add_rows(co.normalize_rows(xn[0::2]), quant[0::2], K) + \
-        co.scatter_add_rows(co.normalize_rows(xn[1::2]), quant[1::2], K)
-    np.testing.assert_allclose(step(xn[0::2], quant[0::2], hist, sums), z['w_new_2rank'], rtol=0, atol=2e-6)
+    q0, q1 = co.cos_argmin(xn[0::2], w0), co.cos_argmin(xn[1::2], w0)
+    np.testing.assert_array_equal(q0, z['quant_rank0'].astype(np.int64))
+    np.testing.assert_array_equal(q1, z['quant_rank1'].astype(np.int64))
+    hist = co.bincount(q0, K) + co.bincount(q1, K)
+    sums = co.scatter_add_rows(co.normalize_rows(xn[0::2]), q0, K) + co.scatter_add_rows(co.normalize_rows(xn[1::2]), q1, K)
+    np.testing.assert_allclose(step(xn[0::2], q0, hist, sums), z['w_new_2rank'], rtol=0, atol=2e-6)
+
+
+def test_lazy_init_kmeans(golden_dir):
+    """The C oracle runs the same 10 Lloyd iterations from the reference's seeded random.sample start; per-iteration
+    assignments agree with the reference run except on fp32 rounding-envelope rows (summation order of the centroid
+    sums / norms), and the final codebook agrees to 1e-5."""
+    z = np.load(os.path.join(golden_dir, 'lazy_init_vqkd.npz'))
+    spec = json.loads(str(z['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, _ = synth.make_inputs('normal', spec['x_seed'], N, K, D)
+    assert synth.sha(x) == str(z['x_sha'])
+    import random
+    idx = random.Random(spec['seed']).sample(range(N), K)
+    np.testing.assert_array_equal(np.asarray(idx), z['indices'])
+    xn = co.normalize_rows(x)
+    e = xn[idx]
+    total_diff = 0
+    for it in range(spec['iters']):
+        w = co.normalize_rows(e)
+        if it == 0:
+            np.testing.assert_allclose(w, z['books_first'], rtol=0, atol=2e-7)
+        quant = co.cos_argmin(xn, w)
+        total_diff += int((quant != z['quants'][it].astype(np.int64)).sum())
+        e = co.kmeans_centroids(xn, quant, w)
+    assert total_diff <= 1e-3 * N * spec['iters'], total_diff
+    np.testing.assert_allclose(co.normalize_rows(e), z['w_init'], rtol=0, atol=1e-5 if total_diff == 0 else 5e-2)
 
 
 @pytest.mark.parametrize('dist', ['l2', 'cosine'])

@@ -1,0 +1,103 @@
+"""The oracle's pin to the reference ITSELF (CPU, build container only: /root/reference cannot travel).
+
+``oracle/ref_import.py`` executes the reference's own quantizer-path source files behind a structure-only stand-in
+for todd.  These tests (a) regenerate every fixture from those files and require the committed ``tests/golden/*.npz``
+to be byte-identical, (b) thereby re-run make_golden's assertions that the restatement ``oracle/torch_ref.py`` is
+byte-identical to the reference on every case (it is what runs on the GPU box), (c) check the stand-in supplies no
+arithmetic beyond the three documented un-vendored todd definitions, and (d) drive the product's
+``integration.register_into_reference()`` against the reference's real registries.
+"""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason='/root/reference is only present in the build container')
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_reference_files_are_the_ones_executed():
+    ref = ref_import.load()
+    want = {'vq/algorithms/vq/distances.py', 'vq/algorithms/vq/quantizers.py', 'vq/algorithms/vq/losses.py',
+            'vq/algorithms/vq/utils.py', 'vq/algorithms/vq/callbacks/normalize.py', 'vq/algorithms/vq/callbacks/update.py',
+            'vq/algorithms/vqgan/quantizer.py', 'vq/algorithms/vqkd/quantizers/base.py',
+            'vq/algorithms/vqkd/quantizers/callbacks.py', 'vq/algorithms/cvqvae/anchors.py',
+            'vq/algorithms/cvqvae/quantizer_callback.py', 'vq/tasks/image_tokenization/models/quantizers/base.py',
+            'vq/tasks/image_tokenization/models/quantizers/utils/ste.py',
+            'vq/tasks/image_tokenization/models/quantizers/callbacks/composed.py'}
+    assert want <= set(ref.files.values())
+    for mod in ref.modules.values():                       # every loaded class lives in a file under the reference root
+        for name, obj in vars(mod).items():
+            if isinstance(obj, type) and obj.__module__.startswith('vq.'):
+                import sys
+                assert sys.modules[obj.__module__].__file__.startswith(ref_import.REFERENCE_ROOT), name
+
+
+def test_standin_supplies_no_arithmetic_but_the_documented_three():
+    """No torch/numpy arithmetic call in the stand-in outside _ToddArithmetic (ema, EMA, MSELoss(norm))."""
+    src = open(ref_import.__file__).read()
+    body = src.split('def _install_todd()')[1].split('# 2. the reference')[0]
+    for needle in ('torch.cdist', 'einsum', 'argmin', 'softmax', 'scatter_add', 'bincount', '.normalize(', 'mse_loss',
+                   'torch.exp', 'torch.sqrt'):
+        assert needle not in body, f'stand-in todd computes with {needle}'
+    arith = src.split('class _ToddArithmetic')[1].split('def _install_todd()')[0]
+    assert 'a * decay + b * (1 - decay)' in arith and 'F.mse_loss' in arith
+
+
+def test_committed_fixtures_are_the_reference_outputs(tmp_path):
+    """Regenerate everything from /root/reference (incl. the two-process gloo run of the reference callbacks) and
+    compare with the committed files key by key, byte by byte.  make_golden asserts torch_ref == reference inside."""
+    from oracle import make_golden
+    make_golden.main(out_dir=str(tmp_path), quiet=True)
+    fresh = sorted(os.path.basename(p) for p in glob.glob(os.path.join(str(tmp_path), '*.npz')))
+    committed = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
+    assert fresh == committed
+    for name in fresh:
+        a, b = np.load(os.path.join(str(tmp_path), name)), np.load(os.path.join(GOLDEN, name))
+        assert sorted(a.files) == sorted(b.files), name
+        for k in a.files:
+            if k == 'spec':
+                sa, sb = json.loads(str(a[k])), json.loads(str(b[k]))
+                assert sb['source'] == 'reference-import' and sb['reference'], name
+                sa.pop('torch', None), sb.pop('torch', None)
+                assert sa == sb, name
+            else:
+                assert a[k].dtype == b[k].dtype and a[k].tobytes() == b[k].tobytes(), f'{name}:{k} drifted from the reference'
+
+
+def test_every_fixture_cites_reference_lines():
+    for p in glob.glob(os.path.join(GOLDEN, '*.npz')):
+        spec = json.loads(str(np.load(p)['spec']))
+        assert spec['source'] == 'reference-import'
+        for cite in spec['reference']:
+            m = re.match(r'(vq/[\w/]+\.py):[\d,\-]+$', cite)
+            assert m and os.path.isfile(os.path.join(ref_import.REFERENCE_ROOT, m.group(1))), cite
+
+
+def test_register_into_reference_registries():
+    """integration.register_into_reference() against the reference's real registry classes: afterwards the reference's
+    own ``VQITQuantizerRegistry.build`` of the reference's config dict returns THIS package's quantizer."""
+    ref = ref_import.load()
+    from vector_quantization_amd import integration, quantizers as Q
+    saved = {}
+    regs = dict(VQITQuantizerRegistry=ref.VQITQuantizerRegistry, VQITQuantizerDistanceRegistry=ref.VQITQuantizerDistanceRegistry,
+                VQITQuantizerLossRegistry=ref.VQITQuantizerLossRegistry,
+                VQITQuantizerCallbackRegistry=ref.VQITQuantizerCallbackRegistry, AnchorRegistry=ref.AnchorRegistry)
+    for n, r in regs.items():
+        saved[n] = dict(r._table)
+    try:
+        done = integration.register_into_reference()
+        assert 'VQGANQuantizer' in done['VQITQuantizerRegistry']
+        assert ref.VQITQuantizerRegistry._resolve('VQGANQuantizer') is Q.VQGANQuantizer
+        assert ref.VQITQuantizerCallbackRegistry._resolve('CVQVAECallback') is Q.CVQVAECallback
+        assert ref.AnchorRegistry._resolve('NearestAnchor') is Q.NearestAnchor
+    finally:
+        for n, r in regs.items():
+            r._table.clear()
+            r._table.update(saved[n])
