@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: config / registry shim, building the reference's quantizer configs, hook
 ordering, state-dict layout, and the guarantee that the product refuses to run without the HIP path."""
+import os
+
 import pytest
 import torch
 
@@ -141,3 +143,18 @@ def test_committed_bench_line_has_the_contract_fields():
     assert roof['bound'] in ('hbm', 'mfma') and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9
     tokens = line['config']['tokens_per_gpu_per_step'] * line['n_gpus'] * 1e3 / line['ms_per_step']
     assert abs(tokens - line['value']) / line['value'] < 1e-6
+
+
+def test_bench_gpus_n_self_launch_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` with no launcher environment starts the ranks itself (torch.distributed.run child
+    process); here there is no GPU, so the ranks fail and the parent must exit non-zero without printing a JSON line
+    (never a silent 1-rank number)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert '"metric"' not in p.stdout
+    assert '2-rank launch failed' in p.stderr

@@ -67,14 +67,15 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
 static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
+static int g_tune_filter = 1;   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static int g_tune_gather_grid = 0, g_tune_gather_nt = 0;   // gather kernel knobs (keys 3, 4)
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, hipStream_t s) {
     constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER>;
     static size_t lds_set[16] = {0};
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
@@ -125,9 +126,13 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, s); \
     }
     switch (nstep) {
-        case 2: if (small) VQ_CFG(2, 2, 8, 4, 4) else VQ_CFG(2, 4, 8, 4, 4)
-        case 4: if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4)
-        case 8: if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4)
+        // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
+        case 2: if (!g_tune_filter) { if (small) VQ_CFG(2, 2, 8, 4, 4) else VQ_CFG(2, 4, 8, 4, 4) }
+                if (small) VQ_CFG(2, 2, 8, 4, 4, true) else VQ_CFG(2, 4, 8, 4, 4, true)
+        case 4: if (!g_tune_filter) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
+                if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
+        case 8: if (!g_tune_filter) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
+                if (small) VQ_CFG(8, 2, 8, 4, 4, true) else VQ_CFG(8, 4, 8, 4, 4, true)
         case 16: if (small) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
         case 32: VQ_CFG(32, 2, 8, 2)
         case 48: VQ_CFG(48, 2, 8, 1)
@@ -719,6 +724,7 @@ int vqhip_set_tuning(int key, int value) {
     if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;
     else if (key == 3) g_tune_gather_grid = value > 0 ? value : 0;
     else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
+    else if (key == 5) g_tune_filter = value != 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

@@ -83,6 +83,21 @@ __device__ __forceinline__ float vmax(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max over the four lanes l, l^16, l^32, l^48 (the lanes that share a token in the 16x16 MFMA output):
+// v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves of two registers in place; fed the same
+// value twice, {result 0, result 1} = {own, partner} in some order on every lane
+__device__ __forceinline__ float quad_rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // fp32 -> fp16 (RNE) with subnormal results flushed to zero, so the MFMA never sees an fp16 subnormal
 __device__ __forceinline__ _Float16 to_f16_ftz(float v) {
     _Float16 q = (_Float16)v;
@@ -428,8 +443,17 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
 // MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
 // The epilogue of tile t-1 (3 VALU per element) is spread over the MFMAs of tile t (two accumulator sets ping-pong).
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
-__global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
+//
+// FILTER (small D, where 3 VALU per score against D/8 MFMA cycles per score make the kernel VALU-issue-bound): the 8
+// elements a lane holds per (token tile, code tile) first go through a 4-instruction maximum (v_max3) and ONE compare
+// against the lane's threshold; the per-element update runs only if some lane of the wave exceeds its threshold
+// (wave-uniform branch).  The threshold is the largest runner-up bound b2 among the four lanes that share the token,
+// refreshed once per stage.  Validity: an element that is skipped is <= the threshold of its time <= the final
+// max-over-lanes b2, which is what the merged record carries as v3 (bound on everything unidentified); with the
+// lane's own b2 as threshold the skip would change nothing at all (med3(b1,b2,v) = b2 and max(b1,v) = b1 for
+// v <= b2), the shared threshold only moves the few rows whose third-best lies within the margin to the second pass.
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -457,10 +481,11 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
         for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
     }
 
-    float b1[TT], b2[TT];
+    float b1[TT], b2[TT], th[TT];
     uint32_t t1[TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; t1[t] = 0; }
+    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; th[t] = -INFINITY; t1[t] = 0; }
+    static_assert(!FILTER || PIPE, "the filtered epilogue is written for the ping-pong form");
 
     auto issue_stage = [&](int64_t st, int buf) {
         const char *src = frag + st * (int64_t)STAGE_BYTES;
@@ -524,10 +549,33 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
                     cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                if constexpr (FILTER) {
+                    // token tile t of the previous code tile: maximum of its 8 elements, one compare, wave-uniform skip
+                    const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;
+#pragma unroll
+                    for (int i = 0; i < (TT + NSTEP - 1) / NSTEP; ++i) {
+                        const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % (NSTEP / TT) == 0) ? ch / (NSTEP / TT) : -1);
+                        if (t >= 0 && t < TT) {
+                            const float m0 = vmax3(prv[0][t][0], prv[0][t][1], prv[0][t][2]);
+                            const float m1 = vmax3(prv[0][t][3], prv[1][t][0], prv[1][t][1]);
+                            const float tm = vmax3(m0, m1, vmax(prv[1][t][2], prv[1][t][3]));
+                            if (__any(tm > th[t])) {
+                                const uint32_t was = __float_as_uint(b1[t]);
+#pragma unroll
+                                for (int e = 0; e < NE; ++e) {
+                                    float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                                    b1[t] = vmax(b1[t], v);
+                                }
+                                t1[t] = (__float_as_uint(b1[t]) != was) ? tgp : t1[t];
+                            }
+                        }
+                    }
+                }
                 // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
                 constexpr int TOTAL = NE * TT;
 #pragma unroll
-                for (int i = 0; PIPE && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                for (int i = 0; PIPE && !FILTER && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
                     const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % (NSTEP / TOTAL) == 0) ? ch / (NSTEP / TOTAL) : -1);
                     if (id >= 0 && id < TOTAL) {
                         const int t = id / NE, e = id % NE;
@@ -547,10 +595,16 @@ __global__ __launch_bounds__(WAVES * 64) void coarse_kernel(
                         b1[t] = vmax(b1[t], v);
                     }
             }
-            const uint32_t tgp = (uint32_t)(st * TPS + ti) - (PIPE ? 1u : 0u);  // tile the retired elements belong to
+            if constexpr (!FILTER) {
+                const uint32_t tgp = (uint32_t)(st * TPS + ti) - (PIPE ? 1u : 0u);  // tile the retired elements belong to
 #pragma unroll
-            for (int t = 0; t < TT; ++t)
-                t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
+                for (int t = 0; t < TT; ++t)
+                    t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
+            }
+        }
+        if constexpr (FILTER) {      // refresh the skip thresholds: largest runner-up bound among the token's four lanes
+#pragma unroll
+            for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b2[t]);
         }
         __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
     }
