@@ -40,7 +40,13 @@ const char *vqhip_last_error(void); /* host string describing the last non-zero 
 /* ---- sizes of caller-owned buffers -------------------------------------------------------------- */
 /* bytes of the prepared-codebook image produced by vqhip_codebook_prepare for a [K,D] codebook */
 int64_t vqhip_codebook_bytes(int64_t K, int D);
-/* bytes of per-call scratch for vqhip_argmin / vqhip_argmin_exact / vqhip_col_argmin over N rows */
+/* bytes of per-call scratch for vqhip_argmin / vqhip_argmin_exact / vqhip_distance over N rows.
+ * (vqhip_col_argmin needs the LARGER vqhip_col_workspace_bytes, declared next to it below.)
+ * Preconditions shared by every entry point (the kernels use 16-byte vector loads and do not re-check):
+ *   - every buffer pointer (x, e, cb, ws, outputs) is 16-byte aligned (hipMalloc / torch allocations are);
+ *   - rows are dense: x is [N, D] and e is [K, D] row-major with no padding between rows;
+ *   - ws holds at least the number of bytes the matching *_bytes function returns;
+ *   - all pointers are device pointers of the device that `stream` belongs to, which is the current HIP device. */
 int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D);
 
 /* ---- codebook preparation --------------------------------------------------------------------------

@@ -158,3 +158,72 @@ def test_bench_gpus_n_self_launch_fails_loudly_without_gpus():
     assert p.returncode != 0
     assert '"metric"' not in p.stdout
     assert '2-rank launch failed' in p.stderr
+
+
+class _StubDistance(Q.BaseDistance):
+    """torch.cdist on whatever device the operands live on — only to exercise LazyDistance's tensor behaviour on CPU
+    (the product distances have no CPU path)."""
+    metric = 'L2'
+
+    def __init__(self):
+        super().__init__()
+        self.materialisations = 0
+
+    def forward(self, x, e):
+        self.materialisations += 1
+        return torch.cdist(x, e)
+
+    def argmin(self, x, e, hist=None, prepared=None):
+        return torch.cdist(x.detach(), e.detach()).argmin(-1)
+
+
+def test_lazy_distance_is_a_tensor_for_unknown_consumers():
+    """memo['distance'] must work for callbacks/losses written against the reference's plain tensor:
+    metadata without materialising, fused argmin without materialising, everything else on the real matrix, with
+    autograd to both operands."""
+    import einops
+    dist = _StubDistance()
+    x = torch.randn(10, 4, requires_grad=True)
+    e = torch.randn(6, 4, requires_grad=True)
+    d = Q.LazyDistance(dist, x, e)
+    assert isinstance(d, torch.Tensor) and d.shape == (10, 6) and d.dtype == torch.float32 and d.dim() == 2 and len(d) == 10
+    assert torch.equal(d.argmin(-1), torch.cdist(x, e).argmin(-1)) and torch.equal(torch.argmin(d, dim=1), d.argmin(-1))
+    assert dist.materialisations == 0
+    ref = torch.cdist(x, e)
+    t = einops.rearrange(d, 'x e -> e x')                       # MultinomialAnchor's first line (anchors.py:98)
+    assert type(t) is torch.Tensor and torch.equal(t, ref.t()) and dist.materialisations == 1
+    assert torch.equal(d[2], ref[2]) and torch.equal(1 - d, 1 - ref) and torch.equal(d / 0.5, ref / 0.5)
+    assert torch.equal(torch.cat([d, d]), torch.cat([ref, ref])) and torch.equal(d.T.softmax(1), ref.T.softmax(1))
+    assert dist.materialisations == 1                           # materialised once, cached
+    (d / 0.5).softmax(-1)[:, 0].sum().backward()                # EntropyLoss-style use: gradients reach x and e
+    assert x.grad.abs().sum() > 0 and e.grad.abs().sum() > 0
+    assert 'LazyDistance' in repr({'distance': d})
+
+
+def test_composed_callback_threads_values_in_priority_order():
+    class Add(Q.BaseCallback):
+        def __init__(self, k):
+            super().__init__()
+            self.k = k
+
+        def before_encode(self, x, memo):
+            memo.setdefault('order', []).append(self.k)
+            return x * 10 + self.k
+
+        def before_loss(self, z, x, memo):
+            return z + self.k, x - self.k
+
+        def after_init_weights(self, config, recursive):
+            return recursive and self.k != 2
+
+    cc = Q.ComposedCallback(priorities=[dict(before_encode=5), dict(), dict(before_encode=-1)], callbacks=[Add(1), Add(2), Add(3)])
+    memo = {}
+    out = cc.before_encode(torch.zeros(()), memo)
+    assert memo['order'] == [3, 2, 1] and float(out) == 321.0
+    z, x = cc.before_loss(torch.zeros(()), torch.zeros(()), {})
+    assert float(z) == 6.0 and float(x) == -6.0
+    assert cc.after_init_weights(Config(), True) is False
+    assert cc.after_decode('z', {}) == 'z' and cc.before_init_weights(Config()) is None
+    sentinel = object()
+    cc.bind(sentinel)
+    assert cc.quantizer is sentinel and all(cb.quantizer is sentinel for cb in cc.callbacks)

@@ -29,34 +29,50 @@ static int fail(int code, const char *what, const char *detail = "") {
 // ---- optional per-launch timing of the proposal kernel (bench.py roofline) -------------------------------
 // Events are recorded on the caller's stream right around the coarse_kernel launch; vqhip_profile_collect
 // synchronises on them.  Disabled (zero overhead) unless vqhip_profile_enable(1) was called.
+// Process-wide state is limited to this block and the tuning knobs below; all of it is safe to touch from several host
+// threads (each with its own stream): the profiling list is mutex-protected (the mutex is taken only while profiling is
+// on), the knobs and the per-device attribute cache are atomics.
+#include <atomic>
+#include <mutex>
 #include <vector>
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
 static size_t g_prof_used = 0;
 
-static void prof_begin(hipStream_t s) {
-    if (!g_prof_on) return;
+// returns the slot the matching prof_end must close, or -1 when profiling is off
+static long prof_begin(hipStream_t s) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof_used == g_prof_events.size()) {
         hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return; }
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return -1; }
         g_prof_events.emplace_back(a, b);
     }
-    (void)hipEventRecord(g_prof_events[g_prof_used].first, s);
+    const long slot = (long)g_prof_used++;
+    (void)hipEventRecord(g_prof_events[slot].first, s);
+    return slot;
 }
-static void prof_end(hipStream_t s) {
-    if (!g_prof_on) return;
-    (void)hipEventRecord(g_prof_events[g_prof_used].second, s);
-    ++g_prof_used;
+static void prof_end(long slot, hipStream_t s) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if ((size_t)slot < g_prof_events.size()) (void)hipEventRecord(g_prof_events[slot].second, s);
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember what was set for (kernel, device)
-static int ensure_dyn_lds(const void *kern, size_t bytes, size_t (&set)[16]) {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember what was set for (kernel, device).
+// Devices beyond the cache simply set the attribute on every call.
+#define VQ_MAX_DEVICES 64
+typedef std::atomic<size_t> LdsCache[VQ_MAX_DEVICES];
+static int ensure_dyn_lds(const void *kern, size_t bytes, LdsCache &set) {
     int dev = 0;
     VQ_HIP(hipGetDevice(&dev));
-    dev &= 15;
-    if (bytes > set[dev]) {
+    const bool cached = dev >= 0 && dev < VQ_MAX_DEVICES;
+    if (!cached || bytes > set[dev].load(std::memory_order_acquire)) {
         VQ_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        set[dev] = bytes;
+        if (cached) {                                   // keep the maximum (another thread may have raised it meanwhile)
+            size_t cur = set[dev].load(std::memory_order_relaxed);
+            while (cur < bytes && !set[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+        }
     }
     return VQHIP_OK;
 }
@@ -66,22 +82,23 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 }
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
-static int g_tune_slices = 0;   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
-static int g_tune_filter = 1;   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
-static int g_tune_gather_grid = 0, g_tune_gather_nt = 0;   // gather kernel knobs (keys 3, 4)
+static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
+static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
+static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
 
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
-                             int64_t Np, hipStream_t s) {
+                             int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
+                             hipStream_t s) {
     constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
     auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER>;
-    static size_t lds_set[16] = {0};
+    static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
-    prof_begin(s);
-    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np);
-    prof_end(s);
+    const long slot = prof_begin(s);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric);
+    prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse_kernel");
     return VQHIP_OK;
 }
@@ -91,22 +108,28 @@ static int launch_rescan_cfg(const char *rimg, const char *frag, int64_t nstages
                              const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
     auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
-    static size_t lds_set[16] = {0};
+    static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     kern<<<256, WAVES * 64, LDS, s>>>(rimg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
     VQ_CHECK_LAUNCH("rescan_kernel");
     return VQHIP_OK;
 }
 
-static int pick_slices(int64_t ntb, int64_t nstages) {
-    if (g_tune_slices > 0) { int ns = g_tune_slices; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
+#ifndef VQ_MIN_SLICES_FILTER
+#define VQ_MIN_SLICES_FILTER 2
+#endif
+#ifndef VQ_TT_D32
+#define VQ_TT_D32 4
+#endif
+static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
+    if (const int forced = g_tune_slices.load(); forced > 0) { int ns = forced; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
     // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
     // record write-back, re-read the token image fewer times and write fewer records.  (Rows whose candidates cannot
     // all be identified get a second proposal pass, so the number of candidate groups does not matter for speed.)
     // ... but at least two: a lane's stream then covers half the codebook, which halves the rows whose runner-up
     // cannot be identified (second proposal pass); measured +0.7 % at 524 288 tokens, nothing lost elsewhere.
     int64_t want = (256 + ntb - 1) / ntb;
-    want = want < 2 ? 2 : want;
+    want = want < min_slices ? min_slices : want;
     int ns = 1;
     while (ns < want && ns < VQ_MAX_SLICES) ns <<= 1;
     while (ns > 1 && ns > nstages) ns >>= 1;
@@ -114,24 +137,25 @@ static int pick_slices(int64_t ntb, int64_t nstages) {
 }
 
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
-                         int *nslices_out, hipStream_t s) {
+                         const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, int *nslices_out,
+                         hipStream_t s) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
 #define VQ_CFG(NS, TT, W, ...)                                                                      \
     {                                                                                               \
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
-        int ns = pick_slices(ntb, L.nstages);                                                       \
+        int ns = pick_slices(ntb, L.nstages, (NS) <= 8 ? VQ_MIN_SLICES_FILTER : 2);                 \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, s); \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, s); \
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
-        case 2: if (!g_tune_filter) { if (small) VQ_CFG(2, 2, 8, 4, 4) else VQ_CFG(2, 4, 8, 4, 4) }
-                if (small) VQ_CFG(2, 2, 8, 4, 4, true) else VQ_CFG(2, 4, 8, 4, 4, true)
-        case 4: if (!g_tune_filter) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
+        case 2: if (!g_tune_filter.load()) { if (small) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4) }
+                if (small) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4, true) else VQ_CFG(2, VQ_TT_D32, 8, VQ_TPS_D32, 4, true)
+        case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
-        case 8: if (!g_tune_filter) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
+        case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
                 if (small) VQ_CFG(8, 2, 8, 4, 4, true) else VQ_CFG(8, 4, 8, 4, 4, true)
         case 16: if (small) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
         case 32: VQ_CFG(32, 2, 8, 2)
@@ -149,7 +173,7 @@ static int run_exact_tiled(const void *x, int x_dtype, const float *e, const flo
     constexpr int LDS = 2 * 32 * 128 * 4;
     auto k0 = exact_tiled_kernel<0, MODE>;
     auto k1 = exact_tiled_kernel<1, MODE>;
-    static size_t set0[16] = {0}, set1[16] = {0};
+    static LdsCache set0, set1;
     if (int rc = ensure_dyn_lds((const void *)k0, LDS, set0)) return rc;
     if (int rc = ensure_dyn_lds((const void *)k1, LDS, set1)) return rc;
     int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
@@ -271,7 +295,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
     else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
     VQ_CHECK_LAUNCH("x_prep_kernel");
-    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, &nslices, s);
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, &nslices, s);
     if (rc) return rc;
     const int rgrid = (int)((N + 1023) / 1024);
     int *rescan_list = flag_list;
@@ -306,7 +330,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         int rrc = VQHIP_OK;
         switch (L.nstep) {
 #define VQ_RESCAN(NS, TT, ...) case NS: rrc = launch_rescan_cfg<NS, TT, 8, __VA_ARGS__>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
-            VQ_RESCAN(2, 2, 4, 4) VQ_RESCAN(4, 2, 4, 4) VQ_RESCAN(8, 2, 4, 4) VQ_RESCAN(16, 2, VQ_TPS16, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
+            VQ_RESCAN(2, 2, VQ_TPS_D32, 4) VQ_RESCAN(4, 2, 4, 4) VQ_RESCAN(8, 2, 4, 4) VQ_RESCAN(16, 2, VQ_TPS16, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
         }
@@ -473,8 +497,9 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
     hipStream_t s = (hipStream_t)stream;
     // outputs beyond the Infinity Cache (256 MiB) are streamed: non-temporal accesses and twice the waves in flight
     const int64_t out_bytes = (int64_t)N * D * 4 * ((z ? 1 : 0) + (z_ste ? 1 : 0));
-    const bool streamed = g_tune_gather_nt ? g_tune_gather_nt == 1 : out_bytes > (192ll << 20);
-    int cap = g_tune_gather_grid > 0 ? g_tune_gather_grid : (streamed ? 512 : 256);      // blocks of 16 waves
+    const int tune_nt = g_tune_gather_nt.load(), tune_grid = g_tune_gather_grid.load();
+    const bool streamed = tune_nt ? tune_nt == 1 : out_bytes > (192ll << 20);
+    int cap = tune_grid > 0 ? tune_grid : (streamed ? 512 : 256);      // blocks of 16 waves
     int grid = (int)((N + 15) / 16);
     grid = grid > cap ? cap : grid;
 #define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse)
@@ -491,7 +516,7 @@ int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *st
     if (N == 0) return VQHIP_OK;
     if (K <= 32768 && N >= 16384) {
         // enough tokens per block that the K-bin flush pays: at most 256 blocks, >= 2048 tokens each
-        static size_t lds_set[16] = {0};
+        static LdsCache lds_set;
         if (int rc = ensure_dyn_lds((const void *)hist_lds_kernel, (size_t)K * 4, lds_set)) return rc;
         int grid = (int)((N + 2047) / 2048); grid = grid > 256 ? 256 : grid;
         hist_lds_kernel<<<grid, 1024, (size_t)K * 4, (hipStream_t)stream>>>(idx, N, (int)K, hist);
@@ -609,7 +634,7 @@ int vqhip_token_order(const int64_t *idx, int64_t N, int64_t K, int32_t *counts,
     hipStream_t s = (hipStream_t)stream;
     int *blockhist = (int *)ws;
     const size_t lds = (size_t)K * 4;
-    static size_t lds_set[16] = {0};
+    static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)sort_hist_kernel, lds, lds_set)) return rc;
     if (nchunks > 0) {
         sort_hist_kernel<<<(int)nchunks, VQ_SORT_CHUNK, lds, s>>>(idx, N, (int)K, blockhist);
@@ -710,7 +735,7 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
     const char *frag = c + L.off_frag;
     switch (L.nstep) {
 #define VQ_DBG(NS, TPS) case NS: debug_scores_kernel<NS, TPS><<<512, 256, 0, s>>>(ximg, frag, L.nstages, N, K, scores); break;
-        VQ_DBG(2, 4) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, VQ_TPS16) VQ_DBG(32, 2) VQ_DBG(48, 1) VQ_DBG(64, 1)
+        VQ_DBG(2, VQ_TPS_D32) VQ_DBG(4, 4) VQ_DBG(8, 4) VQ_DBG(16, VQ_TPS16) VQ_DBG(32, 2) VQ_DBG(48, 1) VQ_DBG(64, 1)
 #undef VQ_DBG
         default: return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: unsupported padded D");
     }
@@ -731,6 +756,7 @@ int vqhip_set_tuning(int key, int value) {
 }
 
 int vqhip_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = on != 0;
     g_prof_used = 0;
     return VQHIP_OK;
@@ -738,6 +764,7 @@ int vqhip_profile_enable(int on) {
 
 int vqhip_profile_collect(double *ms_sum, int64_t *launches) {
     if (!ms_sum || !launches) return fail(VQHIP_EINVAL, "vqhip_profile_collect: bad argument");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     double total = 0.0;
     for (size_t i = 0; i < g_prof_used; ++i) {
         VQ_HIP(hipEventSynchronize(g_prof_events[i].second));

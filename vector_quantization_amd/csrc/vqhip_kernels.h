@@ -83,6 +83,21 @@ __device__ __forceinline__ float vmax(float a, float b) {
     return r;
 }
 
+// v_max3_f32 / v_max_f32 on values an MFMA produced.  hipcc pads no hazard for a consumer INSIDE an asm statement
+// (MI355X guide §5.7 item 2: an MFMA's D needs 12 wait states before any non-MFMA reader), so the statement must not be
+// scheduled right behind the MFMA that wrote its inputs.  `after` is a fake input — named, never read by the
+// instruction: pass the result of an MFMA issued at least two MFMAs later than the producers; the data dependence the
+// compiler sees keeps the statement behind that MFMA, and two back-to-back 16-cycle MFMAs cover the wait states.
+__device__ __forceinline__ float vmax3_after(float a, float b, float c, float after) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after));
+    return r;
+}
+__device__ __forceinline__ float vmax_after(float a, float b, float after) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b), "v"(after));
+    return r;
+}
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -417,6 +432,7 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 // fp16 MFMA proposal pass
 // ------------------------------------------------------------------------------------------------
 struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2);
 
 __device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
     if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }
@@ -446,16 +462,17 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 //
 // FILTER (small D, where 3 VALU per score against D/8 MFMA cycles per score make the kernel VALU-issue-bound): the 8
 // elements a lane holds per (token tile, code tile) first go through a 4-instruction maximum (v_max3) and ONE compare
-// against the lane's threshold; the per-element update runs only if some lane of the wave exceeds its threshold
-// (wave-uniform branch).  The threshold is the largest runner-up bound b2 among the four lanes that share the token,
-// refreshed once per stage.  Validity: an element that is skipped is <= the threshold of its time <= the final
-// max-over-lanes b2, which is what the merged record carries as v3 (bound on everything unidentified); with the
-// lane's own b2 as threshold the skip would change nothing at all (med3(b1,b2,v) = b2 and max(b1,v) = b1 for
-// v <= b2), the shared threshold only moves the few rows whose third-best lies within the margin to the second pass.
+// against the lane's threshold; the per-element update runs only if some lane of the wave reaches its threshold
+// (wave-uniform branch).  The threshold of a token is (best score any of its four lanes has seen) - (the row's margin
+// m, the very number the decision kernel uses), refreshed once per stage.  A skipped score s satisfies
+// s < best_so_far - m <= final best - m = the decision threshold, so it is strictly outside the candidate set the
+// margin defines and needs neither identification nor a bound in the record; every score within the margin of the
+// running best still goes through the exact per-element update.  Rows without a usable margin never skip.
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
 __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
-    float *__restrict__ rec, int64_t Np) {
+    float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
+    const float *__restrict__ rho2, int Dp, int metric) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
     constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
@@ -481,11 +498,20 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
         for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
     }
 
-    float b1[TT], b2[TT], th[TT];
+    float b1[TT], b2[TT], th[TT], mg[TT];
     uint32_t t1[TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; th[t] = -INFINITY; t1[t] = 0; }
+    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; th[t] = -INFINITY; mg[t] = INFINITY; t1[t] = 0; }
     static_assert(!FILTER || PIPE, "the filtered epilogue is written for the ping-pong form");
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+            tokn = tokn < N ? tokn : N - 1;
+            const float m = row_margin(cbst, Dp, metric, xh2[tokn], rho2[tokn]);
+            mg[t] = (m > 0.0f) ? m : INFINITY;                 // no usable bound: threshold -inf, nothing is skipped
+        }
+    }
 
     auto issue_stage = [&](int64_t st, int buf) {
         const char *src = frag + st * (int64_t)STAGE_BYTES;
@@ -556,10 +582,12 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                     for (int i = 0; i < (TT + NSTEP - 1) / NSTEP; ++i) {
                         const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % (NSTEP / TT) == 0) ? ch / (NSTEP / TT) : -1);
                         if (t >= 0 && t < TT) {
-                            const float m0 = vmax3(prv[0][t][0], prv[0][t][1], prv[0][t][2]);
-                            const float m1 = vmax3(prv[0][t][3], prv[1][t][0], prv[1][t][1]);
-                            const float tm = vmax3(m0, m1, vmax(prv[1][t][2], prv[1][t][3]));
-                            if (__any(tm > th[t])) {
+                            // (ordered behind this chunk's last MFMA: >= TT MFMAs after the previous tile's last one)
+                            const float dep = cur[ch & 1][TT - 1][0];
+                            const float m0 = vmax3_after(prv[0][t][0], prv[0][t][1], prv[0][t][2], dep);
+                            const float m1 = vmax3_after(prv[0][t][3], prv[1][t][0], prv[1][t][1], dep);
+                            const float tm = vmax3(m0, m1, vmax_after(prv[1][t][2], prv[1][t][3], dep));
+                            if (__any(!(tm < th[t]))) {
                                 const uint32_t was = __float_as_uint(b1[t]);
 #pragma unroll
                                 for (int e = 0; e < NE; ++e) {
@@ -602,9 +630,9 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                     t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
             }
         }
-        if constexpr (FILTER) {      // refresh the skip thresholds: largest runner-up bound among the token's four lanes
+        if constexpr (FILTER) {      // refresh the skip thresholds: best score among the token's four lanes, less the margin
 #pragma unroll
-            for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b2[t]);
+            for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
         }
         __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
     }

@@ -26,7 +26,10 @@ VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 1024 && (D % 8) == 
 // tiles (32 codes) staged per LDS stage
 // (the proposal kernel keeps a ring of four stages up to D = 256: 4 x 33 KiB at D = 256, hence two tiles per stage there)
 #define VQ_TPS16 2
-VQ_HD int vq_tiles_per_stage(int nstep) { return nstep < 16 ? 4 : (nstep <= 32 ? 2 : 1); }
+#ifndef VQ_TPS_D32
+#define VQ_TPS_D32 4               // D <= 32 (one 32-dim k-step): tiles per stage (the aux chunk holds at most 8 tiles' biases)
+#endif
+VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 2 ? VQ_TPS_D32 : (nstep < 16 ? 4 : (nstep <= 32 ? 2 : 1)); }
 
 struct VqCbLayout {
     int64_t K, Kp;          // codes, codes padded to a whole stage

@@ -24,6 +24,25 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_tensor_device(fn):
+    """Run the wrapped op with the first device tensor argument's device current: the launches go to that device's
+    current stream, and the per-device kernel attributes (dynamic LDS size) are set for the right device.  A no-op when
+    the tensors already live on the current device (the usual one-process-per-GPU case)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            t = a.weight if isinstance(a, PreparedCodebook) else a
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                if t.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(t.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
 def _require_cuda(*ts: torch.Tensor) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -68,6 +87,7 @@ class PreparedCodebook:
     metric: int
 
 
+@_on_tensor_device
 def prepare_codebook(e: torch.Tensor, metric='L2') -> PreparedCodebook:
     _require_cuda(e)
     e = _codebook(e)
@@ -79,6 +99,7 @@ def prepare_codebook(e: torch.Tensor, metric='L2') -> PreparedCodebook:
     return PreparedCodebook(image, e, K, D, m)
 
 
+@_on_tensor_device
 def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] = None,
            return_stats: bool = False):
     """idx[n] = argmin_k distance(x_n, e_k) — fused fp16 proposal + exact fp32 re-rank.
@@ -104,6 +125,7 @@ def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] =
     return idx
 
 
+@_on_tensor_device
 def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None,
                  return_min: bool = False):
     """Same contract as ``argmin`` evaluated entirely with fp32 MFMA (x, e normalised by the caller for cosine)."""
@@ -121,6 +143,7 @@ def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[t
     return (idx, dmin) if return_min else idx
 
 
+@_on_tensor_device
 def distance(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     """Materialised d[N, K] (memo['distance']); x, e normalised by the caller for cosine."""
     _require_cuda(x, e)
@@ -136,6 +159,7 @@ def distance(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     return d
 
 
+@_on_tensor_device
 def col_argmin(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     """NearestAnchor indices: for every code the nearest token (lowest token on ties)."""
     _require_cuda(x, e)
@@ -151,6 +175,7 @@ def col_argmin(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def row_sqnorm(v: torch.Tensor) -> torch.Tensor:
     _require_cuda(v)
     v, dt = _latents(v)
@@ -159,6 +184,7 @@ def row_sqnorm(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def normalize_rows(v: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     """F.normalize(v, dim=1) as fp32."""
     _require_cuda(v)
@@ -169,6 +195,7 @@ def normalize_rows(v: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def gather_ste_loss(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: bool = True,
                     need_ste: bool = True, need_sse: bool = True):
     """(z = e[idx], z_ste = x + (z - x), sse = sum (z-x)^2 as a float64[1] tensor); unwanted outputs are None."""
@@ -186,6 +213,7 @@ def gather_ste_loss(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z:
     return z, zs, sse
 
 
+@_on_tensor_device
 def hist(idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _require_cuda(idx)
     idx = idx.reshape(-1).contiguous()
@@ -226,6 +254,7 @@ def use_ordered(K: int, D: int, ordered: Optional[bool] = None, N: Optional[int]
     return bool(ordered)
 
 
+@_on_tensor_device
 def token_order(idx: torch.Tensor, K: int):
     """Stable counting sort of the token ids by code: (counts int32[K], offsets int32[K+1], order int32[N])."""
     _require_cuda(idx)
@@ -242,6 +271,7 @@ def token_order(idx: torch.Tensor, K: int):
     return counts, offsets, order[:N]
 
 
+@_on_tensor_device
 def segsum_rows(src: torch.Tensor, idx: torch.Tensor, offsets: torch.Tensor, order: torch.Tensor, K: int) -> torch.Tensor:
     """out[k] = sum of src[order[p]] for p in [offsets[k], offsets[k+1]) in the fixed blocked order of the ordered route
     (fp32; see include/vqhip.h)."""
@@ -256,6 +286,7 @@ def segsum_rows(src: torch.Tensor, idx: torch.Tensor, offsets: torch.Tensor, ord
     return out
 
 
+@_on_tensor_device
 def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None,
                      ordered: Optional[bool] = None) -> torch.Tensor:
     """out[idx[n]] += src[n] (centroid sums / dense embedding backward).  Ordered route (see ``use_ordered``) when no
@@ -273,6 +304,7 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, K: int, out: Optional
     return out
 
 
+@_on_tensor_device
 def gather_rows(x: torch.Tensor, row_idx: torch.Tensor) -> torch.Tensor:
     _require_cuda(x, row_idx)
     x, dt = _latents(x)
@@ -283,16 +315,19 @@ def gather_rows(x: torch.Tensor, row_idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def vqkd_update_(w: torch.Tensor, hist64: torch.Tensor, sums: torch.Tensor, decay: float, mode: str = 'full') -> torch.Tensor:
     """In-place VQ-KD codebook update on a contiguous fp32 [K, D] tensor (mode 'centroid': k-means centroids only)."""
     _require_cuda(w, hist64, sums)
     assert w.dtype == torch.float32 and w.is_contiguous() and hist64.dtype == torch.int64
     K, D = w.shape
-    check(_lib.lib().vqhip_vqkd_update(_ptr(w), _ptr(hist64.contiguous()), _ptr(sums.contiguous()), K, D, decay,
+    hist64, sums = hist64.contiguous(), sums.contiguous()      # named: they must outlive the enqueue
+    check(_lib.lib().vqhip_vqkd_update(_ptr(w), _ptr(hist64), _ptr(sums), K, D, decay,
                                        1 if mode == 'centroid' else 0, _stream()), 'vqhip_vqkd_update')
     return w
 
 
+@_on_tensor_device
 def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: Optional[torch.Tensor], numel, anchors: Optional[torch.Tensor],
                 ema_decay: float, eps: float, stage: int = 3) -> None:
     """In-place CVQ-VAE update; stage 1 = probability only, 2 = codebook only (from the current p), 3 = both.
@@ -311,6 +346,7 @@ def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: Optional[torch.Tensor]
                                       _stream()), 'vqhip_cvq_update')
 
 
+@_on_tensor_device
 def cvq_decay(p: torch.Tensor, K: int, ema_decay: float, eps: float) -> torch.Tensor:
     """decay_k = 1 - exp(-p_k*K*10/(1-ema_decay) - eps) with the update kernel's own expression (fp32 [K])."""
     _require_cuda(p)
@@ -320,6 +356,7 @@ def cvq_decay(p: torch.Tensor, K: int, ema_decay: float, eps: float) -> torch.Te
     return out
 
 
+@_on_tensor_device
 def cvq_update_rows_(w: torch.Tensor, p: torch.Tensor, rows: torch.Tensor, anchors_sub: torch.Tensor, ema_decay: float,
                      eps: float) -> None:
     """In place: w[rows[i]] = w[rows[i]]*decay + anchors_sub[i]*(1-decay) — stage 2 of the CVQ-VAE update for the
@@ -342,6 +379,7 @@ def _any(t: torch.Tensor):
     return t, (_lib.DTYPE_F32 if t.dtype == torch.float32 else _lib.DTYPE_BF16)
 
 
+@_on_tensor_device
 def sse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """sum((a-b)^2) as a float64[1] device tensor."""
     _require_cuda(a, b)
@@ -354,6 +392,7 @@ def sse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def diff_scale(a: torch.Tensor, b: torch.Tensor, scale: float, scale_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(a - b) * scale [* scale_dev] as fp32 (the MSE backward; scale_dev = upstream scalar gradient on the device)."""
     _require_cuda(a, b)
@@ -368,6 +407,7 @@ def diff_scale(a: torch.Tensor, b: torch.Tensor, scale: float, scale_dev: Option
     return out.view(shape)
 
 
+@_on_tensor_device
 def ste(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     """x + (z - x) as fp32."""
     _require_cuda(x, z)
@@ -379,6 +419,7 @@ def ste(x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return out.view(shape)
 
 
+@_on_tensor_device
 def normalize_rows_bwd(v: torch.Tensor, g: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     _require_cuda(v, g)
     v, dt = _latents(v)
@@ -389,6 +430,7 @@ def normalize_rows_bwd(v: torch.Tensor, g: torch.Tensor, eps: float = 1e-12) -> 
     return out
 
 
+@_on_tensor_device
 def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Optional[torch.Tensor],
                 g_cb: Optional[torch.Tensor], g_cm: Optional[torch.Tensor], need_x: bool, need_w: bool,
                 ordered: Optional[bool] = None):
@@ -423,6 +465,7 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
     return gx, gw
 
 
+@_on_tensor_device
 def transpose_last2(t: torch.Tensor) -> torch.Tensor:
     """[B, R, C] -> [B, C, R] for fp32 / bf16 / fp16 tensors (the BCHW <-> (BHW)C rearrangement)."""
     _require_cuda(t)
@@ -434,6 +477,7 @@ def transpose_last2(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def codebook_metrics(counts: torch.Tensor) -> torch.Tensor:
     """float64[2] device tensor: (usage = nonzero/K, entropy in nats) of an int64 count vector."""
     _require_cuda(counts)
@@ -443,6 +487,7 @@ def codebook_metrics(counts: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def debug_proposal_scores(x: torch.Tensor, cb: PreparedCodebook):
     """(scores[N, K], margin[N], scale) of the fp16 proposal pass — verification aid for the error-bound tests."""
     _require_cuda(x)

@@ -74,48 +74,63 @@ class NearestAnchor(BaseAnchor):
 
 @AnchorRegistry.register_()
 class MultinomialAnchor(BaseAnchor):
-    """anchors.py:88-104 — needs the materialised matrix; not used by any shipped config (fallback, unoptimised)."""
+    """One latent per code drawn from softmax over the code's column of distances (anchors.py:88-104).  Needs the
+    materialised matrix (HIP distance kernel); the draw uses the device generator.  No shipped config uses it."""
+
+    @staticmethod
+    def probabilities(d) -> torch.Tensor:
+        return as_distance_tensor(d).detach().t().softmax(1)             # [K, N]
 
     def _anchors(self, x, e, d, quant, p, memo: Memo):
-        d = as_distance_tensor(d)
-        indices = d.t().softmax(1).multinomial(1).reshape(-1)
+        indices = self.probabilities(d).multinomial(1).reshape(-1)
         return ops.gather_rows(x, indices), memo
 
 
 @AnchorRegistry.register_()
 class CachedAnchor(BaseAnchor):
-    """anchors.py:107-166 — random permutation with a cache of the previous anchors (fallback, unoptimised)."""
+    """K anchors drawn without replacement from a pool of candidate rows: this step's latents, topped up — when the
+    batch is smaller than the codebook — with the anchors of the previous step (the ``_cache`` buffer) and, if that is
+    still not enough, with uniform noise (vq/algorithms/cvqvae/anchors.py:107-166; no shipped config uses it).
+    The draw itself uses the host-side generators the reference uses (``random.sample`` when the pool is larger than
+    the codebook, the CPU ``torch.randperm`` otherwise), so a seeded run selects the same rows as the reference on any
+    device; only the noise rows come from the device generator."""
 
     def __init__(self, *args, **kwargs) -> None:
         super().__init__(*args, **kwargs)
-        self._update_cache(torch.empty(0))
+        self.register_buffer('_cache', torch.empty(0))
 
     @property
     def cache(self) -> torch.Tensor:
         return self.get_buffer('_cache')
 
-    def _update_cache(self, value: torch.Tensor) -> None:
-        self.register_buffer('_cache', value)
-
     def _load_from_state_dict(self, state_dict: Mapping[str, torch.Tensor], prefix: str, *args, **kwargs) -> None:
-        cache = state_dict.get(f'{prefix}_cache')
-        if cache is not None:
-            self.cache.resize_(cache.shape)
+        saved = state_dict.get(prefix + '_cache')
+        if saved is not None:
+            self.cache.resize_(saved.shape)          # the buffer starts empty: give it the checkpoint's shape first
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _pool(self, x: torch.Tensor, K: int) -> torch.Tensor:
+        pool = x.float()
+        if pool.shape[0] < K and self.cache.numel() > 0:
+            pool = torch.cat([pool, self.cache.to(pool.device)])
+        return pool
+
+    @staticmethod
+    def _draw(rows: int, K: int) -> torch.Tensor:
+        if rows > K:
+            return torch.as_tensor(random.sample(range(rows), K))
+        return torch.randperm(K)                      # indices >= rows select the noise rows appended below
 
     def _anchors(self, x, e, d, quant, p, memo: Memo):
         K = e.shape[0]
-        x = x.float()
-        if x.shape[0] < K and self.cache.numel() > 0:
-            x = torch.cat([x, self.cache.to(x.device)])
-        indices = torch.randperm(K) if x.shape[0] <= K else torch.as_tensor(random.sample(range(x.shape[0]), K))
-        if x.shape[0] < K:
-            missing = torch.rand(K - x.shape[0], x.shape[1], device=x.device)
-            x = torch.cat([x, missing])
-        anchors = ops.gather_rows(x, indices.to(x.device))
-        return anchors, memo
+        pool = self._pool(x, K)
+        picks = self._draw(pool.shape[0], K)
+        short = K - pool.shape[0]
+        if short > 0:
+            pool = torch.cat([pool, torch.rand(short, pool.shape[1], device=pool.device)])
+        return ops.gather_rows(pool, picks.to(pool.device)), memo
 
     def forward(self, *args, **kwargs):
         anchors, memo = super().forward(*args, **kwargs)
-        self._update_cache(anchors.detach())
+        self.register_buffer('_cache', anchors.detach())
         return anchors, memo

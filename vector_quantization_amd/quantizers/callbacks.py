@@ -77,9 +77,25 @@ class BaseCallback(QuantizerHolderMixin):
 
 _DECODE_LOSS_HOOKS = ('before_decode', 'after_decode', 'before_loss', 'after_loss')
 
+# The nine hooks of the protocol (callbacks/composed.py:16-19) -> positions of the arguments a callback may replace by its
+# return value: none for the two notification hooks, one for the value-threading hooks, two for before_loss.
+_HOOK_THREADS = {
+    'bind': (), 'before_init_weights': (),
+    'after_init_weights': (1,),          # (config, recursive) -> recursive
+    'before_encode': (0,),               # (x, memo) -> x
+    'after_encode': (1,),                # (x, quant, memo) -> quant
+    'before_decode': (0,),               # (quant, memo) -> quant
+    'after_decode': (0,),                # (z, memo) -> z
+    'before_loss': (0, 1),               # (z, x, memo) -> (z, x)
+    'after_loss': (0,),                  # (loss, memo) -> loss
+}
+
 
 @VQITQuantizerCallbackRegistry.register_()
 class ComposedCallback(BuildPreHookMixin, BaseCallback):
+    """Fans every hook out to its callbacks in per-hook priority order (ascending, stable), threading the value each
+    hook may rewrite from one callback to the next (callbacks/composed.py:22-108).  The dispatchers are generated from
+    ``_HOOK_THREADS`` below the class."""
 
     def __init__(self, *args, priorities: Iterable[Mapping[str, int]], callbacks: Iterable[BaseCallback], **kwargs) -> None:
         super().__init__(*args, **kwargs)
@@ -88,9 +104,9 @@ class ComposedCallback(BuildPreHookMixin, BaseCallback):
     @classmethod
     def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
         config = super().build_pre_hook(config, registry, item)
-        callbacks = [Config(c) if isinstance(c, dict) else c for c in config.callbacks]
-        config.priorities = [c.pop('priority', dict()) if isinstance(c, dict) else dict() for c in callbacks]
-        config.callbacks = [registry.build_or_return(c) for c in callbacks]
+        entries = [Config(c) if isinstance(c, dict) else c for c in config.callbacks]
+        config.priorities = [c.pop('priority', dict()) if isinstance(c, dict) else dict() for c in entries]
+        config.callbacks = [registry.build_or_return(c) for c in entries]
         return config
 
     @property
@@ -105,57 +121,31 @@ class ComposedCallback(BuildPreHookMixin, BaseCallback):
                     return True
         return False
 
-    def bind(self, *args, **kwargs) -> None:
-        super().bind(*args, **kwargs)
-        for callback in self._priority_queue('bind'):
-            callback.bind(*args, **kwargs)
 
-    def before_init_weights(self, *args, **kwargs) -> None:
-        super().before_init_weights(*args, **kwargs)
-        for callback in self._priority_queue('before_init_weights'):
-            callback.before_init_weights(*args, **kwargs)
+def _make_dispatcher(hook: str, threaded: tuple):
+    own = getattr(BaseCallback, hook)                       # the composed callback's own (no-op / bind) behaviour runs first
 
-    def after_init_weights(self, config: Config, recursive: bool) -> bool:
-        recursive = super().after_init_weights(config, recursive)
-        for callback in self._priority_queue('after_init_weights'):
-            recursive = callback.after_init_weights(config, recursive)
-        return recursive
+    def dispatch(self, *args, **kwargs):
+        args = list(args)
+        for target in [lambda *a, **k: own(self, *a, **k)] + [getattr(cb, hook) for cb in self._priority_queue(hook)]:
+            out = target(*args, **kwargs)
+            if len(threaded) == 1:
+                args[threaded[0]] = out
+            elif threaded:
+                for pos, value in zip(threaded, out):
+                    args[pos] = value
+        if not threaded:
+            return None
+        return args[threaded[0]] if len(threaded) == 1 else tuple(args[pos] for pos in threaded)
 
-    def before_encode(self, x: torch.Tensor, memo: Memo) -> torch.Tensor:
-        x = super().before_encode(x, memo)
-        for callback in self._priority_queue('before_encode'):
-            x = callback.before_encode(x, memo)
-        return x
+    dispatch.__name__ = dispatch.__qualname__ = hook
+    dispatch.__doc__ = f'{hook}: own behaviour, then every callback in priority order' + \
+        (f' (argument(s) {threaded} threaded through the returns)' if threaded else '')
+    return dispatch
 
-    def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
-        quant = super().after_encode(x, quant, memo)
-        for callback in self._priority_queue('after_encode'):
-            quant = callback.after_encode(x, quant, memo)
-        return quant
 
-    def before_decode(self, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
-        quant = super().before_decode(quant, memo)
-        for callback in self._priority_queue('before_decode'):
-            quant = callback.before_decode(quant, memo)
-        return quant
-
-    def after_decode(self, z: torch.Tensor, memo: Memo) -> torch.Tensor:
-        z = super().after_decode(z, memo)
-        for callback in self._priority_queue('after_decode'):
-            z = callback.after_decode(z, memo)
-        return z
-
-    def before_loss(self, z: torch.Tensor, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor]:
-        z, x = super().before_loss(z, x, memo)
-        for callback in self._priority_queue('before_loss'):
-            z, x = callback.before_loss(z, x, memo)
-        return z, x
-
-    def after_loss(self, loss: torch.Tensor, memo: Memo) -> torch.Tensor:
-        loss = super().after_loss(loss, memo)
-        for callback in self._priority_queue('after_loss'):
-            loss = callback.after_loss(loss, memo)
-        return loss
+for _hook, _threaded in _HOOK_THREADS.items():
+    setattr(ComposedCallback, _hook, _make_dispatcher(_hook, _threaded))
 
 
 class LazyInitWeightsMixin(BaseCallback):

@@ -1,7 +1,8 @@
 """Distances — mirror of vq/algorithms/vq/distances.py:19-46.
 
-``forward(x, e)`` materialises d[N, K] like the reference (used only by consumers that need the matrix);
-``argmin(x, e)`` is the fused hot path that never forms it."""
+``forward(x, e)`` materialises d[N, K] like the reference, WITH autograd (forward = the HIP fp32-MFMA distance kernel,
+backward = two plain library GEMMs; used only by consumers that need the matrix); ``argmin(x, e)`` is the fused hot
+path that never forms it."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
@@ -9,14 +10,70 @@ from typing import Optional
 
 import torch
 from torch import nn
+from torch.autograd import Function
 
+from .. import functional as VF
 from .. import ops
 from ..registries import VQITQuantizerDistanceRegistry
 
 
-class LazyDistance:
-    """Stands in for memo['distance'] (vq/algorithms/vq/quantizers.py:98): the [N, K] matrix is produced by the HIP
-    distance kernel only if a consumer asks for it."""
+class _L2Matrix(Function):
+    """d = torch.cdist(x, e) (p = 2, mm path).  Backward of the same definition:
+    G = g / d (0 where d == 0, as torch.cdist's backward defines it);
+    dx = x * rowsum(G) - G @ e;  de = e * colsum(G) - G^T @ x   — two plain fp32 GEMMs (library), no [N, K, D] temporary."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+        d = ops.distance(x, e, 'L2')
+        ctx.save_for_backward(x, e, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e, d = ctx.saved_tensors
+        x32, e32 = x.float(), e.float()
+        G = torch.where(d > 0, g / d, torch.zeros_like(g))
+        gx = ge = None
+        if ctx.needs_input_grad[0]:
+            gx = (x32 * G.sum(1, keepdim=True) - G @ e32).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            ge = (e32 * G.sum(0).unsqueeze(1) - G.t() @ x32).to(e.dtype)
+        return gx, ge
+
+
+class _DotMatrix(Function):
+    """d = 1 - xn @ en^T on operands that are already normalised (CosineDistance: distances.py:39-46)."""
+
+    @staticmethod
+    def forward(ctx, xn: torch.Tensor, en: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(xn, en)
+        return ops.distance(xn, en, 'Cosine')
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, en = ctx.saved_tensors
+        gx = -(g @ en) if ctx.needs_input_grad[0] else None
+        ge = -(g.t() @ xn) if ctx.needs_input_grad[1] else None
+        return gx, ge
+
+
+class LazyDistance(torch.Tensor):
+    """memo['distance'] (vq/algorithms/vq/quantizers.py:98) without the cost: a tensor-typed handle of shape [N, K]
+    whose values are produced (by the HIP distance kernel, with autograd to x and the codebook) only when a consumer
+    actually touches them.  ``d.argmin(0)`` / ``d.argmin(-1)`` — the only uses by shipped configs — never materialise:
+    they run the fused column / row argmin.  Any other torch function or tensor method applied to it (softmax,
+    division, indexing, einops.rearrange, torch.cat, ...) transparently sees the real fp32 matrix, so third-party
+    callbacks and losses written against the reference keep working."""
+
+    _METADATA = frozenset({'shape', 'dtype', 'device', 'layout', 'ndim', 'requires_grad', 'is_cuda', 'size', 'dim',
+                           'numel', 'nelement', 'is_floating_point', 'is_complex', 'element_size', 'stride',
+                           'is_contiguous', 'storage_offset', '__len__', 'is_sparse', 'is_quantized', 'is_meta',
+                           'names', 'grad_fn', 'grad', 'is_leaf', 'output_nr', '_version', 'data_ptr', 'is_inference',
+                           'retains_grad', '_base', 'is_nested', 'is_mkldnn', 'is_xpu', 'is_mps', 'is_cpu'})
+
+    @staticmethod
+    def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor):
+        return torch.Tensor._make_wrapper_subclass(cls, (x.shape[0], e.shape[0]), dtype=torch.float32, device=x.device)
 
     def __init__(self, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor) -> None:
         self._distance, self._x, self._e = distance, x, e
@@ -35,12 +92,45 @@ class LazyDistance:
             self._value = self._distance(self._x, self._e)
         return self._value
 
-    def argmin(self, dim: int) -> torch.Tensor:
-        assert dim in (0, -1, 1)
-        if dim == 0:        # NearestAnchor: d.argmin(0), fused (never materialises)
+    def fused_argmin(self, dim: int) -> torch.Tensor:
+        if dim == 0:        # NearestAnchor: d.argmin(0) — nearest latent per code
             xq, eq = self._distance.exact_operands(self._x, self._e)
             return ops.col_argmin(xq, eq, self.metric)
         return self._distance.argmin(self._x, self._e)
+
+    def __repr__(self):
+        return f'LazyDistance({self.metric}, shape={tuple(self.shape)}, materialized={self._value is not None})'
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, '__name__', '')
+        if name == '__get__':                                   # attribute descriptors: Tensor.shape.__get__ ...
+            name = getattr(getattr(func, '__self__', None), '__name__', '')
+        if name in cls._METADATA:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if name == 'argmin' and args and isinstance(args[0], LazyDistance) and args[0]._value is None:
+            dim = args[1] if len(args) > 1 else kwargs.get('dim')
+            if dim in (0, 1, -1) and not kwargs.get('keepdim', False):
+                return args[0].fused_argmin(dim)
+
+        def real(a):
+            if isinstance(a, LazyDistance):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(i) for i in a)
+            return a
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*real(args), **{k: real(v) for k, v in kwargs.items()})
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        """Safety net for calls that reach the dispatcher without passing __torch_function__ (C++ callers)."""
+        from torch.utils._pytree import tree_map
+        unwrap = lambda a: a.materialize() if isinstance(a, LazyDistance) else a   # noqa: E731
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
 
 
 def as_distance_tensor(d) -> torch.Tensor:
@@ -73,8 +163,8 @@ class L2Distance(BaseDistance):
     metric = 'L2'
 
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
-        """torch.cdist(x, e) (mm path), fp32."""
-        return ops.distance(x.detach(), e.detach(), 'L2')
+        """torch.cdist(x, e) (mm path), fp32, differentiable."""
+        return _L2Matrix.apply(x, e)
 
 
 @VQITQuantizerDistanceRegistry.register_()
@@ -87,10 +177,10 @@ class CosineDistance(BaseDistance):
     @staticmethod
     def cosine_similarity(x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         """normalize(x) @ normalize(e).T, returned as 1 - distance (the distance kernel's own value)."""
-        return 1 - ops.distance(ops.normalize_rows(x.detach()), ops.normalize_rows(e.detach()), 'Cosine')
+        return 1 - _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
 
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
-        return ops.distance(ops.normalize_rows(x.detach()), ops.normalize_rows(e.detach()), 'Cosine')
+        return _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
 
     def argmin(self, x, e, hist=None, prepared=None):
         cb = prepared if prepared is not None else self.prepare(e)

@@ -129,8 +129,10 @@ class VQGANLoss(BuildPreHookMixin, BaseLoss):
 @VQITQuantizerLossRegistry.register_()
 class EntropyLoss(BaseLoss):
     """vq/algorithms/vq/losses.py:130-153 ("TODO: refactor" in the reference; used by no shipped config).
-    Needs the whole [N, K] matrix with autograd, which the fused path never forms: this is an explicit, unoptimised
-    materialising fallback on stock device ops, outside the hot path (DESIGN.md "Out of scope")."""
+    Needs the whole [N, K] matrix with autograd, which the fused path never forms: ``memo['distance']`` (a
+    ``LazyDistance``) is materialised on demand by the HIP distance kernel with gradients to the latents and the
+    codebook (``distances._L2Matrix`` / ``_DotMatrix``); the softmax/entropy arithmetic on it is stock device ops.
+    As in the reference the loss reads ``memo['distance']`` of the memo it is handed (the encode-stage memo)."""
 
     def __init__(self, *args, temperature: float, **kwargs) -> None:
         super().__init__(*args, **kwargs)

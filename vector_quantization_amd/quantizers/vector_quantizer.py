@@ -117,7 +117,14 @@ class VectorQuantizer(BaseQuantizer):
         if self.training and len(self._callbacks.callbacks) > 0:
             hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
         quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w))
-        memo['distance'] = LazyDistance(self._distance, x2, w)
+        # memo['distance'] stays symbolic.  With autograd on, its operands keep their graph (EntropyLoss differentiates
+        # through the matrix: losses.py:130-153); the codebook operand is an alias of the CURRENT weight storage, so the
+        # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
+        if torch.is_grad_enabled() and (x.requires_grad or self._embedding.weight.requires_grad):
+            weight = self._embedding.weight
+            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight))
+        else:
+            memo['distance'] = LazyDistance(self._distance, x2, w)
         if hist is not None:
             memo['hist'] = hist
         return quant.reshape(shape), memo
