@@ -261,6 +261,21 @@ def main():
             return z, loss, memo
 
         ops_step = train_step = None
+        graph_step = None
+        if not distributed or backend == 'nccl':            # HIP-graph replay of the same step (graphs.py); gloo cannot be captured
+            from vector_quantization_amd.graphs import GraphedQuantizer
+            qg = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
+            xg = x.detach().clone().requires_grad_(True)
+            try:
+                gq = GraphedQuantizer(qg, xg.detach())
+
+                def graph_step():
+                    qg.zero_grad(set_to_none=True)
+                    xg.grad = None
+                    z, loss, _ = gq(xg)
+                    (loss + z.mean()).backward()
+            except Exception as exc:                          # reported, never silently dropped
+                extra['module_graphed'] = {'error': f'{type(exc).__name__}: {exc}'}
         tokens_per_step_global = N * world
         scaling = 'weak'
         workload = ('CVQ-VAE training step K=16384 D=256 cosine, VQGANQuantizer + CVQVAECallback(NearestAnchor): forward '
@@ -335,6 +350,12 @@ def main():
         extra['module_train'] = {'ms_per_step': e_tr / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_tr,
                                  'what': 'VQGANQuantizer.forward in train mode + backward (fused HIP backward, codebook gradient)'}
     elif wl == 'cvq':
+        if graph_step is not None:
+            side_steps = max(10, args.steps)
+            e_g, _, _ = timed(graph_step, side_steps, 3)
+            extra['module_graphed'] = {'ms_per_step': e_g / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_g,
+                                       'what': 'the same training step replayed from HIP graphs (GraphedQuantizer: forward with '
+                                               'in-place codebook update + backward, one launch each)'}
         loss = float(out[1].item())
         used_codes = int((out[2]['encode']['hist'] > 0).sum().item()) if 'hist' in out[2]['encode'] else None
         wsum = q.embedding.weight.detach().double().sum().reshape(1).to(coll_dev)

@@ -426,3 +426,62 @@ def test_cvq_full_size_c4_step():
     np.testing.assert_allclose(q.get_buffer('_probability').cpu().numpy(), p1, rtol=1e-6, atol=1e-9)
     w_new = co.ema(w, x[col], co.cvq_decay(p1, K, 0.99, 1e-3))
     np.testing.assert_allclose(q.embedding.weight.detach().cpu().numpy(), w_new, rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize('mode', ['cvq_train', 'vqgan_eval'])
+def test_graphed_quantizer_steps_match_eager(mode):
+    """GraphedQuantizer (graphs.py): the whole module step — callbacks with the in-place codebook update, decode, loss and,
+    in train mode, the backward — replayed from HIP graphs gives the eager module's results step after step: identical
+    tokens, outputs and codebooks, gradients to summation-order tolerance."""
+    from vector_quantization_amd.graphs import GraphedQuantizer
+    N, K, D = 3072, 2048, 64
+    gen = synth.rng(17)
+    w0 = synth.unit_rows(gen.standard_normal((K, D), dtype=np.float32))
+    xs = [gen.standard_normal((N, D), dtype=np.float32) for _ in range(3)]
+    up = torch.from_numpy(gen.standard_normal((N, D), dtype=np.float32)).cuda()
+    train = mode == 'cvq_train'
+    cbs = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))] if train else []
+
+    def make():
+        q = build(vqgan_cfg(K, D, 'Cosine' if train else 'L2', callbacks=cbs), train=train, init=dict(type='vqgan'))
+        set_weight(q, w0)
+        return q
+
+    def run(step):
+        out = []
+        for x in xs:
+            xd = torch.from_numpy(x).cuda().requires_grad_(train)
+            z, loss, quant = step(xd)
+            if train:
+                q_ = step.quantizer if hasattr(step, 'quantizer') else step.__self__
+                q_.zero_grad(set_to_none=True)
+                (loss + (z * up).sum()).backward()
+                grads = (xd.grad.clone(), q_.embedding.weight.grad.clone())
+            else:
+                grads = None
+            out.append((quant.clone(), z.detach().clone(), loss.detach().clone(), grads))
+        return out
+
+    class Eager:
+        def __init__(self, q):
+            self.quantizer = q
+
+        def __call__(self, x):
+            z, loss, memo = self.quantizer(x, {})
+            return z, loss, memo['quant']
+
+    q1, q2 = make(), make()
+    ref = run(Eager(q1))
+    gq = GraphedQuantizer(q2, torch.from_numpy(xs[0]).cuda())
+    assert torch.equal(q2.embedding.weight.detach().cpu(), torch.from_numpy(w0))          # capture left no trace
+    got = run(gq)
+    for (qa, za, la, ga), (qb, zb, lb, gb) in zip(ref, got):
+        assert torch.equal(qa, qb) and torch.equal(za, zb)
+        assert abs(la.item() - lb.item()) <= 1e-6 * max(1.0, abs(la.item()))
+        if train:
+            np.testing.assert_allclose(gb[0].cpu().numpy(), ga[0].cpu().numpy(), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(gb[1].cpu().numpy(), ga[1].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert torch.equal(q1.embedding.weight.detach(), q2.embedding.weight.detach())          # bit-identical codebooks after 3 steps
+    if train:
+        assert torch.equal(q1.get_buffer('_probability'), q2.get_buffer('_probability'))
+        assert not torch.equal(q2.embedding.weight.detach().cpu(), torch.from_numpy(w0))   # and they did move

@@ -8,12 +8,17 @@ import torch
 from vector_quantization_amd import ops
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+DIMS = [int(d) for d in os.environ['VQ_FUZZ_DIMS'].split(',')] if 'VQ_FUZZ_DIMS' in os.environ else \
+    [8, 16, 32, 64, 128, 256, 256, 256, 512, 768, 1024]
+if 'VQ_FILTER' in os.environ:                      # A/B knob: 0 = unfiltered epilogue on the small-D proposal kernels
+    from vector_quantization_amd import _lib
+    _lib.lib().vqhip_set_tuning(5, int(os.environ['VQ_FILTER']))
 g = torch.Generator(device='cuda').manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 20261003)
 def ri(lo, hi): return int(torch.randint(lo, hi, (1,), generator=g, device='cuda').item())
 t_end = time.time() + budget
 trials = bad = 0
 while time.time() < t_end:
-    D = [8, 16, 32, 64, 128, 256, 256, 256, 512, 768, 1024][ri(0, 11)]
+    D = DIMS[ri(0, len(DIMS))]
     K = [ri(1, 64), ri(64, 4096), 8192, 16384, ri(4096, 20000)][ri(0, 5)]
     N = [ri(1, 512), ri(512, 70000), 65536, ri(70000, 300000)][ri(0, 4)]
     if N * K * D > 3e12: N = max(1, int(3e12 / (K * D)))

@@ -104,22 +104,20 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
 }
 
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
-static int launch_rescan_cfg(const char *rimg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
+static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
                              const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
     auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
-    kern<<<256, WAVES * 64, LDS, s>>>(rimg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
+    kern<<<256, WAVES * 64, LDS, s>>>(ximg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
     VQ_CHECK_LAUNCH("rescan_kernel");
     return VQHIP_OK;
 }
 
+// filtered (small-D) proposal kernels: long code streams make the skip test effective, so one slice is allowed
 #ifndef VQ_MIN_SLICES_FILTER
-#define VQ_MIN_SLICES_FILTER 2
-#endif
-#ifndef VQ_TT_D32
-#define VQ_TT_D32 4
+#define VQ_MIN_SLICES_FILTER 1
 #endif
 static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
     if (const int forced = g_tune_slices.load(); forced > 0) { int ns = forced; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
@@ -142,6 +140,10 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
+    // D <= 32: 32 tokens per wave until 64-token workgroups would number two per CU (measured at N = 100 352, K = 8192:
+    // proposal kernel 128 -> 108 us with 8 tiles per stage, one slice and 32 tokens per wave; at N = 524 288 the
+    // 64-token form is the faster one)
+    const bool small32 = N < 512 * 512;
 #define VQ_CFG(NS, TT, W, ...)                                                                      \
     {                                                                                               \
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
@@ -151,8 +153,8 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
-        case 2: if (!g_tune_filter.load()) { if (small) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4) }
-                if (small) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4, true) else VQ_CFG(2, VQ_TT_D32, 8, VQ_TPS_D32, 4, true)
+        case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4) }
+                if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4, true)
         case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
@@ -309,27 +311,14 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         default: return fail(VQHIP_EINVAL, "vqhip_argmin: bad slice count");
     }
     VQ_CHECK_LAUNCH("refine_decide_kernel");
-    // exact re-rank of the rows with several identified candidates: one lane per (row, record slot)
+    // second-chance proposals for rows with a possibly unidentified candidate (the kernel gathers their fragments from
+    // the token image itself) ...
     float *xnorm = (float *)(w + W.off_xn);
     {
-        const int S = 2 * nslices < 4 ? 4 : 2 * nslices;      // slot lanes per row (power of two, >= 4)
-        if (x_dtype == VQHIP_DTYPE_F32)
-            refine_rerank_kernel<0, 0><<<2048, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
-                                                           hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
-        else
-            refine_rerank_kernel<1, 0><<<2048, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S, rec, xh2, rho2, xnorm, Np, idx,
-                                                           hist, multi_list, counters, nullptr, nullptr, nullptr, nullptr);
-        VQ_CHECK_LAUNCH("refine_rerank_kernel");
-    }
-    // second-chance proposals for rows with a possibly unidentified candidate, then their exact re-rank
-    {
         const char *frag = c + L.off_frag;
-        char *rimg = w + W.off_rimg;
-        rescan_pack_kernel<<<512, 256, 0, s>>>(ximg, rescan_list, counters, L.nstep / 2, 1, rimg);
-        VQ_CHECK_LAUNCH("rescan_pack_kernel");
         int rrc = VQHIP_OK;
         switch (L.nstep) {
-#define VQ_RESCAN(NS, TT, ...) case NS: rrc = launch_rescan_cfg<NS, TT, 8, __VA_ARGS__>(rimg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
+#define VQ_RESCAN(NS, TT, ...) case NS: rrc = launch_rescan_cfg<NS, TT, 8, __VA_ARGS__>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
             VQ_RESCAN(2, 2, VQ_TPS_D32, 4) VQ_RESCAN(4, 2, 4, 4) VQ_RESCAN(8, 2, 4, 4) VQ_RESCAN(16, 2, VQ_TPS16, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
             default: return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
@@ -337,15 +326,23 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         if (rrc) return rrc;
         VQ_CHECK_LAUNCH("rescan_kernel");
     }
-    if (x_dtype == VQHIP_DTYPE_F32)
-        refine_rerank_kernel<0, 1><<<1024, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
-                                                       Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
-                                                       keys);
-    else
-        refine_rerank_kernel<1, 1><<<1024, 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2, rho2, xnorm,
-                                                       Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list,
-                                                       keys);
-    VQ_CHECK_LAUNCH("refine_rerank_kernel<list>");
+    // ... then ONE launch re-ranks exactly both the rows with several identified candidates (one lane per (row, record
+    // slot)) and the rescanned rows' candidate lists; grid shares follow the typical queue lengths (4 % / 0.7 % of N)
+    {
+        const int S0 = 2 * nslices < 4 ? 4 : 2 * nslices;     // slot lanes per multi row (power of two, >= 4)
+        int64_t g0 = (N / 16 + 3) / 4, g1 = (N / 64 + 3) / 4;                 // waves ~ expected rows / rows per wave
+        g0 = g0 < 64 ? 64 : (g0 > 2048 ? 2048 : g0);
+        g1 = g1 < 64 ? 64 : (g1 > 1024 ? 1024 : g1);
+        if (x_dtype == VQHIP_DTYPE_F32)
+            refine_rerank_kernel<0><<<(int)(g0 + g1), 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S0, (int)g0, rec, xh2, rho2,
+                                                                  xnorm, Np, idx, hist, multi_list, rescan_list, counters,
+                                                                  rescan_cnt, cand_list, exact_list, keys);
+        else
+            refine_rerank_kernel<1><<<(int)(g0 + g1), 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S0, (int)g0, rec, xh2, rho2,
+                                                                  xnorm, Np, idx, hist, multi_list, rescan_list, counters,
+                                                                  rescan_cnt, cand_list, exact_list, keys);
+        VQ_CHECK_LAUNCH("refine_rerank_kernel");
+    }
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
     rc = run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, s);
     if (rc) return rc;

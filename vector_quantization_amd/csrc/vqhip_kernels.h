@@ -83,20 +83,55 @@ __device__ __forceinline__ float vmax(float a, float b) {
     return r;
 }
 
-// v_max3_f32 / v_max_f32 on values an MFMA produced.  hipcc pads no hazard for a consumer INSIDE an asm statement
-// (MI355X guide §5.7 item 2: an MFMA's D needs 12 wait states before any non-MFMA reader), so the statement must not be
-// scheduled right behind the MFMA that wrote its inputs.  `after` is a fake input — named, never read by the
-// instruction: pass the result of an MFMA issued at least two MFMAs later than the producers; the data dependence the
-// compiler sees keeps the statement behind that MFMA, and two back-to-back 16-cycle MFMAs cover the wait states.
-__device__ __forceinline__ float vmax3_after(float a, float b, float c, float after) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after));
-    return r;
-}
-__device__ __forceinline__ float vmax_after(float a, float b, float after) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b), "v"(after));
-    return r;
+// v_max3_f32 / v_max_f32 on values an MFMA produced, issued between MFMAs.  hipcc pads no hazard for an instruction
+// INSIDE an asm statement (MI355X guide §5.7 item 2), so the statements below are made hazard-free by construction:
+//  * inputs (an MFMA's D needs 12 wait states before a non-MFMA reader): `after` is a fake input — named, never read by
+//    the instruction; pass the result of an MFMA issued at least two MFMAs later than the producers: the dependence the
+//    compiler sees keeps the statement behind that MFMA, and two back-to-back 16-cycle MFMAs cover the wait states;
+//  * output (a VALU write to a register an in-flight MFMA still reads as A/B/C operand corrupts that MFMA — found by
+//    the randomised campaign: the allocator had given a temporary the register of the A fragment just issued): the
+//    destination is a "+v" variable the caller keeps alive across the whole MFMA loop, so its register is never shared
+//    with an MFMA operand (that turned out NOT to be the cause of the mismatches; kept because it costs nothing).
+// What the campaign did pin down (tools/fuzz_vs_exact.py, D = 64/128: 1.3 % of the trials wrong): one fake input is not
+// enough — hipcc reorders the MFMAs of a chunk, so the single MFMA the statement was tied to could be the one issued
+// right behind the producers.  The statement is therefore tied to ALL TT MFMAs of the chunk (tile_max8 below).
+#ifndef VQ_FILTER_MAX_IMPL
+#define VQ_FILTER_MAX_IMPL 3
+#endif
+// Maximum of the 8 accumulator elements p[0..7] of one (token tile, code tile) into `dst` (sc1/sc2: scratch).
+// after[]: results of TT MFMAs of the CURRENT tile (fake inputs, see above).  Variants kept for the A/B record:
+//   2: compiler-visible v_med3 (max(a,b) = med3(a,b,+inf)), 7 instructions, hazards handled by hipcc
+//   3: 4 asm instructions ordered behind ALL the fake inputs (>= 2 MFMAs after the producers)
+//   4: as 3 in one statement that opens with s_nop 11 (the full 12 wait states, wherever it is placed)
+//   5: as 3 with s_nop 3 in front
+template <int TT>
+__device__ __forceinline__ void tile_max8(float &dst, float &sc1, float &sc2, const f32x4 &lo, const f32x4 &hi,
+                                          const float (&after)[TT]) {
+#if VQ_FILTER_MAX_IMPL == 2
+    float m = __builtin_amdgcn_fmed3f(lo[0], lo[1], INFINITY);
+    m = __builtin_amdgcn_fmed3f(m, lo[2], INFINITY); m = __builtin_amdgcn_fmed3f(m, lo[3], INFINITY);
+    m = __builtin_amdgcn_fmed3f(m, hi[0], INFINITY); m = __builtin_amdgcn_fmed3f(m, hi[1], INFINITY);
+    m = __builtin_amdgcn_fmed3f(m, hi[2], INFINITY); dst = __builtin_amdgcn_fmed3f(m, hi[3], INFINITY);
+    (void)sc1; (void)sc2; (void)after;
+#else
+    const float a0 = after[0], a1 = after[TT > 1 ? 1 : 0], a2 = after[TT > 2 ? 2 : 0], a3 = after[TT > 3 ? 3 : 0];
+#if VQ_FILTER_MAX_IMPL == 4
+#define VQ_TM_HEAD "s_nop 11\n\t"
+#elif VQ_FILTER_MAX_IMPL == 5
+#define VQ_TM_HEAD "s_nop 3\n\t"
+#else
+#define VQ_TM_HEAD ""
+#endif
+    asm(VQ_TM_HEAD
+        "v_max3_f32 %0, %3, %4, %5\n\t"
+        "v_max3_f32 %1, %6, %7, %8\n\t"
+        "v_max_f32 %2, %9, %10\n\t"
+        "v_max3_f32 %0, %0, %1, %2"
+        : "+v"(dst), "+v"(sc1), "+v"(sc2)
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]),
+          "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+#undef VQ_TM_HEAD
+#endif
 }
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
@@ -503,6 +538,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
 #pragma unroll
     for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; th[t] = -INFINITY; mg[t] = INFINITY; t1[t] = 0; }
     static_assert(!FILTER || PIPE, "the filtered epilogue is written for the ping-pong form");
+    float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;     // destinations of the asm maxima: live across the whole loop (see vmax3_into)
     if constexpr (FILTER) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -582,12 +618,12 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                     for (int i = 0; i < (TT + NSTEP - 1) / NSTEP; ++i) {
                         const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % (NSTEP / TT) == 0) ? ch / (NSTEP / TT) : -1);
                         if (t >= 0 && t < TT) {
-                            // (ordered behind this chunk's last MFMA: >= TT MFMAs after the previous tile's last one)
-                            const float dep = cur[ch & 1][TT - 1][0];
-                            const float m0 = vmax3_after(prv[0][t][0], prv[0][t][1], prv[0][t][2], dep);
-                            const float m1 = vmax3_after(prv[0][t][3], prv[1][t][0], prv[1][t][1], dep);
-                            const float tm = vmax3(m0, m1, vmax_after(prv[1][t][2], prv[1][t][3], dep));
-                            if (__any(!(tm < th[t]))) {
+                            // (ordered behind all TT MFMAs of this chunk: >= TT MFMAs after the previous tile's last one)
+                            float after[TT];
+#pragma unroll
+                            for (int u = 0; u < TT; ++u) after[u] = cur[ch & 1][u][0];
+                            tile_max8<TT>(sc0, sc1, sc2, prv[0][t], prv[1][t], after);
+                            if (__any(!(sc0 < th[t]))) {
                                 const uint32_t was = __float_as_uint(b1[t]);
 #pragma unroll
                                 for (int e = 0; e < NE; ++e) {
@@ -818,25 +854,6 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     }
 }
 
-// Packs the fp16 fragments of the rows on rescan_list into a dense fragment-major image in list order, so that the
-// second proposal pass reads whole 1 KiB chunks instead of one 16-byte piece per cache line.
-__global__ __launch_bounds__(256) void rescan_pack_kernel(const char *__restrict__ ximg, const int *__restrict__ rescan_list,
-                                                          const int *__restrict__ counters, int ns32, int group_tiles, char *__restrict__ rimg) {
-    const int nrows = counters[0];
-    const int64_t ntiles = (nrows + 16 * group_tiles - 1) / (16 * group_tiles) * group_tiles;   // whole groups of the rescan kernel
-    const int64_t total = ntiles * ns32 * 64;            // 16-byte pieces
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i & 63);
-        const int64_t c = i >> 6;                        // chunk = tile * ns32 + s
-        const int64_t tile = c / ns32;
-        const int s = (int)(c % ns32);
-        const int64_t slot = tile * 16 + (p & 15);
-        const int64_t tk = rescan_list[slot < nrows ? slot : nrows - 1];   // pad the last tile with a valid row
-        const uint4 v = *(const uint4 *)(ximg + ((tk >> 4) * ns32 + s) * (int64_t)VQ_CHUNK_BYTES + ((p >> 4) * 16 + (int)(tk & 15)) * 16);
-        *(uint4 *)(rimg + i * 16) = v;
-    }
-}
-
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
 // operands, same instruction sequence per accumulator), but every score >= the row's threshold is appended to the row's
 // candidate list.  Same machinery as coarse_kernel — the rows' fragments (from the packed image) stay in registers,
@@ -844,7 +861,7 @@ __global__ __launch_bounds__(256) void rescan_pack_kernel(const char *__restrict
 // (block of WAVES*TT*16 queued rows, slice of stages) items, the slice count chosen on the device from the queue
 // length so that every workgroup gets an item.
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
-__global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restrict__ rimg, const char *__restrict__ frag,
+__global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
                                                             int64_t nstages, const int *__restrict__ rescan_list,
                                                             const int *__restrict__ counters, const float *__restrict__ thr,
                                                             int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
@@ -862,7 +879,6 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrows = counters[0];
     if (nrows <= 0) return;
-    const int64_t ntiles = (nrows + 15) / 16;            // 16-row tiles of the packed image
     const int64_t ntb = (nrows + BM - 1) / BM;
     int64_t ns = 1;
     while (ntb * ns < (int64_t)gridDim.x && ns * 2 <= nstages) ns <<= 1;
@@ -890,9 +906,12 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
             int64_t tt = tb * (BM / 16) + wave * TT + t;
             slot[t] = (int)(tt * 16 + (lane & 15));
             const bool valid = slot[t] < nrows;
-            mythr[t] = valid ? thr[rescan_list[slot[t]]] : INFINITY;   // padding repeats a queued row: never emitted
-            tt = tt < ntiles ? tt : ntiles - 1;
-            const char *src = rimg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
+            // this lane's queued row (padding slots repeat the last queued row and never emit) and its B fragments,
+            // gathered straight from the token image: 16-byte piece (lane>>4, row&15) of chunk (row>>4, s).  All
+            // TT*NS32 loads of a lane are independent and in flight together, once per item.
+            const int64_t tk = rescan_list[valid ? slot[t] : nrows - 1];
+            mythr[t] = valid ? thr[tk] : INFINITY;
+            const char *src = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
 #pragma unroll
             for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
         }
@@ -967,23 +986,19 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
 // SRC 1: rows of rescan_list, slots = the first VQ_RESCAN_CAP emitted candidates; longer lists go to the fp32 pass.
 #define VQ_RR_STRIDE 36      // floats per LDS tile row: 32 dims + 4 pad (conflict-free b128 reads of 16 rows)
 template <int DT, int SRC>
-__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restrict__ x, const float *__restrict__ e_exact,
-                                                            const char *__restrict__ cb, VqCbLayout L, int D, int metric,
-                                                            int nslices, int S, const float *__restrict__ rec,
-                                                            const float *__restrict__ xh2, const float *__restrict__ rho2,
-                                                            const float *__restrict__ xnorm, int64_t Np,
-                                                            int64_t *__restrict__ idx, int32_t *__restrict__ hist,
-                                                            const int *__restrict__ row_list, int *__restrict__ counters,
-                                                            const int *__restrict__ rescan_cnt,
-                                                            const int *__restrict__ cand_list, int *__restrict__ exact_list,
-                                                            u64 *__restrict__ keys) {
-    __shared__ __attribute__((aligned(16))) float tile_e[4][32 * VQ_RR_STRIDE];
-    __shared__ __attribute__((aligned(16))) float tile_x[4][8 * VQ_RR_STRIDE];
+__device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave, int64_t nwaves,
+                                            const void *__restrict__ x, const float *__restrict__ e_exact,
+                                            const char *__restrict__ cb, const VqCbLayout &L, int D, int metric,
+                                            int nslices, int S, const float *__restrict__ rec,
+                                            const float *__restrict__ xh2, const float *__restrict__ rho2,
+                                            const float *__restrict__ xnorm, int64_t Np,
+                                            int64_t *__restrict__ idx, int32_t *__restrict__ hist,
+                                            const int *__restrict__ row_list, int *__restrict__ counters,
+                                            const int *__restrict__ rescan_cnt,
+                                            const int *__restrict__ cand_list, int *__restrict__ exact_list,
+                                            u64 *__restrict__ keys) {
     constexpr int XL = DT == 0 ? 8 : 4;                       // lanes per 32-dim latent row piece (16 bytes each)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *te = tile_e[wave], *tx = tile_x[wave];
-    const int64_t gwave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
     const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
     const float *en = (const float *)(cb + L.off_en);
     const int nrows = counters[SRC == 0 ? 1 : 0];
@@ -1132,6 +1147,34 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
             if (hist) atomicAdd(&hist[best], 1);
         }
     }
+}
+
+// One launch re-ranks both queues: blocks [0, g0) take the rows with several identified candidates (multi_list, S0
+// slot lanes per row), the other blocks the rescanned rows (rescan_list, VQ_RESCAN_CAP slots).  g0 == gridDim.x or
+// g0 == 0 runs one queue only.
+template <int DT>
+__global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restrict__ x, const float *__restrict__ e_exact,
+                                                            const char *__restrict__ cb, VqCbLayout L, int D, int metric,
+                                                            int nslices, int S0, int g0, const float *__restrict__ rec,
+                                                            const float *__restrict__ xh2, const float *__restrict__ rho2,
+                                                            const float *__restrict__ xnorm, int64_t Np,
+                                                            int64_t *__restrict__ idx, int32_t *__restrict__ hist,
+                                                            const int *__restrict__ multi_list,
+                                                            const int *__restrict__ rescan_list, int *__restrict__ counters,
+                                                            const int *__restrict__ rescan_cnt,
+                                                            const int *__restrict__ cand_list, int *__restrict__ exact_list,
+                                                            u64 *__restrict__ keys) {
+    __shared__ __attribute__((aligned(16))) float tile_e[4][32 * VQ_RR_STRIDE];
+    __shared__ __attribute__((aligned(16))) float tile_x[4][8 * VQ_RR_STRIDE];
+    const int wave = threadIdx.x >> 6;
+    if ((int)blockIdx.x < g0)
+        rerank_rows<DT, 0>(tile_e[wave], tile_x[wave], (int64_t)blockIdx.x * 4 + wave, (int64_t)g0 * 4, x, e_exact, cb, L, D,
+                           metric, nslices, S0, rec, xh2, rho2, xnorm, Np, idx, hist, multi_list, counters, nullptr, nullptr,
+                           nullptr, nullptr);
+    else
+        rerank_rows<DT, 1>(tile_e[wave], tile_x[wave], (int64_t)(blockIdx.x - g0) * 4 + wave,
+                           (int64_t)(gridDim.x - g0) * 4, x, e_exact, cb, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2,
+                           rho2, xnorm, Np, idx, hist, rescan_list, counters, rescan_cnt, cand_list, exact_list, keys);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ VQ_HD int vq_coarse_supported(int D) { return D >= 1 && D <= 1024 && (D % 8) == 
 // (the proposal kernel keeps a ring of four stages up to D = 256: 4 x 33 KiB at D = 256, hence two tiles per stage there)
 #define VQ_TPS16 2
 #ifndef VQ_TPS_D32
-#define VQ_TPS_D32 4               // D <= 32 (one 32-dim k-step): tiles per stage (the aux chunk holds at most 8 tiles' biases)
+#define VQ_TPS_D32 8               // D <= 32 (one 32-dim k-step): tiles per stage (the aux chunk holds at most 8 tiles' biases)
 #endif
 VQ_HD int vq_tiles_per_stage(int nstep) { return nstep <= 2 ? VQ_TPS_D32 : (nstep < 16 ? 4 : (nstep <= 32 ? 2 : 1)); }
 
@@ -74,7 +74,7 @@ struct VqCbStats {
 
 struct VqWsLayout {
     int64_t N;
-    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_ximg, off_rimg, total;
+    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_ximg, total;
 };
 
 // counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
@@ -99,7 +99,6 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
     W.off_ximg = (W.off_xn + Np * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
     const int64_t img = vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0;
-    W.off_rimg = W.off_ximg + img;           // the rescanned rows' fragments, packed in list order
-    W.total = W.off_rimg + img + 4 * (int64_t)(vq_padded_d(D) / 32) * VQ_CHUNK_BYTES;   // whole groups of up to 4 tiles
+    W.total = W.off_ximg + img;
     return W;
 }

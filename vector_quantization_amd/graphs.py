@@ -1,0 +1,84 @@
+"""HIP-graph replay of a quantizer step for launch-bound shapes (training batches of a few thousand tokens).
+
+At the reference's per-rank training batch (12 images = 3072 tokens, K = 16384, D = 256) the step is about forty short
+kernels; issued eagerly from Python the GPU idles between them (measured: 0.18-0.35 ms of kernels inside a 0.7-0.9 ms
+step).  ``GraphedQuantizer`` captures the whole step — callbacks with their codebook update, decode, losses and, in train
+mode, the backward — once for a fixed input shape and replays it with one launch per step.
+
+What capture needs from the step, and how the quantizer provides it:
+  * no host synchronisation and no allocation outside torch's graph pool — true of every libvqhip entry point
+    (include/vqhip.h) and of the module code on the default paths;
+  * stable addresses: the reference's callbacks REBIND ``weight.data`` / re-register ``_probability`` with a fresh tensor
+    every step (callbacks/update.py:56, quantizer_callback.py:72-73); a replayed graph would keep reading the old
+    storage.  ``quantizer.inplace_updates = True`` makes the same callbacks write the same values INTO the existing
+    storage instead (value-identical; optimizer state keyed on the Parameter is unaffected either way).
+Collectives: captured as issued; RCCL ("nccl") supports capture, gloo does not — use the graph at world size 1 or on RCCL.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+
+class _Step(nn.Module):
+    """forward(x) -> (z, loss, quant): the quantizer call with a fresh memo, tensors only (what graph capture wants)."""
+
+    def __init__(self, quantizer: nn.Module) -> None:
+        super().__init__()
+        self.quantizer = quantizer
+
+    def forward(self, x: torch.Tensor):
+        z, loss, memo = self.quantizer(x, {})
+        return z, loss, memo['quant']
+
+
+class GraphedQuantizer(nn.Module):
+    """``z, loss, quant = GraphedQuantizer(q, sample_x)(x)`` — same values as ``q(x, {})`` step after step, replayed from
+    HIP graphs.  ``x`` must have the sample's shape and dtype.  Train mode (``q.training``) captures forward + backward
+    with ``torch.cuda.make_graphed_callables``; eval mode captures the forward under ``no_grad``.
+
+    Warm-up and capture run the step a few times on ``sample_x``; parameters and buffers are restored afterwards, so the
+    codebook is exactly what it was before the constructor ran.  (A VQ-KD quantizer's lazy k-means init, which needs host
+    logic, must already have happened: call the quantizer once eagerly first.)"""
+
+    def __init__(self, quantizer: nn.Module, sample_x: torch.Tensor, warmup: int = 3) -> None:
+        super().__init__()
+        if not sample_x.is_cuda:
+            raise ValueError('GraphedQuantizer needs a device tensor (no CPU path)')
+        if len(getattr(quantizer, '_forward_pre_hooks', {})) > 0:
+            raise RuntimeError('the quantizer still has a pending forward pre-hook (lazy init): run one eager step first')
+        self.quantizer = quantizer
+        quantizer.inplace_updates = True
+        self._train = quantizer.training
+        self._shape, self._dtype = tuple(sample_x.shape), sample_x.dtype
+        saved = {k: v.detach().clone() for k, v in quantizer.state_dict().items()}
+        step = _Step(quantizer)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        if self._train:
+            sample = sample_x.detach().clone().requires_grad_(True)
+            self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup)
+        else:
+            self._x = sample_x.detach().clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    step(self._x)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph), torch.no_grad():
+                self._out = step(self._x)
+        with torch.no_grad():                                    # undo the side effects of warm-up and capture
+            for k, v in quantizer.state_dict().items():
+                v.copy_(saved[k])
+
+    def forward(self, x: torch.Tensor):
+        if tuple(x.shape) != self._shape or x.dtype != self._dtype:
+            raise ValueError(f'graph captured for {self._shape} {self._dtype}, got {tuple(x.shape)} {x.dtype}')
+        if self._train:
+            return self._call(x)
+        self._x.copy_(x)
+        self._graph.replay()
+        return self._out

@@ -12,15 +12,9 @@ from torch import nn
 from .. import ops
 from ..config import Config
 from ..registries import AnchorRegistry
-from ..utils import Store, get_world_size, is_sync
+from ..utils import Store, all_gather, get_world_size, is_sync
 from .memo import Memo
 from .distances import LazyDistance, as_distance_tensor
-
-
-def all_gather(t: torch.Tensor) -> list:
-    out = [torch.empty_like(t) for _ in range(get_world_size())]
-    dist.all_gather(out, t.contiguous())
-    return out
 
 
 class BaseAnchor(nn.Module, ABC):

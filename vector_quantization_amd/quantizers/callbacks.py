@@ -16,7 +16,8 @@ import torch.distributed as dist
 from .. import ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
-from ..utils import EMA, PriorityQueue, Store, all_reduce_statistics, get_rank, get_world_size, is_sync
+from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, gather_to_rank0, get_rank,
+                     get_world_size, is_sync)
 from .anchors import NearestAnchor
 from .distances import LazyDistance
 from .memo import Memo
@@ -187,7 +188,12 @@ class UpdateMixin(BuildPreHookMixin, BaseCallback):
     def _update_embedding(self, e: torch.Tensor) -> None:
         if Store.DRY_RUN:
             assert is_sync(e)
-        self.vector_quantizer.embedding.weight.data = e      # rebinds the storage, like callbacks/update.py:56
+        weight = self.vector_quantizer.embedding.weight
+        if self.quantizer.inplace_updates:                   # same values into the existing storage (graph replay)
+            weight.data.copy_(e)
+        else:
+            weight.data = e                                  # rebinds the storage, like callbacks/update.py:56
+        self.vector_quantizer.invalidate_codebook()          # neither form bumps weight._version
 
 
 @VQITQuantizerCallbackRegistry.register_()
@@ -204,15 +210,12 @@ class NormalizeCallback(UpdateMixin, BaseCallback):
 
 
 def distributed_cat(x: torch.Tensor) -> torch.Tensor:
-    """vqkd/quantizers/callbacks.py:26-35: gather the first batch on rank 0."""
+    """The first batch of every rank, concatenated on rank 0; an empty tensor on the other ranks
+    (vqkd/quantizers/callbacks.py:26-35)."""
     if get_world_size() <= 1:
         return x
-    if get_rank() > 0:
-        dist.gather(x)
-        return x.new_empty(0)
-    gather_list = [torch.zeros_like(x) for _ in range(get_world_size())]
-    dist.gather(x, gather_list)
-    return torch.cat(gather_list)
+    parts = gather_to_rank0(x)
+    return x.new_empty(0) if parts is None else torch.cat(parts)
 
 
 @VQITQuantizerCallbackRegistry.register_()
@@ -259,7 +262,7 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
                 quant, _ = self.vector_quantizer._encode(x, Config())
                 e = self._kmeans(x, quant, False)
         if get_world_size() > 1:
-            dist.broadcast(e, 0)
+            broadcast_(e, 0)
         self._update_embedding(e)
 
     def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
@@ -306,7 +309,12 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         return self.quantizer.get_buffer('_probability')
 
     def _update_probability(self, value: torch.Tensor) -> None:
-        self.quantizer.register_buffer('_probability', value)
+        if self.quantizer.inplace_updates and '_probability' in self.quantizer._buffers \
+                and self.quantizer._buffers['_probability'].shape == value.shape \
+                and self.quantizer._buffers['_probability'].device == value.device:
+            self.quantizer._buffers['_probability'].copy_(value)
+        else:
+            self.quantizer.register_buffer('_probability', value)
 
     def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
         quant = super().after_encode(x, quant, memo)

@@ -48,6 +48,9 @@ class _CodebookShape(ABC):
 class BaseQuantizer(BuildPreHookMixin, _CodebookShape, nn.Module):
     # sub-configs turned into objects before __init__ runs, in this order (each has a `<name>_build_pre_hook`)
     _BUILT_PARTS = ('callbacks', 'losses')
+    # False = the reference's semantics: update callbacks rebind weight.data / re-register buffers with fresh tensors.
+    # True  = they write the same values into the existing storage, which a captured HIP graph requires (graphs.py).
+    inplace_updates = False
 
     def __init__(self, *args, callbacks: 'ComposedCallback', losses: ModuleDict, **kwargs) -> None:
         super().__init__(*args, **kwargs)

@@ -68,6 +68,37 @@ def get_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+# ---- collectives that also work on a backend without device-tensor support for the op (gloo: only broadcast and
+#      all_reduce take device tensors) — staged through the host there; RCCL ("nccl") takes the device tensors directly ----
+
+def _stage(t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def all_gather(t: torch.Tensor) -> list:
+    """[t_rank0, t_rank1, ...] (todd.patches.torch.all_gather; same shape on every rank)."""
+    src = t.contiguous().cpu() if _stage(t) else t.contiguous()
+    out = [torch.empty_like(src) for _ in range(get_world_size())]
+    dist.all_gather(out, src)
+    return [o.to(t.device) for o in out] if _stage(t) else out
+
+
+def gather_to_rank0(t: torch.Tensor):
+    """torch.distributed.gather to rank 0: the list of every rank's tensor on rank 0, None elsewhere."""
+    src = t.contiguous().cpu() if _stage(t) else t.contiguous()
+    if get_rank() > 0:
+        dist.gather(src)
+        return None
+    out = [torch.zeros_like(src) for _ in range(get_world_size())]
+    dist.gather(src, out)
+    return [o.to(t.device) for o in out] if _stage(t) else out
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    dist.broadcast(t, src)          # device tensors are fine on gloo and RCCL alike
+    return t
+
+
 def is_sync(t: torch.Tensor) -> bool:
     """True when ``t`` is bit-identical on every rank (todd.utils.is_sync; the reference's only
     distributed-correctness assert: callbacks/update.py:54-55, cvqvae/anchors.py:52-53,62-63)."""
