@@ -83,13 +83,17 @@ static inline int waves_grid(int64_t rows, int waves_per_block) {
 
 // ---- proposal-pass dispatch ------------------------------------------------------------------------
 static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B measurements (vqhip_set_tuning key 2)
+// key 6: 1 = the proposal kernel runs the decision stage itself (last workgroup of a token block, arrival tickets).
+// Measured neutral (tools/ab_key.py 6: -1.6 % .. +1.4 % over seven shapes; the release/acquire fences cost what the
+// launch saves), so the stand-alone launch stays the default; results are identical either way.
+static std::atomic<int> g_tune_fused_decide{0};
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
 
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
-                             hipStream_t s) {
+                             const VqDecideOut &dec, hipStream_t s) {
     constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
     auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER>;
@@ -97,7 +101,7 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
     const long slot = prof_begin(s);
-    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec);
     prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse_kernel");
     return VQHIP_OK;
@@ -135,8 +139,8 @@ static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
 }
 
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
-                         const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, int *nslices_out,
-                         hipStream_t s) {
+                         const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, const VqDecideOut &dec,
+                         int *nslices_out, hipStream_t s) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
@@ -149,7 +153,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
         int ns = pick_slices(ntb, L.nstages, (NS) <= 8 ? VQ_MIN_SLICES_FILTER : 2);                 \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, s); \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, s); \
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
@@ -187,13 +191,15 @@ static int run_exact_tiled(const void *x, int x_dtype, const float *e, const flo
 }
 
 static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
-                          int metric, const int *row_list, const int *nrows_dev, u64 *keys, hipStream_t s) {
-    // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items)
+                          int metric, const int *row_list, const int *nrows_dev, u64 *keys, int *ticket, int64_t *idx,
+                          int32_t *hist, hipStream_t s) {
+    // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items); the workgroup
+    // that finishes last turns the keys into indices (ticket: zeroed by x_prep_kernel with the other counters)
     const int grid = 256;
     if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+        exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr, ticket, idx, hist);
     else
-        exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr);
+        exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr, ticket, idx, hist);
     VQ_CHECK_LAUNCH("exact_kernel");
     return VQHIP_OK;
 }
@@ -293,24 +299,27 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
 
     int nslices = 1, rc;
     char *ximg = w + W.off_ximg;
-    const int xgrid = (int)((N + 31) / 32);
-    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
-    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L);
-    VQ_CHECK_LAUNCH("x_prep_kernel");
-    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, &nslices, s);
-    if (rc) return rc;
-    const int rgrid = (int)((N + 1023) / 1024);
     int *rescan_list = flag_list;
     int *multi_list = (int *)(w + W.off_multi), *exact_list = (int *)(w + W.off_exact);
     float *thr = (float *)(w + W.off_thr);
     int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
-    switch (nslices) {
-#define VQ_DECIDE(NSL) case NSL: refine_decide_kernel<NSL><<<rgrid, 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt); break;
-        VQ_DECIDE(1) VQ_DECIDE(2) VQ_DECIDE(4) VQ_DECIDE(8) VQ_DECIDE(16)
-#undef VQ_DECIDE
-        default: return fail(VQHIP_EINVAL, "vqhip_argmin: bad slice count");
+    int *arrive = (int *)(w + W.off_arrive);
+    const int narrive = (int)(Np / 128 + 8);
+    const int xgrid = (int)((N + 31) / 32);
+    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
+    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
+    VQ_CHECK_LAUNCH("x_prep_kernel");
+    // the proposal kernel also runs the decision stage (the workgroup that completes a token block merges its slices)
+    VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive};
+    const bool fused_decide = g_tune_fused_decide.load() != 0;
+    VqDecideOut dec_arg = dec;
+    if (!fused_decide) dec_arg.idx = nullptr;
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, s);
+    if (rc) return rc;
+    if (!fused_decide) {
+        refine_decide_kernel<<<(int)((N + 1023) / 1024), 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, dec);
+        VQ_CHECK_LAUNCH("refine_decide_kernel");
     }
-    VQ_CHECK_LAUNCH("refine_decide_kernel");
     // second-chance proposals for rows with a possibly unidentified candidate (the kernel gathers their fragments from
     // the token image itself) ...
     float *xnorm = (float *)(w + W.off_xn);
@@ -327,12 +336,12 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("rescan_kernel");
     }
     // ... then ONE launch re-ranks exactly both the rows with several identified candidates (one lane per (row, record
-    // slot)) and the rescanned rows' candidate lists; grid shares follow the typical queue lengths (4 % / 0.7 % of N)
+    // slot)) and the rescanned rows' candidate lists
     {
         const int S0 = 2 * nslices < 4 ? 4 : 2 * nslices;     // slot lanes per multi row (power of two, >= 4)
-        int64_t g0 = (N / 16 + 3) / 4, g1 = (N / 64 + 3) / 4;                 // waves ~ expected rows / rows per wave
-        g0 = g0 < 64 ? 64 : (g0 > 2048 ? 2048 : g0);
-        g1 = g1 < 64 ? 64 : (g1 > 1024 ? 1024 : g1);
+        // the re-rank is a latency chain per (row, candidate) pair: it wants one row per wave however short the queues
+        // are (64 + 64 workgroups made it 80 us instead of 14 at N = 3072, cosine, 16 slices); idle workgroups exit at once
+        const int64_t g0 = 2048, g1 = 1024;
         if (x_dtype == VQHIP_DTYPE_F32)
             refine_rerank_kernel<0><<<(int)(g0 + g1), 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S0, (int)g0, rec, xh2, rho2,
                                                                   xnorm, Np, idx, hist, multi_list, rescan_list, counters,
@@ -344,11 +353,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("refine_rerank_kernel");
     }
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
-    rc = run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, s);
-    if (rc) return rc;
-    finalize_kernel<<<16, 256, 0, s>>>(keys, exact_list, counters + 2, N, idx, nullptr, hist);
-    VQ_CHECK_LAUNCH("finalize_kernel");
-    return VQHIP_OK;
+    return run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, counters + 3, idx, hist, s);
 }
 
 int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
@@ -747,6 +752,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 3) g_tune_gather_grid = value > 0 ? value : 0;
     else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
     else if (key == 5) g_tune_filter = value != 0;
+    else if (key == 6) g_tune_fused_decide = value != 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

@@ -399,7 +399,8 @@ template <int DT>
 __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
                                                      char *__restrict__ ximg, float *__restrict__ xh2,
                                                      float *__restrict__ rho2, float *__restrict__ xn,
-                                                     int *__restrict__ counters, char *cb, VqCbLayout L) {
+                                                     int *__restrict__ counters, char *cb, VqCbLayout L,
+                                                     int *__restrict__ arrive = nullptr, int narrive = 0) {
     __shared__ float red[2][8][32];
     __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
     __shared__ float red4[4];
@@ -407,6 +408,8 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
         if (threadIdx.x < 8) counters[threadIdx.x] = 0;
         cb_finalize_stats(cb, L, red4);
     }
+    // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
+    if (arrive != nullptr && threadIdx.x == 0 && (int64_t)blockIdx.x < narrive) arrive[blockIdx.x] = 0;
     const int64_t blk = blockIdx.x;
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t t = blk * 32 + r;
@@ -469,6 +472,17 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
 __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2);
 
+// where the decision stage writes (one struct: the proposal kernel carries it as a single argument)
+struct VqDecideOut {
+    int64_t *idx; int32_t *hist;
+    int *rescan_list, *multi_list, *exact_list, *counters;
+    u64 *keys; float *thr_out; int *rescan_cnt;
+    int *arrive;            // one arrival counter per token block of the proposal kernel (zeroed by x_prep_kernel)
+};
+__device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
+                                            const float *rec, const float *xh2, const float *rho2, int64_t Np,
+                                            const VqDecideOut &o, int *wcount, int *wbase);
+
 __device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
     if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }
     else if (v > t.v2) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = v; t.c2 = c; }
@@ -507,7 +521,7 @@ template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = fal
 __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
-    const float *__restrict__ rho2, int Dp, int metric) {
+    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
     constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
@@ -706,6 +720,39 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
             rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
         }
     }
+
+    // ---- decision stage, by the workgroup that completes a token block (dec.idx == nullptr: left to refine_decide_kernel)
+    // Arrival counter per token block (MI355X guide, Guideline 16): every wave drains its record stores, the workgroup
+    // meets, one lane releases at agent scope and takes a ticket; the workgroup that draws the last ticket of the block
+    // (nslices of them) acquires and merges the records of all slices — one launch less on the critical path.
+    if (dec.idx != nullptr) {
+        int *flags = (int *)lds;                         // the stage ring is free now (first barrier below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int last = 1;
+            if (nslices > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = (atomicAdd(&dec.arrive[tb], 1) == nslices - 1) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            flags[0] = last;
+        }
+        __syncthreads();
+        const bool last = flags[0] != 0;
+        __syncthreads();                                 // everybody has read the flag before the LDS words are reused
+        if (last) {
+            int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
+            int64_t n = tb * BM + threadIdx.x;           // BM <= WAVES*64 threads: one token per thread
+            const bool oob = (int)threadIdx.x >= BM || n >= N;
+            if (n >= N) n = N - 1;
+            decide_rows(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,67 +838,67 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
 //   an unidentified candidate may exist   -> rescan_list  (second proposal pass that emits every score >= thr)
 //   no usable bound (non-finite data)     -> exact_list   (whole-codebook fp32 pass)
 // counters: [0] rescan rows, [1] multi rows, [2] exact rows
-template <int NSL>
-__global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
-                                     const float *xh2, const float *rho2, int64_t Np, int64_t *idx, int32_t *hist,
-                                     int *rescan_list, int *multi_list, int *exact_list, int *counters, u64 *keys,
-                                     float *thr_out, int *rescan_cnt) {
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool oob = n >= N;
-    if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
-    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
-    const float m = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
+// `rec` is read with agent-scope loads (they bypass this CU's L1): inside the proposal kernel the records of the other
+// slices were written by other workgroups moments ago.  wcount / wbase: 3 x 16 ints of LDS each.
+__device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
+                                            const float *rec, const float *xh2, const float *rho2, int64_t Np,
+                                            const VqDecideOut &o, int *wcount, int *wbase) {
+    const float m = row_margin(st, Dp, metric, xh2[n], rho2[n]);
     bool invalid = !(m > 0.0f);
-    // NSL = compile-time slice count: all record loads are issued together
-    float v1[NSL], v2[NSL], v3[NSL], c1[NSL];
-    (void)nslices;
-#pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-        const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
-        v1[s] = rp[0]; c1[s] = rp[Np]; v2[s] = rp[2 * Np]; v3[s] = rp[4 * Np];
-    }
     float gbest = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
+    for (int s = 0; s < nslices; ++s)
+        gbest = fmaxf(gbest, __hip_atomic_load(rec + (int64_t)s * VQ_REC_FIELDS * Np + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
     const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
     int nc = 0;
     bool unidentified = false;
     uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-        if (v3[s] >= thr) unidentified = true;
-        if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
-        if (v2[s] >= thr) ++nc;
+    for (int s = 0; s < nslices; ++s) {
+        const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+        const float v1 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v2 = __hip_atomic_load(rp + 2 * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v3 = __hip_atomic_load(rp + 4 * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v3 >= thr) unidentified = true;
+        if (v1 >= thr) { ++nc; best = __float_as_uint(__hip_atomic_load(rp + Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+        if (v2 >= thr) ++nc;
     }
-    // block-aggregated list appends: one atomic per 1024-thread block and list (the three counters are hot words:
+    // block-aggregated list appends: one atomic per workgroup and list (the three counters are hot words:
     // ~8-11 ns per same-address atomic, so per-wave appends from 1024 waves cost ~15 us)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool to_exact = !oob && (invalid || nc == 0);
     const bool to_rescan = !oob && !to_exact && unidentified;
     const bool to_multi = !oob && !to_exact && !to_rescan && nc > 1;
-    __shared__ int wcount[3][16];
-    __shared__ int wbase[3][16];
     const u64 mk_e = __ballot(to_exact), mk_r = __ballot(to_rescan), mk_m = __ballot(to_multi);
-    if (lane == 0) { wcount[0][wave] = __popcll(mk_r); wcount[1][wave] = __popcll(mk_m); wcount[2][wave] = __popcll(mk_e); }
+    if (lane == 0) { wcount[0 * 16 + wave] = __popcll(mk_r); wcount[1 * 16 + wave] = __popcll(mk_m); wcount[2 * 16 + wave] = __popcll(mk_e); }
     __syncthreads();
     if (threadIdx.x < 3) {
         int tot = 0;
         const int nw = blockDim.x >> 6;
-        for (int i = 0; i < nw; ++i) { wbase[threadIdx.x][i] = tot; tot += wcount[threadIdx.x][i]; }
-        const int base = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
-        for (int i = 0; i < nw; ++i) wbase[threadIdx.x][i] += base;
+        for (int i = 0; i < nw; ++i) { wbase[threadIdx.x * 16 + i] = tot; tot += wcount[threadIdx.x * 16 + i]; }
+        const int base = tot ? atomicAdd(&o.counters[threadIdx.x], tot) : 0;
+        for (int i = 0; i < nw; ++i) wbase[threadIdx.x * 16 + i] += base;
     }
     __syncthreads();
     const u64 below = (1ull << lane) - 1ull;
-    if (to_exact) { exact_list[wbase[2][wave] + __popcll(mk_e & below)] = (int)n; keys[n] = ~0ull; }
-    if (to_rescan) { int pos = wbase[0][wave] + __popcll(mk_r & below); rescan_list[pos] = (int)n; rescan_cnt[pos] = 0; thr_out[n] = thr; }
-    if (to_multi) multi_list[wbase[1][wave] + __popcll(mk_m & below)] = (int)n;
+    if (to_exact) { o.exact_list[wbase[2 * 16 + wave] + __popcll(mk_e & below)] = (int)n; o.keys[n] = ~0ull; }
+    if (to_rescan) { int pos = wbase[0 * 16 + wave] + __popcll(mk_r & below); o.rescan_list[pos] = (int)n; o.rescan_cnt[pos] = 0; o.thr_out[n] = thr; }
+    if (to_multi) o.multi_list[wbase[1 * 16 + wave] + __popcll(mk_m & below)] = (int)n;
     if (oob) return;
     if (!to_exact && !to_rescan && !to_multi) {
-        idx[n] = (int64_t)best;
-        if (hist) atomicAdd(&hist[best], 1);
+        o.idx[n] = (int64_t)best;
+        if (o.hist) atomicAdd(&o.hist[best], 1);
     }
+}
+
+// stand-alone form (one thread per token, 1024-thread workgroups): used when the proposal kernel does not decide itself
+__global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
+                                     const float *xh2, const float *rho2, int64_t Np, VqDecideOut o) {
+    __shared__ int wcount[3 * 16];
+    __shared__ int wbase[3 * 16];
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool oob = n >= N;
+    if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
+    decide_rows(n, oob, (const VqCbStats *)(cb + L.off_stats), L.Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase);
 }
 
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
@@ -1188,9 +1235,13 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                                                     const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
                                                     int metric, const int *__restrict__ row_list,
                                                     const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
-                                                    float *__restrict__ dout) {
+                                                    float *__restrict__ dout, int *__restrict__ ticket = nullptr,
+                                                    int64_t *__restrict__ fin_idx = nullptr,
+                                                    int32_t *__restrict__ fin_hist = nullptr) {
     // CT = code tiles (32 codes) per wave: 4 for whole-batch passes, 1 when only a few flagged rows need the
     // whole codebook (more, smaller work items)
+    // ticket != nullptr (row-list form): the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows
+    // itself, so the last-resort path is ONE launch; with an empty list every workgroup returns at once.
     constexpr int DB = 256;                     // dims per register block
     constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1310,6 +1361,29 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
             u64 o = __shfl_xor(best, 32, 64);
             best = o < best ? o : best;
             if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+    if (MODE == 0 && ticket != nullptr && nrows > 0) {
+        // arrival counter (MI355X guide, Guideline 16): the key atomics execute at the memory side; every wave drains
+        // its own, the workgroup meets, one lane publishes; whoever draws the last ticket reads the keys with loads that
+        // bypass its L1 (agent-scope relaxed atomic loads)
+        __shared__ int is_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (is_last) {
+            for (int64_t i = threadIdx.x; i < nrows; i += blockDim.x) {
+                const int64_t r = (int64_t)row_list[i];
+                const u64 key = __hip_atomic_load(&keys[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
+                fin_idx[r] = (int64_t)k;
+                if (fin_hist) atomicAdd(&fin_hist[k], 1);
+            }
         }
     }
 }

@@ -74,7 +74,7 @@ struct VqCbStats {
 
 struct VqWsLayout {
     int64_t N;
-    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_ximg, total;
+    int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_arrive, off_ximg, total;
 };
 
 // counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
@@ -97,7 +97,8 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_keys = (W.off_rlist + Np * 4 * 32 + 255) / 256 * 256;
     W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
     W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
-    W.off_ximg = (W.off_xn + Np * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
+    W.off_arrive = W.off_xn + Np * 4;          // arrival counters of the proposal kernel's token blocks (>= 128 tokens each)
+    W.off_ximg = (W.off_arrive + (Np / 128 + 8) * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
     const int64_t img = vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0;
     W.total = W.off_ximg + img;
     return W;
