@@ -72,11 +72,14 @@ class LazyDistance(torch.Tensor):
                            'retains_grad', '_base', 'is_nested', 'is_mkldnn', 'is_xpu', 'is_mps', 'is_cpu'})
 
     @staticmethod
-    def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor):
+    def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor, xq: Optional[torch.Tensor] = None):
         return torch.Tensor._make_wrapper_subclass(cls, (x.shape[0], e.shape[0]), dtype=torch.float32, device=x.device)
 
-    def __init__(self, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor) -> None:
-        self._distance, self._x, self._e = distance, x, e
+    def __init__(self, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor,
+                 xq: Optional[torch.Tensor] = None) -> None:
+        """``xq``: the latents in the form the exact definition consumes (normalised for cosine), when the encode that
+        produced this handle has already computed them."""
+        self._distance, self._x, self._e, self._xq = distance, x, e, xq
         self._value: Optional[torch.Tensor] = None
 
     @property
@@ -94,7 +97,10 @@ class LazyDistance(torch.Tensor):
 
     def fused_argmin(self, dim: int) -> torch.Tensor:
         if dim == 0:        # NearestAnchor: d.argmin(0) — nearest latent per code
-            xq, eq = self._distance.exact_operands(self._x, self._e)
+            if self._xq is not None:
+                xq, eq = self._xq, self._distance.exact_codebook(self._e)
+            else:
+                xq, eq = self._distance.exact_operands(self._x, self._e)
             return ops.col_argmin(xq, eq, self.metric)
         return self._distance.argmin(self._x, self._e)
 
@@ -148,13 +154,20 @@ class BaseDistance(nn.Module, ABC):
         """Operands of the fp32 definition (normalised for cosine)."""
         return x.detach(), e.detach()
 
+    def exact_codebook(self, e: torch.Tensor) -> torch.Tensor:
+        """The codebook operand of the fp32 definition alone."""
+        return e.detach()
+
     def prepare(self, e: torch.Tensor) -> ops.PreparedCodebook:
         return ops.prepare_codebook(e, self.metric)
 
     def argmin(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
-               prepared: Optional[ops.PreparedCodebook] = None) -> torch.Tensor:
-        """torch.argmin(self(x, e), -1) without materialising the matrix."""
+               prepared: Optional[ops.PreparedCodebook] = None, stash: Optional[dict] = None) -> torch.Tensor:
+        """torch.argmin(self(x, e), -1) without materialising the matrix.  ``stash['xq']`` receives the latents as the
+        exact definition consumes them, for consumers of the same batch (NearestAnchor's column argmin)."""
         cb = prepared if prepared is not None else self.prepare(e)
+        if stash is not None:
+            stash['xq'] = x.detach()
         return ops.argmin(x.detach(), cb, hist=hist)
 
 
@@ -174,6 +187,9 @@ class CosineDistance(BaseDistance):
     def exact_operands(self, x: torch.Tensor, e: torch.Tensor):
         return ops.normalize_rows(x.detach()), ops.normalize_rows(e.detach())
 
+    def exact_codebook(self, e: torch.Tensor) -> torch.Tensor:
+        return ops.normalize_rows(e.detach())
+
     @staticmethod
     def cosine_similarity(x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         """normalize(x) @ normalize(e).T, returned as 1 - distance (the distance kernel's own value)."""
@@ -182,6 +198,9 @@ class CosineDistance(BaseDistance):
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         return _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
 
-    def argmin(self, x, e, hist=None, prepared=None):
+    def argmin(self, x, e, hist=None, prepared=None, stash=None):
         cb = prepared if prepared is not None else self.prepare(e)
-        return ops.argmin(ops.normalize_rows(x.detach()), cb, hist=hist)   # the image holds normalize(e)
+        xn = ops.normalize_rows(x.detach())
+        if stash is not None:
+            stash['xq'] = xn
+        return ops.argmin(xn, cb, hist=hist)   # the image holds normalize(e)

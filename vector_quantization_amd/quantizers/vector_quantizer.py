@@ -116,15 +116,16 @@ class VectorQuantizer(BaseQuantizer):
         hist = None
         if self.training and len(self._callbacks.callbacks) > 0:
             hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
-        quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w))
+        stash = {}
+        quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w), stash=stash)
         # memo['distance'] stays symbolic.  With autograd on, its operands keep their graph (EntropyLoss differentiates
         # through the matrix: losses.py:130-153); the codebook operand is an alias of the CURRENT weight storage, so the
         # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
         if torch.is_grad_enabled() and (x.requires_grad or self._embedding.weight.requires_grad):
             weight = self._embedding.weight
-            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight))
+            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight), xq=stash.get('xq'))
         else:
-            memo['distance'] = LazyDistance(self._distance, x2, w)
+            memo['distance'] = LazyDistance(self._distance, x2, w, xq=stash.get('xq'))
         if hist is not None:
             memo['hist'] = hist
         return quant.reshape(shape), memo
@@ -158,7 +159,7 @@ class VectorQuantizer(BaseQuantizer):
         losses = {}
         for name, loss in self._losses.items():
             if isinstance(loss, VQGANLoss):
-                losses[name] = m_cb + loss.beta * m_cm
+                losses[name] = torch.add(m_cb, m_cm, alpha=loss.beta)        # codebook + beta * commitment, one kernel
             elif isinstance(loss, CodebookLoss):
                 losses[name] = m_cb
             else:
@@ -166,7 +167,11 @@ class VectorQuantizer(BaseQuantizer):
         loss_memo = get_memo(memo, 'loss')
         loss_memo.update(losses)
         memo['loss'] = loss_memo
-        loss = sum(losses.values(), x.new_zeros([], dtype=torch.float32))
+        values = list(losses.values())
+        if len(values) == 1:                  # 0 + v == v: skip the zero-fill and the add of the general form below
+            loss = values[0]
+        else:
+            loss = sum(values, x.new_zeros([], dtype=torch.float32))
         return z_ste, loss, memo
 
 
