@@ -38,4 +38,8 @@ one(65536, 16384, 256, 'L2', torch.bfloat16)
 one(524288, 16384, 256, 'L2', torch.bfloat16, rounds=3, reps=5)
 one(100352, 8192, 32, 'Cosine')
 one(12544, 8192, 32, 'Cosine')
+one(65536, 8192, 32, "Cosine")
+one(262144, 8192, 32, "Cosine")
+one(524288, 16384, 8, "L2", rounds=3, reps=5)
+one(3072, 8192, 32, "Cosine")
 one(1024, 1024, 256, 'L2')

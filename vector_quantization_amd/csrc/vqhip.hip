@@ -90,18 +90,19 @@ static std::atomic<int> g_tune_fused_decide{0};
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
-                             const VqDecideOut &dec, hipStream_t s) {
+                             const VqDecideOut &dec, int streamk_grid, hipStream_t s) {
     constexpr int BM = WAVES * TT * 16;
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, STREAMK>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     int64_t ntb = (N + BM - 1) / BM;
+    const int grid = STREAMK ? streamk_grid : (int)(ntb * nslices);
     const long slot = prof_begin(s);
-    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec);
+    kern<<<grid, WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec);
     prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse_kernel");
     return VQHIP_OK;
@@ -120,6 +121,36 @@ static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages
 }
 
 // filtered (small-D) proposal kernels: long code streams make the skip test effective, so one slice is allowed
+// Stream-K split of the (token block x stage) space over `grid` workgroups (coarse_kernel, streamk form): the largest
+// number of workgroups that touch one token block = record slots the decision stage must read.
+static int streamk_pieces(int64_t ntb, int64_t nstages, int64_t grid) {
+    const int64_t U = ntb * nstages;
+    int64_t worst = 1, g = 0;
+    for (int64_t tb = 0; tb < ntb; ++tb) {
+        while (g + 1 < grid && ((g + 1) * U) / grid <= tb * nstages) ++g;            // first workgroup of the block
+        int64_t gl = g;
+        while (gl + 1 < grid && ((gl + 1) * U) / grid <= tb * nstages + nstages - 1) ++gl;   // last one
+        worst = (gl - g + 1) > worst ? (gl - g + 1) : worst;
+    }
+    return (int)worst;
+}
+// grid for the stream-K form: two workgroups per CU (measured at D = 32, K = 8192: 1.14 ns/token with one workgroup per
+// CU, 0.87 with two, profiles/r02_balance_d32.txt), fewer when a token block would be cut into more than 16 pieces
+static int streamk_grid(int64_t ntb, int64_t nstages, int *pieces_out) {
+    int64_t grid = 512;
+    const int64_t U = ntb * nstages;
+    if (grid > U) grid = U;
+    int pieces = streamk_pieces(ntb, nstages, grid);
+    while (pieces > VQ_MAX_SLICES && grid > 1) { grid = grid * 3 / 4; pieces = streamk_pieces(ntb, nstages, grid); }
+    *pieces_out = pieces;
+    return (int)grid;
+}
+// key 7: 1 = stream-K form on the D <= 32 kernels.  Built to cure the 392-workgroups-on-256-CUs tail of BASELINE
+// configs[2]; measured slower there (-4.6 %) and at small N (-14 %), +2.5 % only at N = 65 536
+// (profiles/r02_ab_streamk.txt): every segment pays a prologue, a ring refill and — the larger part — a cold skip
+// threshold, and a block cut in three needs three records per token.  Off; results are identical either way.
+static std::atomic<int> g_tune_streamk{0};
+
 #ifndef VQ_MIN_SLICES_FILTER
 #define VQ_MIN_SLICES_FILTER 1
 #endif
@@ -140,7 +171,7 @@ static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
 
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
                          const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, const VqDecideOut &dec,
-                         int *nslices_out, hipStream_t s) {
+                         int *nslices_out, int *fused_decide_out, hipStream_t s) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
@@ -153,11 +184,24 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
         int ns = pick_slices(ntb, L.nstages, (NS) <= 8 ? VQ_MIN_SLICES_FILTER : 2);                 \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, s); \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, 0, s); \
+    }
+    // stream-K form (D <= 32): equal shares of the (token block x stage) space, two workgroups per CU
+#define VQ_CFG_SK(NS, TT, W, ...)                                                                   \
+    {                                                                                               \
+        int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
+        int pieces = 1;                                                                             \
+        const int grid = streamk_grid(ntb, L.nstages, &pieces);                                     \
+        *nslices_out = pieces;                                                                      \
+        VqDecideOut nodec = dec; nodec.idx = nullptr;                                               \
+        *fused_decide_out = 0;                                                                      \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, pieces, rec, Np, cbst, xh2, rho2, L.Dp, metric, nodec, grid, s); \
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
         case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4) }
+                // (N >= 262 144: at least 1024 workgroups of 64 tokens per wave — balance no longer matters and that form is the faster one)
+                if (g_tune_streamk.load() && small32) VQ_CFG_SK(2, 2, 8, VQ_TPS_D32, 4, true, true)
                 if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4, true)
         case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
@@ -170,6 +214,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         default: break;
     }
 #undef VQ_CFG
+#undef VQ_CFG_SK
     return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
 }
 
@@ -314,9 +359,10 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     const bool fused_decide = g_tune_fused_decide.load() != 0;
     VqDecideOut dec_arg = dec;
     if (!fused_decide) dec_arg.idx = nullptr;
-    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, s);
+    int fused_done = fused_decide ? 1 : 0;       // the stream-K form always leaves the decision stage to its own launch
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s);
     if (rc) return rc;
-    if (!fused_decide) {
+    if (!fused_done) {
         refine_decide_kernel<<<(int)((N + 1023) / 1024), 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, dec);
         VQ_CHECK_LAUNCH("refine_decide_kernel");
     }
@@ -338,7 +384,8 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     // ... then ONE launch re-ranks exactly both the rows with several identified candidates (one lane per (row, record
     // slot)) and the rescanned rows' candidate lists
     {
-        const int S0 = 2 * nslices < 4 ? 4 : 2 * nslices;     // slot lanes per multi row (power of two, >= 4)
+        int S0 = 4;                                           // slot lanes per multi row: power of two >= max(4, 2*nslices)
+        while (S0 < 2 * nslices) S0 <<= 1;
         // the re-rank is a latency chain per (row, candidate) pair: it wants one row per wave however short the queues
         // are (64 + 64 workgroups made it 80 us instead of 14 at N = 3072, cosine, 16 slices); idle workgroups exit at once
         const int64_t g0 = 2048, g1 = 1024;
@@ -753,6 +800,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
     else if (key == 5) g_tune_filter = value != 0;
     else if (key == 6) g_tune_fused_decide = value != 0;
+    else if (key == 7) g_tune_streamk = value != 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

@@ -517,8 +517,8 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // s < best_so_far - m <= final best - m = the decision threshold, so it is strictly outside the candidate set the
 // margin defines and needs neither identification nor a bound in the record; every score within the margin of the
 // running best still goes through the exact per-element update.  Rows without a usable margin never skip.
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false>
-__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false>
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2 && TT <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
     const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec) {
@@ -531,10 +531,29 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
     constexpr int BM = WAVES * TT * 16;
     constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sl = blockIdx.x % nslices;
-    const int64_t tb = blockIdx.x / nslices;
-    const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
     const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image
+    // Work assignment.  STREAMK false: workgroup = (token block tb, codebook slice sl of nslices), one segment.
+    // STREAMK true (small D): the (token block x stage) space, block-major, is cut into gridDim.x equal ranges — every
+    // CU gets the same share whatever the number of token blocks — and a workgroup walks its range as one or two
+    // segments (tail of one block, head of the next).  A block is then covered by at most `nslices` consecutive
+    // workgroups; the piece index within the block is the record slot, unused slots are filled with "nothing here".
+    const int64_t U = ((N + BM - 1) / BM) * nstages;
+    int64_t u_next = STREAMK ? ((int64_t)blockIdx.x * U) / gridDim.x : 0;
+    const int64_t u_end = STREAMK ? ((int64_t)(blockIdx.x + 1) * U) / gridDim.x : 1;
+  for (bool once = true; STREAMK ? (u_next < u_end) : once; once = false) {
+    int sl;
+    int64_t tb, st0, st1;
+    if constexpr (!STREAMK) {
+        sl = blockIdx.x % nslices; tb = blockIdx.x / nslices;
+        st0 = (nstages * sl) / nslices; st1 = (nstages * (sl + 1)) / nslices;
+    } else {
+        tb = u_next / nstages; st0 = u_next % nstages;
+        st1 = (st0 + (u_end - u_next) < nstages) ? st0 + (u_end - u_next) : nstages;
+        int64_t g = blockIdx.x;                          // first workgroup of this block: largest g with start(g) <= tb*nstages
+        while (g > 0 && (g * U) / gridDim.x > tb * nstages) --g;
+        sl = (int)(blockIdx.x - g);
+        u_next += st1 - st0;
+    }
 
     // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
     half8 xf[TT][NS32];
@@ -721,6 +740,26 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
         }
     }
 
+    if constexpr (STREAMK) {
+        if (sl == 0) {        // this workgroup opens the block: mark the record slots no piece will write
+            int64_t gl = blockIdx.x;                     // last workgroup of the block: largest g with start(g) <= last unit
+            while (gl + 1 < (int64_t)gridDim.x && ((gl + 1) * U) / gridDim.x <= tb * nstages + nstages - 1) ++gl;
+            const int pieces = (int)(gl - blockIdx.x) + 1;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+                if (lane < 16 && tokn < N)
+                    for (int p = pieces; p < nslices; ++p) {
+                        float *rp = rec + (int64_t)p * VQ_REC_FIELDS * Np + tokn;
+                        rp[0] = -INFINITY; rp[Np] = __uint_as_float(0xFFFFFFFFu); rp[2 * Np] = -INFINITY;
+                        rp[3 * Np] = __uint_as_float(0xFFFFFFFFu); rp[4 * Np] = -INFINITY;
+                    }
+            }
+        }
+        __syncthreads();      // the next segment refills the stage ring
+        continue;
+    }
+
     // ---- decision stage, by the workgroup that completes a token block (dec.idx == nullptr: left to refine_decide_kernel)
     // Arrival counter per token block (MI355X guide, Guideline 16): every wave drains its record stores, the workgroup
     // meets, one lane releases at agent scope and takes a ticket; the workgroup that draws the last ticket of the block
@@ -753,6 +792,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
             decide_rows(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
         }
     }
+  }   // segments
 }
 
 // ------------------------------------------------------------------------------------------------
