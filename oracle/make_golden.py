@@ -422,6 +422,49 @@ def entropy_case():
                                                         'vq/algorithms/vq/distances.py:28-46'])))
 
 
+def connector_case():
+    """f3: post_encode ConvConnector -> BaseModel.quantize (the two einops rearrangements around the quantizer call,
+    models/base.py:116-128) -> pre_decode ConvConnector, and BaseModel.encode_to_quant (:135-146), executed from the
+    reference's own files.  BaseModel itself is abstract and drags encoders in: its two methods are called on a
+    minimal holder object (they touch self._quantizer and self.encode only)."""
+    ref = ref_import.load()
+    B, Cin, D, H, W, K = 2, 16, 32, 8, 8, 256
+    gen = synth.rng(61)
+    x_in = gen.standard_normal((B, Cin, H, W), dtype=np.float32)
+    wcb = gen.standard_normal((K, D), dtype=np.float32)
+    torch.manual_seed(61)
+    post = ref.VQITConnectorRegistry.build(dict(type='ConvConnector', in_channels=Cin, out_channels=D))      # configs/vqgan/model.py:18
+    pre = ref.VQITConnectorRegistry.build(dict(type='ConvConnector', in_channels=D, out_channels=Cin))       # :24
+    q = ref_quantizer(K, D, 'L2', 'vqgan', (), wcb)
+
+    class Holder:
+        _quantizer = q
+
+        def encode(self, image, memo):
+            return image, memo
+
+    with torch.no_grad():
+        x_map, _ = post(torch.from_numpy(x_in), {})
+        z_map, q_loss, memo = ref.BaseModel.quantize(Holder(), x_map, {})
+        out, _ = pre(z_map, {})
+        quant_map, memo2 = ref.BaseModel.encode_to_quant(Holder(), x_map, {})
+    assert same(quant_map.reshape(-1), memo['quantizer']['quant']) and tuple(memo['quantizer']['x_shape']) == (B, D, H, W)
+    # restatement: the same two rearrangements around torch_ref.forward
+    r = tr.forward(x_map.permute(0, 2, 3, 1).reshape(-1, D), torch.from_numpy(wcb), 'L2', 'vqgan')
+    assert same(r['quant'], memo['quantizer']['quant']) and same(r['loss'], q_loss)
+    assert same(r['z_ste'].reshape(B, H, W, D).permute(0, 3, 1, 2).contiguous(), z_map)
+    np.savez_compressed(
+        os.path.join(OUT, 'connector_path.npz'), x_in=x_in, w_sha=synth.sha(wcb),
+        post_weight=post._conv.weight.detach().numpy(), post_bias=post._conv.bias.detach().numpy(),
+        pre_weight=pre._conv.weight.detach().numpy(), pre_bias=pre._conv.bias.detach().numpy(),
+        x_map=x_map.numpy(), z_map=z_map.numpy(), loss=np.float32(q_loss.item()),
+        quant=quant_map.numpy().astype(np.int32), out=out.numpy(),
+        spec=json.dumps(dict(B=B, Cin=Cin, D=D, H=H, W=W, K=K, seed=61, source='reference-import',
+                             reference=['vq/tasks/image_tokenization/models/connectors/conv.py:15-56',
+                                        'vq/tasks/image_tokenization/models/connectors/base.py:12-39',
+                                        'vq/tasks/image_tokenization/models/base.py:116-146'])))
+
+
 def main(only=(), out_dir=None, quiet=False):
     global OUT
     if not ref_import.available():
@@ -448,6 +491,8 @@ def main(only=(), out_dir=None, quiet=False):
         anchor_cases()
     if not only or 'entropy' in only:
         entropy_case()
+    if not only or 'connector' in only:
+        connector_case()
     print_('fixtures written to', OUT, '— every value produced by the reference files:')
     for n, f in ref_import.load().files.items():
         print_('   ', f)

@@ -340,6 +340,8 @@ _PACKAGES = {
     'vq.tasks': [('star', 'registries')],                                        # vq/tasks/__init__.py
     'vq.tasks.image_tokenization': [('star', 'registries')],                     # .../image_tokenization/__init__.py:2
     'vq.tasks.image_tokenization.models': [('pkg', 'quantizers'), ('star', 'registries')],   # models/__init__.py:1,3
+    'vq.tasks.image_tokenization.models.connectors': [                           # connectors/__init__.py:1-3
+        ('star', 'base'), ('star', 'composed'), ('star', 'conv')],
     'vq.tasks.image_tokenization.models.quantizers': [                           # quantizers/__init__.py:1-4
         ('pkg', 'callbacks'), ('pkg', 'utils'), ('star', 'base'), ('star', 'losses'), ('star', 'registries')],
     'vq.tasks.image_tokenization.models.quantizers.callbacks': [                 # callbacks/__init__.py:1-3
@@ -357,6 +359,21 @@ _PACKAGES = {
 }
 
 
+# Packages the model-level file (image_tokenization/models/base.py) imports for type annotations only (datasets,
+# encoders, runners): inert placeholder modules, nothing of theirs is ever executed.
+_INERT = ('vq.datasets', 'vq.models.autoencoders', 'vq.runners')
+
+
+class _InertModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        ph = type(name, (), {'__doc__': f'inert placeholder for {self.__name__}.{name}',
+                             '__class_getitem__': classmethod(lambda cls, item: cls)})      # Generic[...] in annotations
+        setattr(self, name, ph)
+        return ph
+
+
 class _RefFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     """Packages listed in _PACKAGES are created bare (their __init__.py is NOT executed) and then re-export what
     _PACKAGES says; every other vq.* name is the reference's own .py file executed unchanged."""
@@ -365,6 +382,8 @@ class _RefFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         if fullname != 'vq' and not fullname.startswith('vq.'):
             return None
         rel = os.path.join(REFERENCE_ROOT, *fullname.split('.'))
+        if fullname in _INERT:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
         if fullname in _PACKAGES:
             spec = importlib.machinery.ModuleSpec(fullname, self, is_package=True)
             spec.submodule_search_locations = [rel]
@@ -374,9 +393,15 @@ class _RefFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         raise ReferenceUnavailable(f'{fullname} is outside the quantizer path loaded by oracle/ref_import.py')
 
     def create_module(self, spec):
+        if spec.name in _INERT:
+            m = _InertModule(spec.name)
+            m.__path__ = []
+            return m
         return None
 
     def exec_module(self, module):
+        if module.__name__ in _INERT:
+            return
         for kind, name in _PACKAGES[module.__name__]:
             sub = importlib.import_module(f'{module.__name__}.{name}')
             if kind == 'star':
@@ -400,7 +425,8 @@ def load() -> types.SimpleNamespace:
                  'vq.tasks.image_tokenization.models.quantizers',
                  'vq.tasks.image_tokenization.models.quantizers.utils',
                  'vq.tasks.image_tokenization.models.quantizers.callbacks',
-                 'vq.tasks.image_tokenization.models', 'vq.algorithms.vq.callbacks'):
+                 'vq.tasks.image_tokenization.models', 'vq.algorithms.vq.callbacks',
+                 'vq.tasks.image_tokenization.models.connectors', 'vq.tasks.image_tokenization.models.base'):
         mods[name] = importlib.import_module(name)
     ns = types.SimpleNamespace(todd=todd, Config=todd.Config, modules=mods, files={})
     for m in mods.values():

@@ -162,3 +162,46 @@ def test_bulk_tokenization_loop_single_rank(tmp_path):
     tok = T.load_tokens(tmp_path / 'tokens' / '1_0.pth')
     assert tok['tokens'].shape == (8, 16, 16) and tok['tokens'].dtype == torch.int64 and len(tok['id_']) == 8
     assert 0.0 < summary['codebook_usage'] <= 1.0 and summary['codebook_ppl'] > 0.0
+
+
+@pytest.mark.gpu
+def test_connector_quantize_path_matches_reference():
+    """f3 against the reference's own files (fixture: its ConvConnector, BaseModel.quantize / encode_to_quant and
+    VQGANQuantizer): the product's connectors reproduce the 1x1 convs to GEMM rounding, and — fed the reference's latent
+    map, NCHW or channels-last — `tokenization.quantize` returns the reference's tokens and straight-through map exactly
+    and its loss to 1e-5."""
+    import json
+    from vector_quantization_amd import Config, build_quantizer, connectors as C, tokenization as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'connector_path.npz'))
+    spec = json.loads(str(g['spec']))
+    B, Cin, D, H, W, K = (spec[k] for k in ('B', 'Cin', 'D', 'H', 'W', 'K'))
+    gen = synth.rng(spec['seed'])
+    x_in = gen.standard_normal((B, Cin, H, W), dtype=np.float32)
+    wcb = gen.standard_normal((K, D), dtype=np.float32)
+    np.testing.assert_array_equal(x_in, g['x_in'])
+    assert synth.sha(wcb) == str(g['w_sha'])
+    post = C.VQITConnectorRegistry.build(dict(type='ConvConnector', in_channels=Cin, out_channels=D)).cuda()
+    pre = C.VQITConnectorRegistry.build(dict(type='ConvConnector', in_channels=D, out_channels=Cin)).cuda()
+    post.load_state_dict({'_conv.weight': torch.from_numpy(g['post_weight']), '_conv.bias': torch.from_numpy(g['post_bias'])})
+    pre.load_state_dict({'_conv.weight': torch.from_numpy(g['pre_weight']), '_conv.bias': torch.from_numpy(g['pre_bias'])})
+    q = build_quantizer(dict(type='VQGANQuantizer',
+                             embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=D),
+                             distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+    q.init_weights(Config(type='vqgan'))
+    q = q.cuda().eval()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(wcb))
+        x_map, _ = post(torch.from_numpy(x_in).cuda(), {})
+        assert T.is_token_major(x_map)                                             # the connector hands over the token matrix
+        np.testing.assert_allclose(x_map.cpu().numpy(), g['x_map'], rtol=1e-5, atol=1e-5)
+        ref_map = torch.from_numpy(g['x_map']).cuda()
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            z_map, loss, memo = T.quantize(q, ref_map.contiguous(memory_format=fmt), {})
+            np.testing.assert_array_equal(memo['quantizer']['quant'].reshape(B, H, W).cpu().numpy(), g['quant'].astype(np.int64))
+            np.testing.assert_array_equal(z_map.cpu().numpy(), g['z_map'])          # x + (z - x): bit-exact
+            assert abs(loss.item() - float(g['loss'])) <= 1e-5 * max(1.0, float(g['loss']))
+            assert tuple(memo['quantizer']['x_shape']) == (B, D, H, W)
+            quant, _ = T.encode_to_quant(q, ref_map.contiguous(memory_format=fmt), {})
+            np.testing.assert_array_equal(quant.cpu().numpy(), g['quant'].astype(np.int64))
+        out, _ = pre(torch.from_numpy(g['z_map']).cuda(), {})
+        np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=1e-5, atol=1e-5)
