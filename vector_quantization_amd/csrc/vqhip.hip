@@ -208,9 +208,19 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
                 if (small) VQ_CFG(8, 2, 8, 4, 4, true) else VQ_CFG(8, 4, 8, 4, 4, true)
         case 16: if (small) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
-        case 32: VQ_CFG(32, 2, 8, 2)
-        case 48: VQ_CFG(48, 2, 8, 1)
-        case 64: VQ_CFG(64, 1, 8, 1)
+        // large D: the token fragments of a wave must stay in registers for the whole stream
+#ifndef VQ_CFG_D512
+#define VQ_CFG_D512 VQ_CFG(32, 2, 8, 2)
+#endif
+#ifndef VQ_CFG_D768
+#define VQ_CFG_D768 VQ_CFG(48, 2, 8, 1)
+#endif
+#ifndef VQ_CFG_D1024
+#define VQ_CFG_D1024 VQ_CFG(64, 1, 8, 1)
+#endif
+        case 32: VQ_CFG_D512
+        case 48: VQ_CFG_D768
+        case 64: VQ_CFG_D1024
         default: break;
     }
 #undef VQ_CFG
