@@ -151,6 +151,9 @@ static int streamk_grid(int64_t ntb, int64_t nstages, int *pieces_out) {
 // threshold, and a block cut in three needs three records per token.  Off; results are identical either way.
 static std::atomic<int> g_tune_streamk{0};
 
+#ifndef VQ_NBUF_D32
+#define VQ_NBUF_D32 4          // LDS ring depth of the D <= 32 proposal kernels (2 and 3 measured: profiles/r02_smallD_ring.txt)
+#endif
 #ifndef VQ_MIN_SLICES_FILTER
 #define VQ_MIN_SLICES_FILTER 1
 #endif
@@ -199,10 +202,10 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
-        case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4) }
+        case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }
                 // (N >= 262 144: at least 1024 workgroups of 64 tokens per wave — balance no longer matters and that form is the faster one)
-                if (g_tune_streamk.load() && small32) VQ_CFG_SK(2, 2, 8, VQ_TPS_D32, 4, true, true)
-                if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, 4, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, 4, true)
+                if (g_tune_streamk.load() && small32) VQ_CFG_SK(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32, true, true)
+                if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true)
         case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }

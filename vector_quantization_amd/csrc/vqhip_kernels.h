@@ -518,7 +518,7 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // margin defines and needs neither identification nor a bound in the record; every score within the margin of the
 // running best still goes through the exact per-element update.  Rows without a usable margin never skip.
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false>
-__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2 && TT <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
     const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec) {
