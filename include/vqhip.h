@@ -126,6 +126,16 @@ int vqhip_vqkd_update(float *w, const int64_t *hist, const float *sums, int64_t 
  *        2 = update w only from the current p, 3 = both. */
 int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, const int64_t *numel_dev,
                      const float *anchors, int64_t K, int D, float ema_decay, float eps, int stage, void *stream);
+/* The whole single-rank update with NearestAnchor in ONE launch (quantizer_callback.py:89-103 + anchors.py:83-84):
+ *   p_out[k] = p_in[k]*g + (hist[k]/numel)*(1-g);  decay_k = 1 - exp(-p_out[k]*K*10/(1-g) - eps)
+ *   w_out[k] = w_in[k]*decay_k + x[col_idx[k]]*(1-decay_k)
+ * hist is the int32 histogram of the argmin epilogue, col_idx the output of vqhip_col_argmin, x the latents [N,D]
+ * (fp32 or bf16).  Same expressions in the same order as stage 1 + vqhip_gather_rows + stage 2 (bit-identical);
+ * w_out may alias w_in, p_out may alias p_in.  With more than one rank the histogram and the anchors are all-reduced
+ * between the stages, so the staged form above is the one to use. */
+int vqhip_cvq_step(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
+                   const void *x, int x_dtype, const int64_t *col_idx, int64_t K, int D, float ema_decay, float eps,
+                   void *stream);
 /* The same update for a subset of the codes.  decay_k == 1.0f (every code with p_k above ~1e-6 at K = 16384) multiplies
  * the code's anchor by exactly 0, so only the codes with decay_k < 1 need an anchor at all: vqhip_cvq_decay writes
  * decay[K] with the update's own expression (bit for bit), the caller selects rows = {k : decay_k < 1}, computes /

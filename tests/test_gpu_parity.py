@@ -197,7 +197,20 @@ def test_cvq_update_matches_golden(ops, dist):
             np.testing.assert_array_equal(col.cpu().numpy(), z[ck].astype(np.int64))
         hist = ops.hist(quant, K).long()
         anchors = ops.gather_rows(xd, col)
+        # the one-launch form (vqhip_cvq_step) on the int32 histogram: bit-identical to the staged update, out of place
+        # and in place, fp32 and bf16 latents
+        w1, p1 = torch.empty_like(wd), torch.empty_like(p)
+        ops.cvq_step(wd, w1, p, p1, hist.int(), N, xd, col, 0.99, 1e-3)
+        w2, p2 = wd.clone(), p.clone()
+        ops.cvq_step(w2, w2, p2, p2, hist.int(), N, xd, col, 0.99, 1e-3)
+        xb = xd.bfloat16()
+        wb_ref, pb_ref = wd.clone(), p.clone()
+        ops.cvq_update_(wb_ref, pb_ref, hist, N, ops.gather_rows(xb, col), 0.99, 1e-3)
+        wb, pb = torch.empty_like(wd), torch.empty_like(p)
+        ops.cvq_step(wd, wb, p, pb, hist.int(), N, xb, col, 0.99, 1e-3)
         ops.cvq_update_(wd, p, hist, N, anchors, 0.99, 1e-3)
+        assert torch.equal(w1, wd) and torch.equal(p1, p) and torch.equal(w2, wd) and torch.equal(p2, p)
+        assert torch.equal(wb, wb_ref) and torch.equal(pb, pb_ref)
         np.testing.assert_allclose(p.cpu().numpy(), z[pk], rtol=1e-5, atol=1e-8)
         if step == 0:
             np.testing.assert_allclose(wd.cpu().numpy(), z[wk], rtol=0, atol=3e-6)

@@ -44,6 +44,7 @@ SIGNATURES = {
     'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vqhip_codebook_metrics': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_argmin_stats': (_i32, [_vp, _vp, _vp]),
+    'vqhip_cvq_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_cvq_decay': (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     'vqhip_cvq_update_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),

@@ -626,6 +626,19 @@ int vqhip_cvq_update(float *w, float *p, const int64_t *hist, int64_t numel, con
     return VQHIP_OK;
 }
 
+int vqhip_cvq_step(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
+                   const void *x, int x_dtype, const int64_t *col_idx, int64_t K, int D, float ema_decay, float eps,
+                   void *stream) {
+    if (!w_in || !w_out || !p_in || !p_out || !hist || !x || !col_idx || K <= 0 || D <= 0 || numel <= 0)
+        return fail(VQHIP_EINVAL, "vqhip_cvq_step: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == VQHIP_DTYPE_F32) cvq_step_kernel<0><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, K, D, ema_decay, eps);
+    else if (x_dtype == VQHIP_DTYPE_BF16) cvq_step_kernel<1><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, K, D, ema_decay, eps);
+    else return fail(VQHIP_EINVAL, "vqhip_cvq_step: x_dtype");
+    VQ_CHECK_LAUNCH("cvq_step_kernel");
+    return VQHIP_OK;
+}
+
 int vqhip_cvq_decay(const float *p, int64_t K, float ema_decay, float eps, float *decay, void *stream) {
     if (!p || !decay || K <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_decay: bad argument");
     cvq_decay_kernel<<<(int)((K + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, K, ema_decay, eps, decay);

@@ -1787,6 +1787,24 @@ __global__ void cvq_update_kernel(float *w, float *p, const int64_t *hist, int64
     if (lane == 0 && (stage & 1)) p[k] = pk;
 }
 
+// The whole one-rank CVQ-VAE update in one launch, wave per code: probability EMA from the int32 epilogue histogram,
+// decay, NearestAnchor's row gather x[col_idx[k]] and the blend — the same expressions, in the same order, as stage 1,
+// vqhip_gather_rows and stage 2 above (bit-identical results); w_out may alias w_in and p_out may alias p_in.
+template <int DT>
+__global__ void cvq_step_kernel(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist,
+                                int64_t numel, const void *x, const int64_t *col_idx, int64_t K, int D, float ema_decay,
+                                float eps) {
+    const int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    const float freq = (float)hist[k] / (float)numel;
+    const float pk = p_in[k] * ema_decay + freq * (1.0f - ema_decay);
+    const float decay = cvq_decay_of(pk, K, ema_decay, eps), om = 1.0f - decay;
+    const int64_t row = col_idx[k];
+    for (int d = lane; d < D; d += 64) w_out[k * D + d] = w_in[k * D + d] * decay + load_elem<DT>(x, row * D + d) * om;
+    if (lane == 0) p_out[k] = pk;
+}
+
 // decay_k of every code (the same expression, bit for bit): decay_k == 1.0f means the code's anchor is multiplied by 0
 __global__ void cvq_decay_kernel(const float *p, int64_t K, float ema_decay, float eps, float *decay) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

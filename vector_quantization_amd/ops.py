@@ -347,6 +347,25 @@ def cvq_update_(w: torch.Tensor, p: torch.Tensor, hist64: Optional[torch.Tensor]
 
 
 @_on_tensor_device
+def cvq_step(w_in: torch.Tensor, w_out: torch.Tensor, p_in: torch.Tensor, p_out: torch.Tensor, hist32: torch.Tensor,
+             numel: int, x: torch.Tensor, col_idx: torch.Tensor, ema_decay: float, eps: float) -> None:
+    """The one-rank CVQ-VAE update (probability EMA, decay, NearestAnchor gather, blend) in one launch; ``w_out`` /
+    ``p_out`` may be ``w_in`` / ``p_in`` themselves."""
+    _require_cuda(w_in, w_out, p_in, p_out, hist32, x, col_idx)
+    x, dt = _latents(x)
+    K, D = w_in.shape
+    for t in (w_in, w_out):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (K, D)
+    for t in (p_in, p_out):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == K
+    assert hist32.dtype == torch.int32 and hist32.is_contiguous() and hist32.numel() == K
+    col_idx = col_idx.to(torch.int64).contiguous()
+    assert col_idx.numel() == K and x.shape[1] == D
+    check(_lib.lib().vqhip_cvq_step(_ptr(w_in), _ptr(w_out), _ptr(p_in), _ptr(p_out), _ptr(hist32), int(numel), _ptr(x), dt,
+                                    _ptr(col_idx), K, D, ema_decay, eps, _stream()), 'vqhip_cvq_step')
+
+
+@_on_tensor_device
 def cvq_decay(p: torch.Tensor, K: int, ema_decay: float, eps: float) -> torch.Tensor:
     """decay_k = 1 - exp(-p_k*K*10/(1-ema_decay) - eps) with the update kernel's own expression (fp32 [K])."""
     _require_cuda(p)

@@ -321,8 +321,31 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         if not self.quantizer.training:
             return quant
         K = self.quantizer.codebook_size
-        e = self.quantizer.embeddings
         d = memo['encode']['distance']
+        hist32 = memo['encode'].get('hist')
+        if (get_world_size() <= 1 and type(self._anchor) is NearestAnchor and not self._anchor._sync
+                and not self._sparse_anchors and isinstance(d, LazyDistance) and hist32 is not None
+                and self.probability.is_cuda and self.probability.dtype == torch.float32):
+            # one rank: nothing is exchanged between the probability update and the blend, so the whole update is one
+            # launch on the epilogue histogram, the column argmin and the latents (vqhip_cvq_step; bit-identical to the
+            # staged form below, which stays for the multi-rank case where hist and anchors are all-reduced in between)
+            weight = self.vector_quantizer.embedding.weight
+            col = d.argmin(0)
+            w_in, p_in = weight.detach(), self.probability
+            inplace = self.quantizer.inplace_updates
+            w_out = w_in if inplace else torch.empty_like(w_in)
+            p_out = p_in if inplace else torch.empty_like(p_in)
+            ops.cvq_step(w_in.contiguous(), w_out, p_in.contiguous(), p_out, hist32, quant.numel(), x.detach(), col,
+                         self._ema.decay, self._eps)
+            if not inplace:
+                self._update_probability(p_out)
+                self._update_embedding(w_out)
+            else:
+                if Store.DRY_RUN:
+                    assert is_sync(w_out)
+                self.vector_quantizer.invalidate_codebook()
+            return quant
+        e = self.quantizer.embeddings
         stats = QuantStatistics(quant=quant, codebook_size=K, sync=True, hist=memo['encode'].get('hist'))
         hist, numel = stats.bin_count(), stats._statistics()[1]
         p = self.probability.to(device=e.device, dtype=torch.float32).clone()
