@@ -102,6 +102,11 @@ int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, 
  *                                         divides by N*D).  sse may be NULL. */
 int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
                           float *z, float *z_ste, double *sse, void *stream);
+/* The same pass with the mean finished on the device: mse[0] = mse[1] = mean((z - x)^2) as fp32 (double sum, one division,
+ * one cast: what `mse_loss` of losses.py:50,62 returns for both terms).  `scratch16`: 16 bytes of device memory that are
+ * ZERO on entry and are left zero on return (one scratch per stream in flight); N > 0. */
+int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
+                         float *z, float *z_ste, float *mse, void *scratch16, void *stream);
 
 /* hist[K] int32 += bincount(idx) (utils.py:42; runners/metrics.py:40-44) */
 int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     'vqhip_row_sqnorm': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     'vqhip_normalize_rows': (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),
     'vqhip_gather_ste_loss': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    'vqhip_gather_ste_mse': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_hist': (_i32, [_vp, _i64, _i64, _vp, _vp]),
     'vqhip_scatter_add_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     'vqhip_vqkd_update': (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),

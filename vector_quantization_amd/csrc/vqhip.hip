@@ -552,9 +552,23 @@ int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_
     return VQHIP_OK;
 }
 
+static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                           float *z_ste, double *sse, float *mse, void *stream);
+
 int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
                           float *z_ste, double *sse, void *stream) {
     if (!x || !e || !idx || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: bad argument");
+    return gather_ste_impl(x, x_dtype, e, idx, N, D, z, z_ste, sse, nullptr, stream);
+}
+
+int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                         float *z_ste, float *mse, void *scratch16, void *stream) {
+    if (!x || !e || !idx || !mse || !scratch16 || N <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_mse: bad argument");
+    return gather_ste_impl(x, x_dtype, e, idx, N, D, z, z_ste, (double *)scratch16, mse, stream);
+}
+
+static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
+                           float *z_ste, double *sse, float *mse, void *stream) {
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
     // outputs beyond the Infinity Cache (256 MiB) are streamed: non-temporal accesses and twice the waves in flight
@@ -564,7 +578,7 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
     int cap = tune_grid > 0 ? tune_grid : (streamed ? 512 : 256);      // blocks of 16 waves
     int grid = (int)((N + 15) / 16);
     grid = grid > cap ? cap : grid;
-#define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse)
+#define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse, mse)
     if (x_dtype == VQHIP_DTYPE_F32) { if (streamed) VQ_GATHER(0, 1); else VQ_GATHER(0, 0); }
     else if (x_dtype == VQHIP_DTYPE_BF16) { if (streamed) VQ_GATHER(1, 1); else VQ_GATHER(1, 0); }
     else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");

@@ -479,6 +479,7 @@ struct VqDecideOut {
     u64 *keys; float *thr_out; int *rescan_cnt;
     int *arrive;            // one arrival counter per token block of the proposal kernel (zeroed by x_prep_kernel)
 };
+template <bool AGENT>
 __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                             const float *rec, const float *xh2, const float *rho2, int64_t Np,
                                             const VqDecideOut &o, int *wcount, int *wbase);
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
             int64_t n = tb * BM + threadIdx.x;           // BM <= WAVES*64 threads: one token per thread
             const bool oob = (int)threadIdx.x >= BM || n >= N;
             if (n >= N) n = N - 1;
-            decide_rows(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
+            decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
         }
     }
   }   // segments
@@ -878,29 +879,56 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
 //   an unidentified candidate may exist   -> rescan_list  (second proposal pass that emits every score >= thr)
 //   no usable bound (non-finite data)     -> exact_list   (whole-codebook fp32 pass)
 // counters: [0] rescan rows, [1] multi rows, [2] exact rows
-// `rec` is read with agent-scope loads (they bypass this CU's L1): inside the proposal kernel the records of the other
-// slices were written by other workgroups moments ago.  wcount / wbase: 3 x 16 ints of LDS each.
-__device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
-                                            const float *rec, const float *xh2, const float *rho2, int64_t Np,
-                                            const VqDecideOut &o, int *wcount, int *wbase) {
+// AGENT: `rec` is read with agent-scope loads (they bypass this CU's L1) — inside the proposal kernel the records of the
+// other slices were written by other workgroups moments ago; the stand-alone kernel reads them with plain loads.
+// NSL > 0: compile-time slice count, every record load is issued before the first one is used (the stage is a latency
+// chain: at 16 slices the run-time loop took 17 us instead of 6 at N = 3072).  wcount / wbase: 3 x 16 ints of LDS each.
+template <bool AGENT>
+__device__ __forceinline__ float rec_load(const float *p) {
+    if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <int NSL, bool AGENT>
+__device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
+                                                 const float *rec, const float *xh2, const float *rho2, int64_t Np,
+                                                 const VqDecideOut &o, int *wcount, int *wbase) {
     const float m = row_margin(st, Dp, metric, xh2[n], rho2[n]);
     bool invalid = !(m > 0.0f);
     float gbest = -INFINITY;
-    for (int s = 0; s < nslices; ++s)
-        gbest = fmaxf(gbest, __hip_atomic_load(rec + (int64_t)s * VQ_REC_FIELDS * Np + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
-    const float thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
     int nc = 0;
     bool unidentified = false;
     uint32_t best = 0xFFFFFFFFu;
-    for (int s = 0; s < nslices; ++s) {
-        const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
-        const float v1 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v2 = __hip_atomic_load(rp + 2 * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float v3 = __hip_atomic_load(rp + 4 * Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v3 >= thr) unidentified = true;
-        if (v1 >= thr) { ++nc; best = __float_as_uint(__hip_atomic_load(rp + Np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-        if (v2 >= thr) ++nc;
+    float thr;
+    if constexpr (NSL > 0) {
+        float v1[NSL], v2[NSL], v3[NSL], c1[NSL];
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+            v1[s] = rec_load<AGENT>(rp); c1[s] = rec_load<AGENT>(rp + Np);
+            v2[s] = rec_load<AGENT>(rp + 2 * Np); v3[s] = rec_load<AGENT>(rp + 4 * Np);
+        }
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
+        if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
+        thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            if (v3[s] >= thr) unidentified = true;
+            if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
+            if (v2[s] >= thr) ++nc;
+        }
+    } else {
+        for (int s = 0; s < nslices; ++s) gbest = fmaxf(gbest, rec_load<AGENT>(rec + (int64_t)s * VQ_REC_FIELDS * Np + n));
+        if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
+        thr = gbest - m;
+        for (int s = 0; s < nslices; ++s) {
+            const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
+            const float v1 = rec_load<AGENT>(rp), v2 = rec_load<AGENT>(rp + 2 * Np), v3 = rec_load<AGENT>(rp + 4 * Np);
+            if (v3 >= thr) unidentified = true;
+            if (v1 >= thr) { ++nc; best = __float_as_uint(rec_load<AGENT>(rp + Np)); }
+            if (v2 >= thr) ++nc;
+        }
     }
     // block-aggregated list appends: one atomic per workgroup and list (the three counters are hot words:
     // ~8-11 ns per same-address atomic, so per-wave appends from 1024 waves cost ~15 us)
@@ -930,6 +958,18 @@ __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats
     }
 }
 
+template <bool AGENT>
+__device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
+                                            const float *rec, const float *xh2, const float *rho2, int64_t Np,
+                                            const VqDecideOut &o, int *wcount, int *wbase) {
+    switch (nslices) {      // every thread of the workgroup takes the same case (the list appends contain barriers)
+#define VQ_DECIDE_CASE(NSL) case NSL: decide_rows_impl<NSL, AGENT>(n, oob, st, Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase); break;
+        VQ_DECIDE_CASE(1) VQ_DECIDE_CASE(2) VQ_DECIDE_CASE(4) VQ_DECIDE_CASE(8) VQ_DECIDE_CASE(16)
+#undef VQ_DECIDE_CASE
+        default: decide_rows_impl<0, AGENT>(n, oob, st, Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase); break;
+    }
+}
+
 // stand-alone form (one thread per token, 1024-thread workgroups): used when the proposal kernel does not decide itself
 __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
                                      const float *xh2, const float *rho2, int64_t Np, VqDecideOut o) {
@@ -938,7 +978,7 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool oob = n >= N;
     if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
-    decide_rows(n, oob, (const VqCbStats *)(cb + L.off_stats), L.Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase);
+    decide_rows<false>(n, oob, (const VqCbStats *)(cb + L.off_stats), L.Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase);
 }
 
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
@@ -1619,8 +1659,12 @@ __device__ __forceinline__ void nt_store4(float *q, float a, float b, float c, f
 // NT: the outputs (and the latents) are larger than the Infinity Cache and are streamed with non-temporal accesses;
 // smaller batches keep normal stores so that the consumer of z finds it in cache.
 template <int DT, int NT>
+// mse != nullptr: `sse` is a 16-byte scratch {double sum; int ticket; int pad} that is zero on entry; the workgroup that
+// draws the last ticket writes mean((z - x)^2) as fp32 to mse[0] and mse[1] (the codebook and the commitment term share
+// the value) and leaves the scratch zeroed for the next call — no zero-fill, division or cast kernels around the launch.
 __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
-                                                              int D, float *z, float *zste, double *sse) {
+                                                              int D, float *z, float *zste, double *sse,
+                                                              float *mse = nullptr) {
     __shared__ double red[16];                                // 16 waves per block: one atomic per 16 waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0;
@@ -1674,6 +1718,18 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) t += red[i];
             atomicAdd(sse, t);
+            if (mse) {
+                int *ticket = (int *)(sse + 1);
+                __threadfence();                                   // the sum above is performed before the ticket is taken
+                if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+                    __threadfence();
+                    const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float mean = (float)(total / ((double)N * (double)D));
+                    mse[0] = mean; mse[1] = mean;
+                    __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }

@@ -105,10 +105,14 @@ class _FusedDecodeLoss(Function):
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor):
-        _, z_ste, sse = ops.gather_ste_loss(x, weight, idx, need_z=False, need_ste=True, need_sse=True)
+        if x.numel() == 0:
+            _, z_ste, sse = ops.gather_ste_loss(x, weight, idx, need_z=False, need_ste=True, need_sse=True)
+            ctx.save_for_backward(x, weight, idx)
+            m = (sse / x.numel()).float().reshape(())                  # nan, as mse_loss of an empty tensor
+            return z_ste.view(x.shape), m, m.clone()
+        _, z_ste, mse = ops.gather_ste_mse(x, weight, idx)            # the mean is finished inside the kernel
         ctx.save_for_backward(x, weight, idx)
-        m = (sse / x.numel()).float().reshape(())
-        return z_ste.view(x.shape), m, m.clone()
+        return z_ste.view(x.shape), mse[0], mse[1]
 
     @staticmethod
     def backward(ctx, g_zste, g_cb, g_cm):

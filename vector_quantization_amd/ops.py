@@ -213,6 +213,35 @@ def gather_ste_loss(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z:
     return z, zs, sse
 
 
+_MSE_SCRATCH: dict = {}      # (device index, stream) -> 16 zeroed bytes the kernel hands back zeroed
+
+
+def _mse_scratch(device: torch.device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _MSE_SCRATCH.get(key)
+    if buf is None:
+        buf = _MSE_SCRATCH[key] = torch.zeros(16, dtype=torch.uint8, device=device)
+    return buf
+
+
+@_on_tensor_device
+def gather_ste_mse(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: bool = False, need_ste: bool = True):
+    """(z or None, z_ste or None, mse fp32[2]) with mse[0] = mse[1] = mean((e[idx] - x)^2): `gather_ste_loss` with the mean
+    finished inside the kernel (no zero-fill, division and cast kernels around it)."""
+    _require_cuda(x, e, idx)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    idx = idx.reshape(-1).contiguous()
+    assert idx.dtype == torch.int64 and idx.numel() == x.shape[0] and x.shape[0] > 0
+    N, D = x.shape
+    z = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_z else None
+    zs = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_ste else None
+    mse = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vqhip_gather_ste_mse(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(z), _ptr(zs), _ptr(mse),
+                                          _ptr(_mse_scratch(x.device)), _stream()), 'vqhip_gather_ste_mse')
+    return z, zs, mse
+
+
 @_on_tensor_device
 def hist(idx: torch.Tensor, K: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _require_cuda(idx)
