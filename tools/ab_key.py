@@ -42,4 +42,8 @@ one(65536, 8192, 32, "Cosine")
 one(262144, 8192, 32, "Cosine")
 one(524288, 16384, 8, "L2", rounds=3, reps=5)
 one(3072, 8192, 32, "Cosine")
+one(80000, 8192, 32, "Cosine")
+one(90000, 16384, 256, 'L2', torch.bfloat16)
+one(40000, 16384, 256, 'L2', torch.bfloat16)
+one(150000, 8192, 64, 'L2')
 one(1024, 1024, 256, 'L2')

@@ -38,6 +38,7 @@ while time.time() < t_end:
     elif kind == 5:  # integer grid (exact ties)
         x = torch.randint(-3, 4, (N, D), device='cuda', generator=g).float(); w = torch.randint(-3, 4, (K, D), device='cuda', generator=g).float()
     x, w = x * scale, w * scale
+    if os.environ.get('VQ_FUZZ_VERBOSE'): print(f'trial {trials + 1}: N={N} K={K} D={D} {metric} kind={kind} scale={scale}', flush=True)
     xd = x.bfloat16() if ri(0, 3) == 0 else x
     if metric == 'Cosine':
         xq = ops.normalize_rows(xd); wq = ops.normalize_rows(w)

@@ -87,22 +87,25 @@ static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B meas
 // Measured neutral (tools/ab_key.py 6: -1.6 % .. +1.4 % over seven shapes; the release/acquire fences cost what the
 // launch saves), so the stand-alone launch stays the default; results are identical either way.
 static std::atomic<int> g_tune_fused_decide{0};
+static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
+static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false, bool NOAUX = false,
+          bool GROUPS = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
-                             const VqDecideOut &dec, int streamk_grid, hipStream_t s) {
-    constexpr int BM = WAVES * TT * 16;
+                             const VqDecideOut &dec, int streamk_grid, int pad_stage, int tpb, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, STREAMK>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, STREAMK, NOAUX, GROUPS>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
-    int64_t ntb = (N + BM - 1) / BM;
+    const int64_t ntiles = (N + 15) / 16;
+    const int64_t ntb = (ntiles + tpb - 1) / tpb;
     const int grid = STREAMK ? streamk_grid : (int)(ntb * nslices);
     const long slot = prof_begin(s);
-    kern<<<grid, WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec);
+    kern<<<grid, WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec, pad_stage, tpb);
     prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse_kernel");
     return VQHIP_OK;
@@ -154,9 +157,35 @@ static std::atomic<int> g_tune_streamk{0};
 #ifndef VQ_NBUF_D32
 #define VQ_NBUF_D32 4          // LDS ring depth of the D <= 32 proposal kernels (2 and 3 measured: profiles/r02_smallD_ring.txt)
 #endif
+#ifndef VQ_D32_SMALL_TT
+#define VQ_D32_SMALL_TT 2      // token tiles per wave / waves per workgroup of the D <= 32 kernels below 262 144 tokens
+#define VQ_D32_SMALL_W 8
+#endif
+#ifndef VQ_GROUPS_MIN_N
+#define VQ_GROUPS_MIN_N 16384
+#endif
 #ifndef VQ_MIN_SLICES_FILTER
 #define VQ_MIN_SLICES_FILTER 1
 #endif
+// Tiles (of 16 tokens) per workgroup of the proposal kernel when the codebook is not sliced: the workgroups of one launch
+// are spread over the 256 CUs by the dispatcher, so the kernel lasts as long as the CU with the most tiles —
+// ceil(workgroups / 256) x tiles per workgroup.  Full workgroups are not always the minimum of that: 100 352 tokens
+// (BASELINE configs[2]) make 392 workgroups of 16 tiles, two on 136 CUs and one on the other 120 (32 tiles at worst);
+// 13 tiles per workgroup make 483, two per CU at worst (26 tiles).  Ties keep the larger workgroup; at least half the
+// waves stay busy (and a workgroup covers >= 128 tokens: the arrival counters of the workspace are laid out for that).
+static std::atomic<int> g_tune_balance{1};  // key 10: 0 = always full workgroups (A/B; results unchanged)
+static int balanced_tiles_per_block(int64_t N, int full) {
+    if (!g_tune_balance.load() || full < 16) return full;
+    const int64_t ntiles = (N + 15) / 16;
+    int best = full;
+    int64_t best_cost = ((ntiles + full - 1) / full + 255) / 256 * full;
+    for (int tpb = full - 1; tpb >= full / 2 && tpb >= 8; --tpb) {
+        const int64_t cost = ((ntiles + tpb - 1) / tpb + 255) / 256 * tpb;
+        if (cost < best_cost) { best_cost = cost; best = tpb; }
+    }
+    return best;
+}
+
 static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
     if (const int forced = g_tune_slices.load(); forced > 0) { int ns = forced; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
     // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
@@ -182,12 +211,16 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     // proposal kernel 128 -> 108 us with 8 tiles per stage, one slice and 32 tokens per wave; at N = 524 288 the
     // 64-token form is the faster one)
     const bool small32 = N < 512 * 512;
+    // cosine / dot product: every real code's aux value is 0 (cb_stats_kernel), only padding codes need the aux chunk
+    const bool noaux = !VQ_IS_L2(metric) && g_tune_noaux.load();
+    const int pad_stage = (L.K % ((int64_t)L.tps * VQ_TILE_CODES)) ? (int)(L.nstages - 1) : -1;
 #define VQ_CFG(NS, TT, W, ...)                                                                      \
     {                                                                                               \
         int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
         int ns = pick_slices(ntb, L.nstages, (NS) <= 8 ? VQ_MIN_SLICES_FILTER : 2);                 \
         *nslices_out = ns;                                                                          \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, 0, s); \
+        const int tpb = (ns == 1) ? balanced_tiles_per_block(N, (W) * (TT)) : (W) * (TT);           \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, 0, pad_stage, tpb, s); \
     }
     // stream-K form (D <= 32): equal shares of the (token block x stage) space, two workgroups per CU
 #define VQ_CFG_SK(NS, TT, W, ...)                                                                   \
@@ -198,14 +231,21 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         *nslices_out = pieces;                                                                      \
         VqDecideOut nodec = dec; nodec.idx = nullptr;                                               \
         *fused_decide_out = 0;                                                                      \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, pieces, rec, Np, cbst, xh2, rho2, L.Dp, metric, nodec, grid, s); \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, pieces, rec, Np, cbst, xh2, rho2, L.Dp, metric, nodec, grid, pad_stage, (W) * (TT), s); \
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
         case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }
                 // (N >= 262 144: at least 1024 workgroups of 64 tokens per wave — balance no longer matters and that form is the faster one)
                 if (g_tune_streamk.load() && small32) VQ_CFG_SK(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32, true, true)
-                if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true)
+                // group records from VQ_GROUPS_MIN_N tokens on: below, the identification replay at the end of a
+                // workgroup (a few L2 round trips) costs more than the stream saves
+                if (N >= VQ_GROUPS_MIN_N && g_tune_groups.load()) {
+                    if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, true, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, true, true) }
+                    if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, false, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, false, true)
+                }
+                if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, true) }
+                if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true)
         case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
@@ -841,6 +881,9 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 5) g_tune_filter = value != 0;
     else if (key == 6) g_tune_fused_decide = value != 0;
     else if (key == 7) g_tune_streamk = value != 0;
+    else if (key == 8) g_tune_noaux = value != 0;
+    else if (key == 9) g_tune_groups = value != 0;
+    else if (key == 10) g_tune_balance = value != 0;
     else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

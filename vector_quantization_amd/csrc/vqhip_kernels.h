@@ -98,6 +98,14 @@ __device__ __forceinline__ float vmax(float a, float b) {
 #ifndef VQ_FILTER_MAX_IMPL
 #define VQ_FILTER_MAX_IMPL 3
 #endif
+// Group records (coarse_kernel, GROUPS): the wave-uniform skip test stays in front of the 4-instruction group update from
+// this many token tiles per wave on (measured: with 2 tiles the straight-line form is faster, with 4 the test pays)
+#ifndef VQ_REPLAY_BATCH
+#define VQ_REPLAY_BATCH 4      // (8 without aux reads: spills inside the replay loop, 123 instead of 92 us at configs[2])
+#endif
+#ifndef VQ_GROUP_BRANCH_MIN_TT
+#define VQ_GROUP_BRANCH_MIN_TT 4
+#endif
 // Maximum of the 8 accumulator elements p[0..7] of one (token tile, code tile) into `dst` (sc1/sc2: scratch).
 // after[]: results of TT MFMAs of the CURRENT tile (fake inputs, see above).  Variants kept for the A/B record:
 //   2: compiler-visible v_med3 (max(a,b) = med3(a,b,+inf)), 7 instructions, hazards handled by hipcc
@@ -518,13 +526,23 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // s < best_so_far - m <= final best - m = the decision threshold, so it is strictly outside the candidate set the
 // margin defines and needs neither identification nor a bound in the record; every score within the margin of the
 // running best still goes through the exact per-element update.  Rows without a usable margin never skip.
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false>
-__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WAVES / 4) void coarse_kernel(
+//
+// NOAUX (cosine / dot product: no |e|^2 term, the aux chunk is all zeros except for the padding codes of the very last
+// stage): the accumulators start from the inline constant 0 and the two 16-byte aux reads per code tile — half of the
+// LDS read traffic at D = 32 — are issued only in `pad_stage` (-1: the codebook fills its last stage).
+//
+// GROUPS (with FILTER; D <= 32, where the per-element update of the tiles that fail the skip test was the larger half of
+// the VALU work): see "group record" in the loop and "group records -> code records" after it.
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false, bool NOAUX = false,
+          bool GROUPS = false>
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
-    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec) {
+    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
+    static_assert(!GROUPS || FILTER, "group records are a form of the filtered epilogue");
+    constexpr bool GBRANCH = TT >= VQ_GROUP_BRANCH_MIN_TT;
     constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
     constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
     constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage (2 per k-step and tile, + aux)
@@ -538,6 +556,9 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
     // CU gets the same share whatever the number of token blocks — and a workgroup walks its range as one or two
     // segments (tail of one block, head of the next).  A block is then covered by at most `nslices` consecutive
     // workgroups; the piece index within the block is the record slot, unused slots are filled with "nothing here".
+    // tpb: 16-token tiles per workgroup, <= WAVES*TT (the host picks it so that the workgroups fill whole rounds of the
+    // chip: launch_coarse).  Waves past it only help filling the ring; tiles past it belong to the next workgroup.
+    const bool wave_active = wave * TT < tpb;
     const int64_t U = ((N + BM - 1) / BM) * nstages;
     int64_t u_next = STREAMK ? ((int64_t)blockIdx.x * U) / gridDim.x : 0;
     const int64_t u_end = STREAMK ? ((int64_t)(blockIdx.x + 1) * U) / gridDim.x : 1;
@@ -560,7 +581,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
     half8 xf[TT][NS32];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        int64_t tt = tb * (BM / 16) + wave * TT + t;
+        int64_t tt = tb * tpb + wave * TT + t;
         tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
         const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
 #pragma unroll
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
     if constexpr (FILTER) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+            int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
             tokn = tokn < N ? tokn : N - 1;
             const float m = row_margin(cbst, Dp, metric, xh2[tokn], rho2[tokn]);
             mg[t] = (m > 0.0f) ? m : INFINITY;                 // no usable bound: threshold -inf, nothing is skipped
@@ -608,25 +629,31 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) accB[c][t][q] = -3.0e38f;   // "previous tile" of the very first tile: never wins
+            for (int q = 0; q < 4; ++q)   // "previous tile" of the very first tile: never wins (group records: never even registers)
+                accB[c][t][q] = GROUPS ? -INFINITY : -3.0e38f;
 
     for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
         const int64_t st = it - lag;
-        if (st < st0 || st >= st1) { __syncthreads(); continue; }
+        if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
         const int buf = (int)((st - st0) % NBUF);
         const char *base = lds + buf * STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+      // the tiles of one stage; WITH_AUX false: accumulators start from the constant 0 (no aux read)
+      auto run_stage = [&](auto with_aux_tag) __attribute__((always_inline)) {
+        constexpr bool WITH_AUX = decltype(with_aux_tag)::value;
 #pragma unroll
         for (int ti = 0; ti < TPS; ++ti) {
             f32x4 (&cur)[2][TT] = (PIPE && (ti & 1)) ? accB : accA;
             f32x4 (&prv)[2][TT] = (PIPE && (ti & 1)) ? accA : accB;
             // accumulator init = -se*|e|^2/2 of this lane's code rows 16c + 4(l>>4) + {0..3}
+            if constexpr (WITH_AUX) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
 #pragma unroll
-                for (int t = 0; t < TT; ++t) cur[c][t] = a4;
+                    for (int t = 0; t < TT; ++t) cur[c][t] = a4;
+                }
             }
             uint32_t old[TT];
 #pragma unroll
@@ -643,21 +670,39 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                 if (ch + PF < NSTEP)
                     af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
+                for (int t = 0; t < TT; ++t) {
+                    if constexpr (!WITH_AUX) {
+                        if (ch < 2) {                      // first k-step of this code half: C = inline constant 0
+                            cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                            continue;
+                        }
+                    }
                     cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                }
                 if constexpr (FILTER) {
                     // token tile t of the previous code tile: maximum of its 8 elements, one compare, wave-uniform skip
                     const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;
 #pragma unroll
                     for (int i = 0; i < (TT + NSTEP - 1) / NSTEP; ++i) {
-                        const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % (NSTEP / TT) == 0) ? ch / (NSTEP / TT) : -1);
+                        constexpr int EVERY = (NSTEP / TT) > 0 ? NSTEP / TT : 1;       // TT < NSTEP: one token tile every EVERY chunks
+                        const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % EVERY == 0) ? ch / EVERY : -1);
                         if (t >= 0 && t < TT) {
                             // (ordered behind all TT MFMAs of this chunk: >= TT MFMAs after the previous tile's last one)
                             float after[TT];
 #pragma unroll
                             for (int u = 0; u < TT; ++u) after[u] = cur[ch & 1][u][0];
                             tile_max8<TT>(sc0, sc1, sc2, prv[0][t], prv[1][t], after);
-                            if (__any(!(sc0 < th[t]))) {
+                            if constexpr (GROUPS) {
+                                // group record: the lane keeps the best GROUP maximum (its 8 codes of one code tile),
+                                // the tile it came from and the best maximum of any other group; which of the 8 codes
+                                // it was is found after the stream by replaying that one tile (below)
+                                if (!GBRANCH || __any(!(sc0 < th[t]))) {
+                                    const float nb = vmax(b1[t], sc0);
+                                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], sc0);
+                                    t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? tgp : t1[t];
+                                    b1[t] = nb;
+                                }
+                            } else if (__any(!(sc0 < th[t]))) {
                                 const uint32_t was = __float_as_uint(b1[t]);
 #pragma unroll
                                 for (int e = 0; e < NE; ++e) {
@@ -674,7 +719,8 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                 constexpr int TOTAL = NE * TT;
 #pragma unroll
                 for (int i = 0; PIPE && !FILTER && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
-                    const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % (NSTEP / TOTAL) == 0) ? ch / (NSTEP / TOTAL) : -1);
+                    constexpr int EVERY = (NSTEP / TOTAL) > 0 ? NSTEP / TOTAL : 1;   // TOTAL < NSTEP: one element every EVERY chunks
+                    const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % EVERY == 0) ? ch / EVERY : -1);
                     if (id >= 0 && id < TOTAL) {
                         const int t = id / NE, e = id % NE;
                         float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
@@ -700,24 +746,124 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
                     t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
             }
         }
-        if constexpr (FILTER) {      // refresh the skip thresholds: best score among the token's four lanes, less the margin
+      };   // run_stage
+        if constexpr (NOAUX) {
+            if (st == (int64_t)pad_stage) run_stage(std::true_type{}); else run_stage(std::false_type{});
+        } else {
+            run_stage(std::true_type{});
+        }
+        if constexpr (FILTER && (!GROUPS || GBRANCH)) {   // refresh the skip thresholds: best score among the token's four lanes, less the margin
 #pragma unroll
             for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
         }
-        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+        // next stage landed (vmcnt(0)) and everybody is done reading this one.  (A barrier that keeps the pieces of the
+        // stage requested in this iteration in flight — s_waitcnt vmcnt(pieces) instead of 0 — was measured: 1-3 %
+        // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
+        __syncthreads();
     }
     // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
     if (PIPE && st1 > st0) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const uint32_t old = __float_as_uint(b1[t]);
+            if constexpr (GROUPS) {
+                float g = accB[0][t][0];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                float v = __uint_as_float((__float_as_uint(accB[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
-                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
-                b1[t] = vmax(b1[t], v);
+                for (int e = 1; e < NE; ++e) g = __builtin_amdgcn_fmed3f(g, accB[e >> 2][t][e & 3], INFINITY);   // max, NaN-transparent like v_max
+                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], g);
+                b1[t] = vmax(b1[t], g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    float v = __uint_as_float((__float_as_uint(accB[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                    b1[t] = vmax(b1[t], v);
+                }
             }
             t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
+    }
+
+    // ---- group records -> code records.  A lane whose best group can matter (its maximum is within the row's margin of
+    // the best any of the token's four lanes holds) replays that one code tile — same fragments, same MFMA sequence per
+    // accumulator, hence the very scores of the stream — and runs the per-element update (index bits, runner-up) on its 8
+    // elements.  Everything else the lane has seen stays a value bound: raised to the largest value the index-bit form
+    // of the same score can take (|low 4 mantissa bits| of slack, on the safe side for either sign).
+    bool ident[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) ident[t] = true;
+    if constexpr (GROUPS) {
+        auto bound_up = [](float v) {
+            const uint32_t b = __float_as_uint(v);
+            return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
+        };
+        constexpr int RB = NSTEP <= 2 ? VQ_REPLAY_BATCH : (NSTEP <= 4 ? 2 : 1);   // tiles replayed per round trip (registers)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float top = quad_rows_max(b1[t]);
+            // (rows past N are image padding: never written, not replayed; the tile range check turns anything unexpected
+            // — a score stream of NaNs, say — into "unidentified", which the decision stage answers with a second pass)
+            const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
+            const bool need = (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) && tokn < N && wave * TT + t < tpb &&
+                              t1[t] >= (uint32_t)(st0 * TPS) && t1[t] < (uint32_t)(st1 * TPS);
+            float e1 = -INFINITY, e2 = -INFINITY;
+            u64 todo = __ballot(need);
+            while (todo) {
+                uint32_t T[RB];
+                u64 rest = todo;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int l = rest ? (__ffsll((unsigned long long)rest) - 1) : (__ffsll((unsigned long long)todo) - 1);
+                    T[i] = (uint32_t)__builtin_amdgcn_readlane((int)t1[t], l);
+                    rest &= rest - 1;
+                }
+                half8 a[RB][NSTEP];
+                f32x4 acc[RB][2];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#ifdef VQ_DEBUG_REPLAY
+                    if (T[i] / TPS >= (uint32_t)nstages) {
+                        if (need && t1[t] == T[i])
+                            printf("replay: bad tile %u (stages %lld, slice %d [%lld,%lld)) block %d lane %d t %d b1 %g b2 %g top %g mg %g\n", T[i],
+                                   (long long)nstages, sl, (long long)st0, (long long)st1, (int)blockIdx.x, lane, t, b1[t], b2[t], top, mg[t]);
+                        T[i] = (uint32_t)(st0 * TPS);
+                    }
+#endif
+                    const int64_t rst = T[i] / TPS;
+                    const int rti = (int)(T[i] % TPS);
+                    const char *sb = frag + rst * (int64_t)STAGE_BYTES;
+#pragma unroll
+                    for (int ch = 0; ch < NSTEP; ++ch)
+                        a[i][ch] = *(const half8 *)(sb + (rti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (NOAUX && rst != (int64_t)pad_stage) acc[i][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        else acc[i][c] = *(const f32x4 *)(sb + TPS * NSTEP * VQ_CHUNK_BYTES + (rti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+                    }
+                }
+                u64 done = 0;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                    for (int ch = 0; ch < NSTEP; ++ch)
+                        acc[i][ch & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ch], xf[t][ch >> 1], acc[i][ch & 1], 0, 0, 0);
+                    float w1 = -INFINITY, w2 = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float v = __uint_as_float((__float_as_uint(acc[i][e >> 2][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        w2 = __builtin_amdgcn_fmed3f(w1, w2, v);
+                        w1 = vmax(w1, v);
+                    }
+                    const bool mine = need && t1[t] == T[i];
+                    e1 = mine ? w1 : e1; e2 = mine ? w2 : e2;
+                    done |= __ballot(mine);
+                }
+                todo &= ~done;
+            }
+            const float other = bound_up(b2[t]);
+            if (need) { b1[t] = e1; b2[t] = fmaxf(other, e2); }
+            else { b2[t] = fmaxf(other, bound_up(b1[t])); }
+            ident[t] = need;
         }
     }
 
@@ -728,13 +874,13 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
         {
             uint32_t bits = __float_as_uint(b1[t]);
             uint32_t code = t1[t] * 32u + (uint32_t)tile_row16((int)(bits & 7u), lane);
-            if (b1[t] > -INFINITY) top_insert(r, b1[t], code);
+            if (ident[t] && b1[t] > -INFINITY) top_insert(r, b1[t], code);
             r.v3 = fmaxf(r.v3, b2[t]);
         }
         top_merge_lane(r, 16);
         top_merge_lane(r, 32);
-        const int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
-        if (lane < 16 && tokn < N) {
+        const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
+        if (lane < 16 && tokn < N && wave * TT + t < tpb) {
             float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
             rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
             rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
@@ -748,7 +894,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
             const int pieces = (int)(gl - blockIdx.x) + 1;
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
-                const int64_t tokn = (tb * (BM / 16) + wave * TT + t) * 16 + (lane & 15);
+                const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
                 if (lane < 16 && tokn < N)
                     for (int p = pieces; p < nslices; ++p) {
                         float *rp = rec + (int64_t)p * VQ_REC_FIELDS * Np + tokn;
@@ -787,8 +933,8 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? WAVES / 2 : WA
         __syncthreads();                                 // everybody has read the flag before the LDS words are reused
         if (last) {
             int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
-            int64_t n = tb * BM + threadIdx.x;           // BM <= WAVES*64 threads: one token per thread
-            const bool oob = (int)threadIdx.x >= BM || n >= N;
+            int64_t n = tb * (int64_t)(tpb * 16) + threadIdx.x;      // tpb*16 <= BM <= WAVES*64 threads: one token per thread
+            const bool oob = (int)threadIdx.x >= tpb * 16 || n >= N;
             if (n >= N) n = N - 1;
             decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
         }
