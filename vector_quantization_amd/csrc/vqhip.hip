@@ -97,7 +97,7 @@ template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = fal
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
                              const VqDecideOut &dec, int streamk_grid, int pad_stage, int tpb, hipStream_t s) {
-    constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES;
+    constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
     auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, STREAMK, NOAUX, GROUPS>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
@@ -114,7 +114,7 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
 static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
                              const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
-    constexpr int LDS = NBUF * (TPS * NSTEP + 1) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
+    constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
     auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;

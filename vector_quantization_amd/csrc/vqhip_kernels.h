@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     constexpr bool GBRANCH = TT >= VQ_GROUP_BRANCH_MIN_TT;
     constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
     constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
-    constexpr int NCH = TPS * NSTEP + 1;                 // chunks per stage (2 per k-step and tile, + aux)
+    constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);   // chunks per stage (2 per k-step and tile, + aux)
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     constexpr int BM = WAVES * TT * 16;
     constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
@@ -632,8 +632,19 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
             for (int q = 0; q < 4; ++q)   // "previous tile" of the very first tile: never wins (group records: never even registers)
                 accB[c][t][q] = GROUPS ? -INFINITY : -3.0e38f;
 
+#ifdef VQ_STAMPS     // diagnostic build only (MI355X guide, In-kernel stamps): shares of the stage loop, printed by a few waves
+#define VQ_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long ts_loop0, ts_a, ts_b, ts_c, acc_issue = 0, acc_body = 0, acc_bar = 0;
+    VQ_STAMP(ts_loop0);
+#endif
     for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
+#ifdef VQ_STAMPS
+        VQ_STAMP(ts_a);
+#endif
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+#ifdef VQ_STAMPS
+        VQ_STAMP(ts_b); acc_issue += ts_b - ts_a;
+#endif
         const int64_t st = it - lag;
         if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
         const int buf = (int)((st - st0) % NBUF);
@@ -756,6 +767,15 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
 #pragma unroll
             for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
         }
+#ifdef VQ_STAMPS
+        VQ_STAMP(ts_c); acc_body += ts_c - ts_b;
+        __syncthreads();
+        VQ_STAMP(ts_a); acc_bar += ts_a - ts_c;
+        if (it + 1 >= st1 + (NBUF >= 4 ? 1 : 0) && lane == 0 && (blockIdx.x % 97) == 0 && (wave == 0 || wave == 5))
+            printf("stamps block %d wave %d: stages %lld  loop %llu  issue %llu  body %llu  barrier %llu (cycles)\n", (int)blockIdx.x, wave,
+                   (long long)(st1 - st0), ts_a - ts_loop0, acc_issue, acc_body, acc_bar);
+        continue;
+#endif
         // next stage landed (vmcnt(0)) and everybody is done reading this one.  (A barrier that keeps the pieces of the
         // stage requested in this iteration in flight — s_waitcnt vmcnt(pieces) instead of 0 — was measured: 1-3 %
         // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
@@ -1140,7 +1160,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
                                                             int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NS32 = NSTEP / 2;
-    constexpr int NCH = TPS * NSTEP + 1;
+    constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     constexpr int BM = WAVES * TT * 16;
     constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);
@@ -2389,7 +2409,7 @@ template <int NSTEP, int TPS>
 __global__ __launch_bounds__(256) void debug_scores_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
                                                            int64_t nstages, int64_t N, int64_t K, float *__restrict__ out) {
     constexpr int NS32 = NSTEP / 2;
-    constexpr int NCH = TPS * NSTEP + 1;
+    constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     constexpr int TR = (NSTEP <= 16) ? 4 : (NSTEP <= 48 ? 2 : 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

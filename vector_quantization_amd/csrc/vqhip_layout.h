@@ -5,6 +5,7 @@
 #define VQ_WAVE 64
 #define VQ_TILE_CODES 32           // codes per tile (two v_mfma_f32_16x16x32_f16 row blocks)
 #define VQ_CHUNK_BYTES 1024        // one wave-instruction of global_load_lds_dwordx4
+#define VQ_AUX_CHUNKS(tps) (((tps) * 128 + VQ_CHUNK_BYTES - 1) / VQ_CHUNK_BYTES)   // aux values: 32 floats per code tile
 #define VQ_MAX_SLICES 16
 #define VQ_REC_FIELDS 5            // v1, c1, v2, c2, v3
 
@@ -35,7 +36,7 @@ struct VqCbLayout {
     int64_t K, Kp;          // codes, codes padded to a whole stage
     int D, Dp, nstep, tps;  // dims, padded dims, k-steps of 16, tiles per stage
     int64_t nstages;
-    int64_t stage_bytes;    // (tps*nstep + 1) KiB: fragment chunks + one aux chunk (-se*|e|^2/2)
+    int64_t stage_bytes;    // (tps*nstep + aux) KiB: fragment chunks + the aux chunk(s) (-se*|e|^2/2, 32 floats per tile)
     int64_t off_stats, off_part1, off_part2, off_en, off_eexact, off_frag, total;
     int64_t nblk1, nblk2;   // blocks of the statistics / image kernels (their partial-result arrays)
 };
@@ -47,7 +48,7 @@ VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
     int64_t cps = (int64_t)L.tps * VQ_TILE_CODES;
     L.nstages = (K + cps - 1) / cps;
     L.Kp = L.nstages * cps;
-    L.stage_bytes = ((int64_t)L.tps * L.nstep + 1) * VQ_CHUNK_BYTES;
+    L.stage_bytes = ((int64_t)L.tps * L.nstep + VQ_AUX_CHUNKS(L.tps)) * VQ_CHUNK_BYTES;
     L.off_stats = 0;
     L.nblk1 = (K + 15) / 16;                 // cb_stats_kernel: 16 codes per block
     L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
