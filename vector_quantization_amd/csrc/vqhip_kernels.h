@@ -549,7 +549,15 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
     constexpr int BM = WAVES * TT * 16;
     constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef VQ_SCALAR_WAVE
+#define VQ_SCALAR_WAVE 1
+#endif
+    // the wave index as a SCALAR: the compiler cannot tell that threadIdx.x >> 6 is wave-uniform, and everything indexed by it
+    // (the LDS-DMA request loop above all) otherwise runs as a divergent loop.  Measured (profiles/r02_scalar_wave.txt):
+    // +1.2 % at D = 256 (3.129 -> 3.093 ms at 524 288 tokens), +0.5-1 % at D >= 128, but -1.5..2.5 % at D = 32
+    // (the kernel is at its SGPR limit there): D <= 32 keeps the vector form
+    const int lane = threadIdx.x & 63;
+    const int wave = (VQ_SCALAR_WAVE && NSTEP > 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image
     // Work assignment.  STREAMK false: workgroup = (token block tb, codebook slice sl of nslices), one segment.
     // STREAMK true (small D): the (token block x stage) space, block-major, is cut into gridDim.x equal ranges — every
