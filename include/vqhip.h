@@ -40,6 +40,11 @@ const char *vqhip_last_error(void); /* host string describing the last non-zero 
 /* ---- sizes of caller-owned buffers -------------------------------------------------------------- */
 /* bytes of the prepared-codebook image produced by vqhip_codebook_prepare for a [K,D] codebook */
 int64_t vqhip_codebook_bytes(int64_t K, int D);
+/* Byte offset, inside an image prepared with VQHIP_METRIC_COS, of the fp32 [K, D] rows F.normalize(e, dim=1) the exact
+ * definition consumes (bit-identical to vqhip_normalize_rows(e)); 256-byte aligned.  Lets a caller that needs the
+ * normalised codebook again in the same step (NearestAnchor's column argmin, vq/algorithms/cvqvae/anchors.py:83-84)
+ * read it instead of normalising twice.  Not written for the L2 metric. */
+int64_t vqhip_codebook_exact_offset(int64_t K, int D);
 /* bytes of per-call scratch for vqhip_argmin / vqhip_argmin_exact / vqhip_distance over N rows.
  * (vqhip_col_argmin needs the LARGER vqhip_col_workspace_bytes, declared next to it below.)
  * Preconditions shared by every entry point (the kernels use 16-byte vector loads and do not re-check):

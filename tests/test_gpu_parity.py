@@ -151,6 +151,15 @@ def test_row_kernels(ops):
         np.testing.assert_array_equal(ops.normalize_rows(dev(v)).cpu().numpy(), co.normalize_rows(v))
 
 
+def test_prepared_cosine_image_holds_the_normalised_rows(ops):
+    """PreparedCodebook.exact_rows(): the view NearestAnchor's column pass reads instead of normalising again."""
+    for K, D in ((1000, 32), (4096, 256), (37, 24)):
+        w = torch.randn(K, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(K + D)) * 3.0
+        cb = ops.prepare_codebook(w, 'Cosine')
+        assert torch.equal(cb.exact_rows(), ops.normalize_rows(w))
+        assert ops.prepare_codebook(w, 'L2').exact_rows() is None
+
+
 def test_hist_scatter_gather(ops):
     g = synth.rng(9)
     N, K, D = 5000, 300, 32

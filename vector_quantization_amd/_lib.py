@@ -22,6 +22,7 @@ SIGNATURES = {
     'vqhip_version': (_i32, []),
     'vqhip_last_error': (ctypes.c_char_p, []),
     'vqhip_codebook_bytes': (_i64, [_i64, _i32]),
+    'vqhip_codebook_exact_offset': (_i64, [_i64, _i32]),
     'vqhip_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_col_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),

@@ -207,6 +207,11 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
+    // D = 256: 64 tokens per wave already from 4097 tokens on when the codebook is long (measured at K = 16 384: proposal
+    // kernel 76 -> 66 us at 8192 tokens, 140 -> 122 at 16 384, 74 -> 62 at 6144; at 3072 / 4096 tokens and for short
+    // codebooks — NearestAnchor's role-swapped pass has K = batch size — 32 tokens per wave stay ahead;
+    // profiles/r02_tokens_per_wave_d256.txt)
+    const bool small16 = N <= 4096 || (N <= 256 * 64 && L.K <= 4096);
     // D <= 32: 32 tokens per wave until 64-token workgroups would number two per CU (measured at N = 100 352, K = 8192:
     // proposal kernel 128 -> 108 us with 8 tiles per stage, one slice and 32 tokens per wave; at N = 524 288 the
     // 64-token form is the faster one)
@@ -250,7 +255,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
                 if (small) VQ_CFG(8, 2, 8, 4, 4, true) else VQ_CFG(8, 4, 8, 4, 4, true)
-        case 16: if (small) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
+        case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
         // large D: the token fragments of a wave must stay in registers for the whole stream
 #ifndef VQ_CFG_D512
 #define VQ_CFG_D512 VQ_CFG(32, 2, 8, 2)
@@ -322,6 +327,11 @@ extern "C" {
 
 int vqhip_version(void) { return VQHIP_VERSION; }
 const char *vqhip_last_error(void) { return g_err; }
+
+int64_t vqhip_codebook_exact_offset(int64_t K, int D) {
+    if (K <= 0 || D <= 0) return -1;
+    return vq_cb_layout(K, D).off_eexact;
+}
 
 int64_t vqhip_codebook_bytes(int64_t K, int D) {
     if (K <= 0 || D <= 0) return 0;

@@ -86,6 +86,14 @@ class PreparedCodebook:
     D: int
     metric: int
 
+    def exact_rows(self) -> Optional[torch.Tensor]:
+        """Cosine images: the fp32 rows F.normalize(weight) the exact definition consumes, as a view into the image
+        (bit-identical to ``normalize_rows(weight)``); None for L2 (the weight itself is the operand)."""
+        if self.metric != METRICS['Cosine']:
+            return None
+        off = _lib.lib().vqhip_codebook_exact_offset(self.K, self.D)
+        return self.image[off:off + self.K * self.D * 4].view(torch.float32).view(self.K, self.D)
+
 
 @_on_tensor_device
 def prepare_codebook(e: torch.Tensor, metric='L2') -> PreparedCodebook:

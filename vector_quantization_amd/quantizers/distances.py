@@ -72,14 +72,15 @@ class LazyDistance(torch.Tensor):
                            'retains_grad', '_base', 'is_nested', 'is_mkldnn', 'is_xpu', 'is_mps', 'is_cpu'})
 
     @staticmethod
-    def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor, xq: Optional[torch.Tensor] = None):
+    def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor, xq: Optional[torch.Tensor] = None,
+                eq: Optional[torch.Tensor] = None):
         return torch.Tensor._make_wrapper_subclass(cls, (x.shape[0], e.shape[0]), dtype=torch.float32, device=x.device)
 
     def __init__(self, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor,
-                 xq: Optional[torch.Tensor] = None) -> None:
-        """``xq``: the latents in the form the exact definition consumes (normalised for cosine), when the encode that
-        produced this handle has already computed them."""
-        self._distance, self._x, self._e, self._xq = distance, x, e, xq
+                 xq: Optional[torch.Tensor] = None, eq: Optional[torch.Tensor] = None) -> None:
+        """``xq`` / ``eq``: the latents / the codebook in the form the exact definition consumes (normalised for
+        cosine), when the encode that produced this handle has already computed them."""
+        self._distance, self._x, self._e, self._xq, self._eq = distance, x, e, xq, eq
         self._value: Optional[torch.Tensor] = None
 
     @property
@@ -98,7 +99,8 @@ class LazyDistance(torch.Tensor):
     def fused_argmin(self, dim: int) -> torch.Tensor:
         if dim == 0:        # NearestAnchor: d.argmin(0) — nearest latent per code
             if self._xq is not None:
-                xq, eq = self._xq, self._distance.exact_codebook(self._e)
+                xq = self._xq
+                eq = self._eq if self._eq is not None else self._distance.exact_codebook(self._e)
             else:
                 xq, eq = self._distance.exact_operands(self._x, self._e)
             return ops.col_argmin(xq, eq, self.metric)
@@ -168,6 +170,7 @@ class BaseDistance(nn.Module, ABC):
         cb = prepared if prepared is not None else self.prepare(e)
         if stash is not None:
             stash['xq'] = x.detach()
+            stash['eq'] = e.detach()
         return ops.argmin(x.detach(), cb, hist=hist)
 
 
@@ -203,4 +206,5 @@ class CosineDistance(BaseDistance):
         xn = ops.normalize_rows(x.detach())
         if stash is not None:
             stash['xq'] = xn
+            stash['eq'] = cb.exact_rows()          # normalize(e), as the image made from e holds it
         return ops.argmin(xn, cb, hist=hist)   # the image holds normalize(e)

@@ -123,9 +123,9 @@ class VectorQuantizer(BaseQuantizer):
         # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
         if torch.is_grad_enabled() and (x.requires_grad or self._embedding.weight.requires_grad):
             weight = self._embedding.weight
-            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight), xq=stash.get('xq'))
+            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight), xq=stash.get('xq'), eq=stash.get('eq'))
         else:
-            memo['distance'] = LazyDistance(self._distance, x2, w, xq=stash.get('xq'))
+            memo['distance'] = LazyDistance(self._distance, x2, w, xq=stash.get('xq'), eq=stash.get('eq'))
         if hist is not None:
             memo['hist'] = hist
         return quant.reshape(shape), memo
