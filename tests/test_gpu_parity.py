@@ -440,6 +440,39 @@ def test_randomised_shapes_sweep(ops):
         assert np.array_equal(got, ref), f'trial {trial}: N={N} K={K} D={D} {metric} {kind} scale={scale} bf16={bf16}'
 
 
+@pytest.mark.parametrize('N,K,D,metric', [(20000, 8192, 32, 'Cosine'), (16500, 1000, 32, 'Cosine'), (40000, 777, 24, 'L2'),
+                                          (70001, 4099, 8, 'L2'), (33333, 300, 16, 'Cosine')])
+def test_small_d_kernel_forms_agree(ops, N, K, D, metric):
+    """D <= 32 at >= 16 384 tokens runs the group-record form (replay identification), without aux reads for cosine
+    (a codebook that does not fill its last stage reads them there) and with balanced workgroup sizes: every
+    combination of the three knobs (8, 9, 10) returns the indices of the all-fp32 route, on the CPU oracle's definition."""
+    from vector_quantization_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(N + K + D)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    x[: N // 3] = w[torch.randint(0, K, (N // 3,), device='cuda', generator=g)] + 0.01 * x[: N // 3]   # near codes
+    w[K // 2] = w[0]                                                                                       # an exact duplicate
+    if metric == 'Cosine':
+        xq, wq = ops.normalize_rows(x), ops.normalize_rows(w)
+    else:
+        xq, wq = x, w
+    ref = ops.argmin_exact(xq, wq, metric)
+    sample = slice(0, 600)
+    oracle = (co.cos_argmin if metric == 'Cosine' else co.l2_argmin)(x[sample].cpu().numpy(), w.cpu().numpy())
+    np.testing.assert_array_equal(ref[sample].cpu().numpy(), oracle)
+    try:
+        for noaux in (0, 1):
+            for groups in (0, 1):
+                for balance in (0, 1):
+                    L.vqhip_set_tuning(8, noaux); L.vqhip_set_tuning(9, groups); L.vqhip_set_tuning(10, balance)
+                    got = ops.argmin(xq, ops.prepare_codebook(w, metric))
+                    assert torch.equal(got, ref), (noaux, groups, balance)
+    finally:
+        for key in (8, 9, 10):
+            L.vqhip_set_tuning(key, 1)
+
+
 @pytest.mark.parametrize('kind,metric,scale', [('normal', 'L2', 1.0), ('normal', 'Cosine', 1.0), ('vqgan_init', 'L2', 1.0),
                                                 ('normal', 'L2', 1e-3), ('normal', 'L2', 300.0), ('planted', 'L2', 1.0)])
 def test_margin_holds(ops, kind, metric, scale, D=256):
