@@ -40,6 +40,18 @@ const char *vqhip_last_error(void); /* host string describing the last non-zero 
 /* ---- sizes of caller-owned buffers -------------------------------------------------------------- */
 /* bytes of the prepared-codebook image produced by vqhip_codebook_prepare for a [K,D] codebook */
 int64_t vqhip_codebook_bytes(int64_t K, int D);
+/* vqhip_codebook_prepare + (cosine: vqhip_normalize_rows of x) + vqhip_argmin in one call with two launches less on the
+ * critical path: the codebook statistics and the whole token side (normalisation included) are independent and run as ONE
+ * launch.  This is the training-time shape of vq/algorithms/vq/quantizers.py:92-100, where the codebook changes every
+ * step; with a frozen codebook prepare once and call vqhip_argmin.
+ *   x [N,D] fp32|bf16: the latents as the quantizer receives them (NOT normalised, also for cosine);
+ *   cb: vqhip_codebook_bytes(K,D), written; idx [N] int64; hist [K] int32 or NULL (counts are ADDED);
+ *   xq [N,D] fp32: cosine only — receives F.normalize(x, dim=1) (bit-identical to vqhip_normalize_rows), which is also the
+ *   operand of the exact re-rank: keep it alive until the call has completed on the stream; NULL for L2;
+ *   ws: vqhip_workspace_bytes(N,K,D).  Results are those of the separate calls, bit for bit. */
+int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
+                 int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream);
+
 /* Byte offset, inside an image prepared with VQHIP_METRIC_COS, of the fp32 [K, D] rows F.normalize(e, dim=1) the exact
  * definition consumes (bit-identical to vqhip_normalize_rows(e)); 256-byte aligned.  Lets a caller that needs the
  * normalised codebook again in the same step (NearestAnchor's column argmin, vq/algorithms/cvqvae/anchors.py:83-84)

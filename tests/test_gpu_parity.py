@@ -160,6 +160,38 @@ def test_prepared_cosine_image_holds_the_normalised_rows(ops):
         assert ops.prepare_codebook(w, 'L2').exact_rows() is None
 
 
+@pytest.mark.parametrize('N,K,D,metric,dtype', [(3072, 16384, 256, 'Cosine', None), (8192, 16384, 256, 'L2', torch.bfloat16),
+                                                (20000, 8192, 32, 'Cosine', None), (1000, 777, 24, 'L2', None),
+                                                (50000, 4099, 8, 'L2', None), (513, 100, 768, 'Cosine', torch.bfloat16),
+                                                (300, 50, 1032, 'L2', None), (31, 5, 520, 'Cosine', None)])
+def test_encode_one_call_equals_separate_calls(ops, N, K, D, metric, dtype):
+    """vqhip_encode (codebook statistics + token side in one launch, cosine normalisation folded in) against
+    prepare_codebook / normalize_rows / argmin: indices, histogram, normalised rows and the prepared image's fp32 rows."""
+    g = torch.Generator(device='cuda').manual_seed(N * 7 + K)
+    w = torch.randn(K, D, device='cuda', generator=g) * 0.7
+    x = torch.randn(N, D, device='cuda', generator=g) * 3.0
+    x[::5] = w[torch.randint(0, K, (len(x[::5]),), device='cuda', generator=g)] * 1.5
+    x[1] = 0
+    if dtype is not None:
+        x = x.to(dtype)
+    cb = ops.prepare_codebook(w, metric)
+    xq_ref = ops.normalize_rows(x) if metric == 'Cosine' else x
+    h_ref = torch.zeros(K, dtype=torch.int32, device='cuda')
+    ref = ops.argmin(xq_ref, cb, hist=h_ref)
+    h = torch.zeros(K, dtype=torch.int32, device='cuda')
+    got, cb2, xq = ops.encode(x, w, metric, hist=h)
+    assert torch.equal(got, ref) and torch.equal(h, h_ref)
+    if metric == 'Cosine':
+        assert torch.equal(xq, xq_ref) and torch.equal(cb2.exact_rows(), cb.exact_rows())
+    else:
+        assert xq is None
+    # the image made by the fused front serves later argmin calls like any other
+    assert torch.equal(ops.argmin(xq_ref, cb2), ref)
+    wq = ops.normalize_rows(w) if metric == 'Cosine' else w
+    xe = xq_ref.float() if metric == 'Cosine' else x
+    assert torch.equal(got, ops.argmin_exact(xe, wq, metric))
+
+
 def test_hist_scatter_gather(ops):
     g = synth.rng(9)
     N, K, D = 5000, 300, 32

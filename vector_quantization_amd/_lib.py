@@ -23,6 +23,7 @@ SIGNATURES = {
     'vqhip_last_error': (ctypes.c_char_p, []),
     'vqhip_codebook_bytes': (_i64, [_i64, _i32]),
     'vqhip_codebook_exact_offset': (_i64, [_i64, _i32]),
+    'vqhip_encode': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_col_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),

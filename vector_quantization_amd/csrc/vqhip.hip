@@ -391,8 +391,9 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
 
 // The proposal + decision pipeline: N rows `x` against the K codes whose prepared image is `cb` and whose fp32 rows
 // (as used by the exact definition) are `e_exact`.  `metric` may carry the internal words (DOT, SWAP).
+// x_prepared: the token side (x_prep) was already produced into `ws` by pre_kernel (encode_fused_front)
 static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, const void *cb, int64_t N, int64_t K, int D,
-                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream) {
+                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream, bool x_prepared = false) {
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     VqWsLayout W = vq_ws_layout(N, K, D);
@@ -414,9 +415,11 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     int *arrive = (int *)(w + W.off_arrive);
     const int narrive = (int)(Np / 128 + 8);
     const int xgrid = (int)((N + 31) / 32);
-    if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
-    else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
-    VQ_CHECK_LAUNCH("x_prep_kernel");
+    if (!x_prepared) {
+        if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
+        else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
+        VQ_CHECK_LAUNCH("x_prep_kernel");
+    }
     // the proposal kernel also runs the decision stage (the workgroup that completes a token block merges its slices)
     VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive};
     const bool fused_decide = g_tune_fused_decide.load() != 0;
@@ -464,6 +467,56 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     }
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
     return run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, counters + 3, idx, hist, s);
+}
+
+// Front of an encode whose codebook image is made in the same call: ONE launch for the codebook statistics and the whole
+// token side (they are independent), then the image kernel.  `rows` are the N rows to quantize (normalised into `xq`
+// first when xnorm), `codes` the Kc rows the image is made from, `ws` the workspace of argmin_pipeline(N rows, Kc codes).
+static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const float *codes, int64_t Kc, int D, int cb_metric,
+                              void *cb, void *ws, bool xnorm, float *xq, hipStream_t s) {
+    VqCbLayout L = vq_cb_layout(Kc, D);
+    VqWsLayout W = vq_ws_layout(N, Kc, D);
+    char *w = (char *)ws, *c = (char *)cb;
+    const int64_t Np = (N + 63) / 64 * 64;
+    const int nblk_stats = (int)((Kc + 15) / 16), xgrid = (int)((N + 31) / 32), narrive = (int)(Np / 128 + 8);
+    int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
+    float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
+    char *ximg = w + W.off_ximg;
+#define VQ_PRE(DT, XN) pre_kernel<DT, XN><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f)
+    if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true); else VQ_PRE(0, false); }
+    else { if (xnorm) VQ_PRE(1, true); else VQ_PRE(1, false); }
+#undef VQ_PRE
+    VQ_CHECK_LAUNCH("pre_kernel");
+    cb_image_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(codes, Kc, D, cb_metric, c, L);
+    VQ_CHECK_LAUNCH("cb_image_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
+                 int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream) {
+    if (N == 0) return e && cb && K > 0 && D > 0 ? vqhip_codebook_prepare(e, K, D, metric, cb, stream) : fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
+    if (!x || !e || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_encode: metric");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: x_dtype");
+    if (metric == VQHIP_METRIC_COS && !xq) return fail(VQHIP_EINVAL, "vqhip_encode: the cosine metric needs the xq buffer");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_encode: N or K too large");
+    if (!vq_coarse_supported(D)) {          // no fp16 proposal image for this D: the separate entry points do the work
+        if (int rc = vqhip_codebook_prepare(e, K, D, metric, cb, stream)) return rc;
+        const void *rows = x; int rows_dtype = x_dtype;
+        if (metric == VQHIP_METRIC_COS) {
+            if (int rc = vqhip_normalize_rows(x, x_dtype, N, D, 1e-12f, xq, stream)) return rc;
+            rows = xq; rows_dtype = VQHIP_DTYPE_F32;
+        }
+        return vqhip_argmin(rows, rows_dtype, e, cb, N, K, D, metric, idx, hist, ws, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool cos = metric == VQHIP_METRIC_COS;
+    if (int rc = encode_fused_front(x, x_dtype, N, e, K, D, metric, cb, ws, cos, xq, s)) return rc;
+    VqCbLayout L = vq_cb_layout(K, D);
+    const float *e_exact = cos ? (const float *)((const char *)cb + L.off_eexact) : e;
+    // from here on the rows are what vqhip_argmin would have been given: the normalised fp32 rows for cosine
+    return argmin_pipeline(cos ? (const void *)xq : x, cos ? VQHIP_DTYPE_F32 : x_dtype, e_exact, cb, N, K, D, metric, idx, hist, ws,
+                           stream, /*x_prepared=*/true);
 }
 
 int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
@@ -550,9 +603,10 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
             codes = copy;
         }
         const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : VQ_METRIC_DOT;
-        int rc = codebook_prepare_impl(codes, N, D, m, img, stream);
+        // statistics of the latents-as-codebook and the token side of the codes-as-rows in one launch, then the image
+        int rc = encode_fused_front(e, VQHIP_DTYPE_F32, K, codes, N, D, m, img, pipe_ws, false, nullptr, s);
         if (rc) return rc;
-        return argmin_pipeline(e, VQHIP_DTYPE_F32, codes, img, K, N, D, m, col_idx, nullptr, pipe_ws, stream);
+        return argmin_pipeline(e, VQHIP_DTYPE_F32, codes, img, K, N, D, m, col_idx, nullptr, pipe_ws, stream, /*x_prepared=*/true);
     }
     VqWsLayout W = vq_ws_layout(N, K, D);
     u64 *keys = (u64 *)(w + W.off_keys);

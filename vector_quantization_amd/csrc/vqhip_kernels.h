@@ -196,6 +196,22 @@ __device__ __forceinline__ void atomic_max_filtered(uint32_t *p, uint32_t v) {
 // C/D register -> row of the 32x32 MFMA tile (v_mfma_f32_32x32x2_f32, MI355X guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// The statistics header as the margin consumes it: header words + the maxima of the VQ_CB_SLOTS slots cb_image_kernel raised
+// (lanes 0..15 load one slot each, a 16-lane shuffle tree folds them).  Wave-level: every lane of the wave must call it.
+__device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
+    VqCbStats v = *st;
+    const int lane = threadIdx.x & 63;
+    const uint32_t *slot = (const uint32_t *)((const char *)st + 256 + (lane & (VQ_CB_SLOTS - 1)) * 128);
+    uint32_t r = slot[0], h = slot[1], bad = slot[2];
+#pragma unroll
+    for (int off = VQ_CB_SLOTS / 2; off >= 1; off >>= 1) {
+        const uint32_t r2 = __shfl_xor(r, off, 64), h2 = __shfl_xor(h, off, 64), b2 = __shfl_xor(bad, off, 64);
+        r = r > r2 ? r : r2; h = h > h2 ? h : h2; bad |= b2;
+    }
+    v.r2max_bits = r; v.eh2max_bits = h; v.nonfinite |= bad;
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // row kernels: oracle-order |v|^2 and F.normalize
 // ------------------------------------------------------------------------------------------------
@@ -237,13 +253,18 @@ __device__ __forceinline__ float block_max4(float v, float *red) {    // max ove
 // pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
 // The four rows of a wave are loaded together and reduced with interleaved shuffle trees; maxima are reduced per
 // block and written as one partial per block (same-line atomics from ~1000 concurrent blocks cost ~25 us).
-__global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+__device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64_t K, int D, int metric, char *cb, const VqCbLayout &L) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
     float *en = (float *)(cb + L.off_en);
     float *ex = (float *)(cb + L.off_eexact);
-    const int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    // the maxima slots cb_image_kernel (the next launch) raises start from zero
+    if (blk == 0 && threadIdx.x < VQ_CB_SLOTS) {
+        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + threadIdx.x * 128);
+        slot[0] = 0u; slot[1] = 0u; slot[2] = 0u;
+    }
+    const int64_t k0 = (blk * 4 + wave) * 4;
     float p[4] = {0, 0, 0, 0}, amax = 0.0f;
     bool bad = false;
     for (int d = lane; d < D; d += 64) {
@@ -291,8 +312,11 @@ __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K
     amax = block_max4(amax, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
     float badf = block_max4(bad ? 1.0f : 0.0f, red);
     // per-block partial result; reduced by every block of cb_image_kernel (no hot-word atomics, no memset)
-    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part1))[blockIdx.x] = f32x4{amax, m_e2, m_en, badf};
+    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part1))[blk] = f32x4{amax, m_e2, m_en, badf};
     (void)st;
+}
+__global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
 }
 
 // pass 2 (one 256-thread block per tile of 32 codes): the MFMA-fragment-major fp16 image, the aux chunk, and the fp16
@@ -325,8 +349,8 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
         g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
-            st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 0u;
-            st->r2max_bits = 0u; st->eh2max_bits = 0u;
+            st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 1u;
+            st->r2max_bits = 0u; st->eh2max_bits = 0u;       // (the image's own maxima live in the slots: cb_stats_view)
         }
     }
     const float se = cb_scale(&g_st), inv = 1.0f / se;
@@ -376,25 +400,18 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     a = wave_max(a); b = wave_max(b);       // waves 1..3 contribute zeros
     a = block_max4(a, red4); b = block_max4(b, red4);
     float badf = block_max4(__any(bad) ? 1.0f : 0.0f, red4);
-    if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part2))[blockIdx.x] = f32x4{a, b, badf, 0.0f};
-}
-
-// Folds the image kernel's per-block partials into the statistics header (run by block 0 of the first kernel of every
-// consumer call; idempotent).
-__device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L, float *red4) {
-    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
-    const f32x4 *part = (const f32x4 *)(cb + L.off_part2);
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    for (int64_t i = threadIdx.x; i < L.nblk2; i += blockDim.x) {
-        f32x4 v = part[i];
-        a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]);
-    }
-    a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2);
-    a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4);
+    // max fp16 residual / image norm / non-finite flag of this tile go into one of VQ_CB_SLOTS slots (zeroed by cb_stats_kernel,
+    // the launch before) with fire-and-forget atomics — a 128-byte line per slot, K/512 atomics per word — and every consumer
+    // wave folds the 16 slots itself (cb_stats_view): the image is complete when its launch is, no consumer kernel has to run
+    // a fold first, so the token side can be prepared in the same launch as the codebook statistics (pre_kernel).
+    // (Tried first: an arrival ticket with the last workgroup folding per-block partials — its agent-scope release writes the
+    // XCD's dirty L2 lines, i.e. the image, back: 8.5 -> 19 us at K = 16 384, D = 256; and read-then-atomic on three header
+    // words — two dependent device-scope round trips at the end of every workgroup: 15 us.)
     if (threadIdx.x == 0) {
-        st->r2max_bits = __float_as_uint(a0); st->eh2max_bits = __float_as_uint(a1);
-        if (a2 > 0.0f) st->nonfinite = 1u;
-        st->finalized = 1u;
+        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + (blockIdx.x % VQ_CB_SLOTS) * 128);
+        atomicMax(&slot[0], __float_as_uint(a));
+        atomicMax(&slot[1], __float_as_uint(b));
+        if (badf > 0.0f) atomicMax(&slot[2], 1u);
     }
 }
 
@@ -403,22 +420,21 @@ __device__ __forceinline__ void cb_finalize_stats(char *cb, const VqCbLayout &L,
 // ------------------------------------------------------------------------------------------------
 // One 256-thread block per 32 tokens.  Image chunk (tile of 16 tokens, k-step s of 32 dims) holds for lane l the dims
 // 32s + 8(l>>4) .. +8 of token tile*16 + (l&15): the B operand of v_mfma_f32_16x16x32_f16.
-template <int DT>
-__global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
-                                                     char *__restrict__ ximg, float *__restrict__ xh2,
-                                                     float *__restrict__ rho2, float *__restrict__ xn,
-                                                     int *__restrict__ counters, char *cb, VqCbLayout L,
-                                                     int *__restrict__ arrive = nullptr, int narrive = 0) {
+// XNORM (cosine through vqhip_encode): the rows are first normalised exactly as normalize_rows_kernel does — the
+// oracle-order |x|^2 this kernel computes anyway is that kernel's sum — written to `xq` as fp32, and everything else
+// (image, |xh|^2, residual, |x|^2) is taken from the normalised rows: one launch less, one pass over x less.
+template <int DT, bool XNORM = false>
+__device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict__ x, int64_t N, int D, int nstep,
+                                            char *__restrict__ ximg, float *__restrict__ xh2,
+                                            float *__restrict__ rho2, float *__restrict__ xn,
+                                            int *__restrict__ counters, int *__restrict__ arrive, int narrive,
+                                            float *__restrict__ xq, float eps) {
     __shared__ float red[2][8][32];
     __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
-    __shared__ float red4[4];
-    if (blockIdx.x == 0) {   // housekeeping for the later kernels of this call (stream-ordered)
-        if (threadIdx.x < 8) counters[threadIdx.x] = 0;
-        cb_finalize_stats(cb, L, red4);
-    }
+    __shared__ float den_s[32];
+    if (blk == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // housekeeping for the later kernels of this call (stream-ordered)
     // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
-    if (arrive != nullptr && threadIdx.x == 0 && (int64_t)blockIdx.x < narrive) arrive[blockIdx.x] = 0;
-    const int64_t blk = blockIdx.x;
+    if (arrive != nullptr && threadIdx.x == 0 && blk < narrive) arrive[blk] = 0;
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t t = blk * 32 + r;
     const bool tvalid = t < N;
@@ -430,6 +446,37 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
     float pn[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) pn[j] = 0.0f;
+    float den = 1.0f;
+    if constexpr (XNORM) {
+        for (int piece = g; piece < ns32 * 4; piece += 8) {
+            const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
+            if (tvalid && d0 < D) {
+                float v[8];
+                load8<DT>(x, trow * D + d0, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pn[j] = fmaf(v[j], v[j], pn[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[8 * g + j][r] = pn[j];
+        __syncthreads();
+        if (g == 0) {                    // halving tree 32, 16, ..., 1 over the partials (normalize_rows_kernel's order)
+            float q[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) q[j] = part[j][r] + part[j + 32][r];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < off) q[j] = q[j] + q[j + off];
+            const float nrm = sqrtf(q[0]);
+            den_s[r] = (nrm < eps) ? eps : nrm;
+        }
+        __syncthreads();
+        den = den_s[r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pn[j] = 0.0f;
+    }
     for (int piece = g; piece < ns32 * 4; piece += 8) {
         const int s = piece >> 2, q4 = piece & 3;
         const int d0 = 32 * s + 8 * q4;
@@ -437,6 +484,12 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
         if (tvalid && d0 < D) {
             float v[8];
             load8<DT>(x, trow * D + d0, v);
+            if constexpr (XNORM) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] / den;
+                *(f32x4 *)(xq + trow * D + d0) = f32x4{v[0], v[1], v[2], v[3]};
+                *(f32x4 *)(xq + trow * D + d0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 _Float16 q = to_f16_ftz(v[j]);
@@ -472,6 +525,26 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
                 if (j < off) q[j] = q[j] + q[j + off];
         xn[t] = q[0];
     }
+}
+template <int DT>
+__global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x, int64_t N, int D, int nstep,
+                                                     char *__restrict__ ximg, float *__restrict__ xh2,
+                                                     float *__restrict__ rho2, float *__restrict__ xn,
+                                                     int *__restrict__ counters, char *cb, VqCbLayout L,
+                                                     int *__restrict__ arrive = nullptr, int narrive = 0) {
+    x_prep_body<DT, false>(blockIdx.x, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, nullptr, 0.0f);
+}
+// vqhip_encode / vqhip_col_argmin: the codebook statistics and the token side in ONE launch (they are independent;
+// the image kernel that follows needs the former, the proposal kernel both)
+template <int DT, bool XNORM>
+__global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int metric, char *cb, VqCbLayout L, int nblk_stats,
+                                                  const void *__restrict__ x, int64_t N, int D, int nstep,
+                                                  char *__restrict__ ximg, float *__restrict__ xh2,
+                                                  float *__restrict__ rho2, float *__restrict__ xn,
+                                                  int *__restrict__ counters, int *__restrict__ arrive, int narrive,
+                                                  float *__restrict__ xq, float eps) {
+    if ((int)blockIdx.x < nblk_stats) cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
+    else x_prep_body<DT, XNORM>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,11 +676,12 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     static_assert(!FILTER || PIPE, "the filtered epilogue is written for the ping-pong form");
     float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;     // destinations of the asm maxima: live across the whole loop (see vmax3_into)
     if constexpr (FILTER) {
+        const VqCbStats stv = cb_stats_view(cbst);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
             tokn = tokn < N ? tokn : N - 1;
-            const float m = row_margin(cbst, Dp, metric, xh2[tokn], rho2[tokn]);
+            const float m = row_margin(&stv, Dp, metric, xh2[tokn], rho2[tokn]);
             mg[t] = (m > 0.0f) ? m : INFINITY;                 // no usable bound: threshold -inf, nothing is skipped
         }
     }
@@ -1067,7 +1141,8 @@ template <int NSL, bool AGENT>
 __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                                  const float *rec, const float *xh2, const float *rho2, int64_t Np,
                                                  const VqDecideOut &o, int *wcount, int *wbase) {
-    const float m = row_margin(st, Dp, metric, xh2[n], rho2[n]);
+    const VqCbStats stv = cb_stats_view(st);
+    const float m = row_margin(&stv, Dp, metric, xh2[n], rho2[n]);
     bool invalid = !(m > 0.0f);
     float gbest = -INFINITY;
     int nc = 0;
@@ -1300,7 +1375,8 @@ __device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave,
                                             u64 *__restrict__ keys) {
     constexpr int XL = DT == 0 ? 8 : 4;                       // lanes per 32-dim latent row piece (16 bytes each)
     const int lane = threadIdx.x & 63;
-    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const VqCbStats stv = cb_stats_view((const VqCbStats *)(cb + L.off_stats));
+    const VqCbStats *st = &stv;
     const float *en = (const float *)(cb + L.off_en);
     const int nrows = counters[SRC == 0 ? 1 : 0];
     const int P = S < 16 ? 16 : S;                            // pairs per wave (16 or 32)
@@ -2466,7 +2542,8 @@ __global__ __launch_bounds__(256) void debug_scores_kernel(const char *__restric
 __global__ void debug_margin_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, const float *xh2, const float *rho2,
                                     float *margin, float *scale) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const VqCbStats *st = (const VqCbStats *)(cb + L.off_stats);
+    const VqCbStats stv = cb_stats_view((const VqCbStats *)(cb + L.off_stats));
+    const VqCbStats *st = &stv;
     if (n == 0) scale[0] = cb_scale(st);
     if (n < N) margin[n] = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
 }

@@ -7,6 +7,7 @@
 #define VQ_CHUNK_BYTES 1024        // one wave-instruction of global_load_lds_dwordx4
 #define VQ_AUX_CHUNKS(tps) (((tps) * 128 + VQ_CHUNK_BYTES - 1) / VQ_CHUNK_BYTES)   // aux values: 32 floats per code tile
 #define VQ_MAX_SLICES 16
+#define VQ_CB_SLOTS 16             // slots (128-byte lines behind the 256-byte header) the image kernel's blocks raise their maxima into
 #define VQ_REC_FIELDS 5            // v1, c1, v2, c2, v3
 
 #if defined(__HIPCC__)
@@ -52,8 +53,9 @@ VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
     L.off_stats = 0;
     L.nblk1 = (K + 15) / 16;                 // cb_stats_kernel: 16 codes per block
     L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
-    L.off_part1 = 256;                       // float4 {max|e|, max e2, max en, bad} per stats block
-    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // float4 {max r2, max eh2, bad, 0} per image block
+    // [256, 256 + 16*128): VQ_CB_SLOTS maxima slots of cb_image_kernel, one 128-byte line each (see cb_stats_view)
+    L.off_part1 = 256 + VQ_CB_SLOTS * 128;   // float4 {max|e|, max e2, max en, bad} per stats block
+    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // (unused since round 2: the image kernel raises the header maxima itself)
     L.off_en = (L.off_part2 + L.nblk2 * 16 + 255) / 256 * 256;
     L.off_eexact = (L.off_en + L.Kp * 4 + 255) / 256 * 256;
     L.off_frag = (L.off_eexact + K * (int64_t)D * 4 + 1023) / 1024 * 1024;
@@ -70,7 +72,7 @@ struct VqCbStats {
     uint32_t enmax_bits;    // max_k oracle |e_k|^2 (0 for COS)
     uint32_t nonfinite;     // !=0: some entry is NaN/Inf (or overflows the fp16 image)
     int32_t metric;
-    uint32_t finalized;     // r2max/eh2max folded in from the image kernel's partials (first consumer call does it)
+    uint32_t finalized;     // the image kernel has run (r2max/eh2max/nonfinite are raised by it with filtered atomics)
 };
 
 struct VqWsLayout {

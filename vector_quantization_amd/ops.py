@@ -134,6 +134,32 @@ def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] =
 
 
 @_on_tensor_device
+def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None):
+    """``prepare_codebook`` + (cosine: ``normalize_rows(x)``) + ``argmin`` as ONE library call with two launches less:
+    the training-time encode, where the codebook changes every step.  x are the latents as the quantizer receives them
+    (not normalised).  Returns (idx, prepared codebook, xq) — xq = the normalised latents for cosine, None for L2;
+    every value is that of the separate calls, bit for bit."""
+    _require_cuda(x, e)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    if D != e.shape[1]:
+        raise ValueError(f'latent dim {D} != codebook dim {e.shape[1]}')
+    m = METRICS[metric]
+    L = _lib.lib()
+    image = _bytes(L.vqhip_codebook_bytes(K, D), e.device)
+    idx = torch.empty(N, dtype=torch.int64, device=x.device)
+    xq = torch.empty(N, D, dtype=torch.float32, device=x.device) if metric == 'Cosine' else None
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
+    if hist is not None:
+        assert hist.dtype == torch.int32 and hist.numel() == K and hist.is_contiguous()
+    check(L.vqhip_encode(_ptr(x), dt, _ptr(e), N, K, D, m, _ptr(image), _ptr(idx), _ptr(hist), _ptr(xq), _ptr(ws),
+                         _stream()), 'vqhip_encode')
+    return idx, PreparedCodebook(image, e, K, D, m), xq
+
+
+@_on_tensor_device
 def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None,
                  return_min: bool = False):
     """Same contract as ``argmin`` evaluated entirely with fp32 MFMA (x, e normalised by the caller for cosine)."""

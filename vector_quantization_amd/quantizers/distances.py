@@ -163,6 +163,23 @@ class BaseDistance(nn.Module, ABC):
     def prepare(self, e: torch.Tensor) -> ops.PreparedCodebook:
         return ops.prepare_codebook(e, self.metric)
 
+    def encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
+               stash: Optional[dict] = None) -> torch.Tensor:
+        """``argmin`` for a codebook that has no prepared image yet (it changes every training step).  The shipped
+        distances do image, token side and, for cosine, the normalisation of x in one library call (``_fused_encode``);
+        a subclass that only customises ``prepare`` / ``argmin`` gets exactly those."""
+        return self.argmin(x, e, hist=hist, prepared=self.prepare(e), stash=stash)
+
+    def _fused_encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor],
+                      stash: Optional[dict]) -> torch.Tensor:
+        quant, cb, xq = ops.encode(x.detach(), e.detach(), self.metric, hist=hist)
+        if stash is not None:
+            stash['xq'] = xq if xq is not None else x.detach()
+            rows = cb.exact_rows()
+            stash['eq'] = rows if rows is not None else e.detach()
+            stash['prepared'] = cb
+        return quant
+
     def argmin(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
                prepared: Optional[ops.PreparedCodebook] = None, stash: Optional[dict] = None) -> torch.Tensor:
         """torch.argmin(self(x, e), -1) without materialising the matrix.  ``stash['xq']`` receives the latents as the
@@ -182,6 +199,9 @@ class L2Distance(BaseDistance):
         """torch.cdist(x, e) (mm path), fp32, differentiable."""
         return _L2Matrix.apply(x, e)
 
+    def encode(self, x, e, hist=None, stash=None):
+        return self._fused_encode(x, e, hist, stash)
+
 
 @VQITQuantizerDistanceRegistry.register_()
 class CosineDistance(BaseDistance):
@@ -200,6 +220,9 @@ class CosineDistance(BaseDistance):
 
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         return _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
+
+    def encode(self, x, e, hist=None, stash=None):
+        return self._fused_encode(x, e, hist, stash)
 
     def argmin(self, x, e, hist=None, prepared=None, stash=None):
         cb = prepared if prepared is not None else self.prepare(e)

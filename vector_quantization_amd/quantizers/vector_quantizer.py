@@ -117,7 +117,10 @@ class VectorQuantizer(BaseQuantizer):
         if self.training and len(self._callbacks.callbacks) > 0:
             hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
         stash = {}
-        quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w), stash=stash)
+        if self._cache_codebook:
+            quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w), stash=stash)
+        else:                                   # the codebook may have changed since the last call: image made in the same call
+            quant = self._distance.encode(x2, w, hist=hist, stash=stash)
         # memo['distance'] stays symbolic.  With autograd on, its operands keep their graph (EntropyLoss differentiates
         # through the matrix: losses.py:130-153); the codebook operand is an alias of the CURRENT weight storage, so the
         # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
