@@ -1967,12 +1967,16 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
             double t = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) t += red[i];
-            atomicAdd(sse, t);
-            if (mse) {
+            if (!mse) {
+                atomicAdd(sse, t);
+            } else {
                 int *ticket = (int *)(sse + 1);
-                __threadfence();                                   // the sum above is performed before the ticket is taken
+                // the sum must be performed before the ticket is taken: a RETURNING atomic is complete when its value is
+                // back, so waiting for the value orders the two without a release fence (an agent-scope __threadfence()
+                // writes the XCD's dirty L2 lines back — this kernel's own 0.5 GB of output — at every workgroup's end)
+                const double before = atomicAdd(sse, t);
+                asm volatile("" :: "v"(before) : "memory");
                 if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
-                    __threadfence();
                     const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const float mean = (float)(total / ((double)N * (double)D));
                     mse[0] = mean; mse[1] = mean;
