@@ -21,9 +21,15 @@ def shape(name, N, K, D, metric, normalize=False, dtype=torch.float32):
         cb = ops.prepare_codebook(ww, metric)
         xq = ops.normalize_rows(xx) if metric == 'Cosine' else xx
         return ops.argmin(xq, cb, return_stats=True)
+    def enc1():             # the same work as ONE library call (vqhip_encode: two or three launches less)
+        ww, xx = w, x
+        if normalize: ww, xx = ops.normalize_rows(w), ops.normalize_rows(x)
+        return ops.encode(xx, ww, metric)[0]
     idx, st = enc(); t = timeit(lambda: enc())
+    assert torch.equal(enc1(), idx)
+    t1 = timeit(lambda: enc1())
     print(f'{name:34s} N={N:7d} K={K:5d} D={D:3d} {metric:6s}: {t*1e3:8.3f} ms  {N/t/1e6:8.1f} Mtok/s  '
-          f'rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])}', flush=True)
+          f'one call {t1*1e3:8.3f} ms {N/t1/1e6:8.1f} Mtok/s  rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])}', flush=True)
 
 shape('C1 VQGAN small', 1024, 1024, 256, 'L2')
 shape('C2 VQGAN 32 img bf16', 8192, 16384, 256, 'L2', dtype=torch.bfloat16)
