@@ -232,9 +232,11 @@ def main():
 
         qt = build_module(quantizer_cfg(K, D, 'L2'), dev, w, train=True)
         xt = x.clone().requires_grad_(True)
+        qt_params = list(qt.parameters())
 
         def train_step():
-            qt.zero_grad(set_to_none=True)
+            for p_ in qt_params:                 # what an optimizer's zero_grad(set_to_none=True) does with its parameter list
+                p_.grad = None
             xt.grad = None
             z, loss, _ = qt(xt, {})
             (loss + z.float().mean()).backward()
@@ -252,9 +254,11 @@ def main():
         x = torch.randn(N, D, device=dev, generator=g).requires_grad_(True)     # codebook identical on all ranks, latents per rank
         cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
         q = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
+        q_params = list(q.parameters())
 
         def step():
-            q.zero_grad(set_to_none=True)
+            for p_ in q_params:
+                p_.grad = None
             x.grad = None
             z, loss, memo = q(x, {})
             (loss + z.mean()).backward()
@@ -266,11 +270,13 @@ def main():
             from vector_quantization_amd.graphs import GraphedQuantizer
             qg = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
             xg = x.detach().clone().requires_grad_(True)
+            qg_params = list(qg.parameters())
             try:
                 gq = GraphedQuantizer(qg, xg.detach())
 
                 def graph_step():
-                    qg.zero_grad(set_to_none=True)
+                    for p_ in qg_params:
+                        p_.grad = None
                     xg.grad = None
                     z, loss, _ = gq(xg)
                     (loss + z.mean()).backward()

@@ -20,7 +20,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of the current stream of the current device.  (The raw accessor: `torch.cuda.current_stream()`
+    builds a Stream object per call — 11 us each, five calls per training step in the eager CVQ-VAE profile.)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -251,7 +258,7 @@ _MSE_SCRATCH: dict = {}      # (device index, stream) -> 16 zeroed bytes the ker
 
 
 def _mse_scratch(device: torch.device) -> torch.Tensor:
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _MSE_SCRATCH.get(key)
     if buf is None:
         buf = _MSE_SCRATCH[key] = torch.zeros(16, dtype=torch.uint8, device=device)
