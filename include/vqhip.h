@@ -26,6 +26,11 @@ extern "C" {
 
 #define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
 #define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
+/* CosineDistance as the reference's GPU runs evaluate it under bf16 autocast (vq/runners/base.py:30-48: normalize is on
+ * autocast's fp32 list, the einsum on its bf16 list): operands rounded to bf16 after the fp32 normalisation, products
+ * summed in fp32 (here: the k-ordered fma chain of the fp32 definition), the sum rounded to bf16, 1 - s rounded to bf16,
+ * lowest index among equal bf16 distances.  Opt-in; the default cosine metric is the fp32 definition. */
+#define VQHIP_METRIC_COS_BF16 5
 
 #define VQHIP_DTYPE_F32 0
 #define VQHIP_DTYPE_BF16 1

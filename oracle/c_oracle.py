@@ -40,7 +40,7 @@ def lib() -> ctypes.CDLL:
         L.vqo_normalize_rows.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, _f32p]
         for name in ('vqo_l2_dist', 'vqo_cos_dist'):
             getattr(L, name).argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _f32p]
-        for name in ('vqo_l2_argmin', 'vqo_cos_argmin'):
+        for name in ('vqo_l2_argmin', 'vqo_cos_argmin', 'vqo_cos_bf16_argmin'):
             getattr(L, name).argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                          _i64p, _f32p]
         for name in ('vqo_col_argmin', 'vqo_row_argmin'):
@@ -120,6 +120,12 @@ def l2_argmin(x, e, with_min: bool = False):
 def cos_argmin(x, e, with_min: bool = False):
     """VectorQuantizer._encode with CosineDistance."""
     return _argmin('vqo_cos_argmin', x, e, with_min)
+
+
+def cos_bf16_argmin(x, e, with_min: bool = False):
+    """VectorQuantizer._encode with CosineDistance under the reference's bf16 autocast (vq/runners/base.py:30-48):
+    bf16 operands after the fp32 normalisation, bf16 similarity and distance, lowest index on ties."""
+    return _argmin('vqo_cos_bf16_argmin', x, e, with_min)
 
 
 def col_argmin(d) -> np.ndarray:

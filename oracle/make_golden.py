@@ -151,6 +151,35 @@ def encode_case(name, kind, seed, N, K, D, distance, normalize, loss):
     return rec
 
 
+def autocast_cases():
+    """CosineDistance.forward inside torch.autocast(bf16) — what the reference's trainers and validators run on a GPU
+    (vq/runners/base.py:30-48 injects the autocast callback; F.normalize is on autocast's fp32 list, the einsum on its
+    bf16 list): bf16 distance matrix, argmin with the lowest index on ties.  Executed here with the reference's own
+    CosineDistance under CPU autocast; pins oracle `cos_bf16_argmin` (the opt-in VQHIP_METRIC_COS_BF16)."""
+    ref = ref_import.load()
+    dist = ref.CosineDistance()
+    for name, kind, seed, N, K, D in (('cosbf16_c3_unit', 'unit', 3407, 1568, 8192, 32),
+                                      ('cosbf16_normal_d256', 'normal', 12, 768, 4096, 256),
+                                      ('cosbf16_int_small', 'int', 3, 64, 48, 16)):
+        x, w = synth.make_inputs(kind, seed, N, K, D)
+        with torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+            d = dist(torch.from_numpy(x), torch.from_numpy(w))
+        assert d.dtype == torch.bfloat16
+        quant = d.argmin(-1)
+        rec = dict(spec=json.dumps(dict(name=name, kind=kind, seed=seed, N=N, K=K, D=D, distance='CosineBF16',
+                                        torch=torch.__version__, source='reference-import',
+                                        reference=['vq/algorithms/vq/distances.py:35-46', 'vq/runners/base.py:30-48',
+                                                   'vq/algorithms/vq/quantizers.py:97-99'])),
+                   x_sha=synth.sha(x), w_sha=synth.sha(w), quant=quant.numpy().astype(np.int32),
+                   mind=d.gather(1, quant.reshape(-1, 1)).reshape(-1).float().numpy(),
+                   col_idx=d.argmin(0).numpy().astype(np.int32),
+                   differs_from_fp32=np.int32(int((quant != dist(torch.from_numpy(x), torch.from_numpy(w)).argmin(-1)).sum())))
+        if N * D + K * D <= 1 << 14:
+            rec['x'] = x; rec['w'] = w
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **rec)
+        print(f"{name:28s} rows that differ from the fp32 argmin: {int(rec['differs_from_fp32'])}/{N}", flush=True)
+
+
 def special_case():
     """NaN / Inf handling of cdist + argmin (torch: NaN is the minimum, first NaN wins) through the real _encode."""
     N, K, D = 32, 64, 32
@@ -481,6 +510,8 @@ def main(only=(), out_dir=None, quiet=False):
             continue
         rec = encode_case(*c)
         print_(f'{c[0]:28s} loss={float(rec["loss"]):.6f} used={int((rec["hist"] > 0).sum())}/{c[4]}', flush=True)
+    if not only or 'autocast' in only:
+        autocast_cases()
     if not only or 'special' in only:
         special_case()
     if not only or 'update' in only:

@@ -168,6 +168,45 @@ void vqo_cos_argmin(const float *x, const float *e, int64_t N, int64_t K, int D,
     free(eT); free(eh); free(xh);
 }
 
+/* fp32 -> nearest bf16, ties to even, as fp32 (torch's Tensor.bfloat16()). */
+static float bf16_rne(float v) {
+    uint32_t b; memcpy(&b, &v, 4);
+    if ((b & 0x7F800000u) == 0x7F800000u) return v;
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    b &= 0xFFFF0000u;
+    memcpy(&v, &b, 4);
+    return v;
+}
+
+/* CosineDistance.forward as evaluated under the reference's bf16 autocast (vq/runners/base.py:30-48 wraps the forward in
+ * torch.autocast; F.normalize is on autocast's fp32 list, torch.einsum -> mm on its bf16 list; distances.py:39-46):
+ *   xh = normalize(x), eh = normalize(e) in fp32;  s = bf16( sum_c bf16(xh)*bf16(eh) )  (fp32 accumulation, here the
+ *   k-ordered fma chain);  d = bf16(1 - s);  argmin over the bf16 values, lowest index on ties.
+ * d (optional): the [N,K] matrix of bf16-valued distances. */
+void vqo_cos_bf16_argmin(const float *x, const float *e, int64_t N, int64_t K, int D,
+                         int64_t *idx, float *mind) {
+    float *xh = (float *)malloc(sizeof(float) * (size_t)N * (size_t)D);
+    float *eh = (float *)malloc(sizeof(float) * (size_t)K * (size_t)D);
+    vqo_normalize_rows(x, N, D, 1e-12f, xh);
+    vqo_normalize_rows(e, K, D, 1e-12f, eh);
+    for (int64_t i = 0; i < N * (int64_t)D; ++i) xh[i] = bf16_rne(xh[i]);
+    for (int64_t i = 0; i < K * (int64_t)D; ++i) eh[i] = bf16_rne(eh[i]);
+    float *eT = transpose_kd(eh, K, D);
+#pragma omp parallel
+    {
+        float *row = (float *)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            dot_chain_row(xh + n * (int64_t)D, 1.0f, eT, K, D, row);
+            float best = bf16_rne(1.0f - bf16_rne(row[0])); int64_t bi = 0;
+            for (int64_t k = 1; k < K; ++k) argmin_update(bf16_rne(1.0f - bf16_rne(row[k])), k, &best, &bi);
+            idx[n] = bi; if (mind) mind[n] = best;
+        }
+        free(row);
+    }
+    free(eT); free(eh); free(xh);
+}
+
 /* d.argmin(0) on a materialised [N,K] matrix: for each code the nearest token, lowest n on ties. */
 void vqo_col_argmin(const float *d, int64_t N, int64_t K, int64_t *idx) {
 #pragma omp parallel for schedule(static)

@@ -24,9 +24,13 @@ def _encode_files():
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, '*.npz'))):
         z = np.load(p)
-        if 'spec' in z.files and 'quant' in z.files and 'kind' in json.loads(str(z['spec'])):
+        if 'spec' in z.files and 'quant' in z.files and 'kind' in json.loads(str(z['spec'])) \
+                and json.loads(str(z['spec'])).get('distance') != 'CosineBF16':
             out.append(p)
     return out
+
+
+AUTOCAST_FILES = sorted(glob.glob(os.path.join(GOLDEN, 'cosbf16_*.npz')))
 
 
 ENCODE_FILES = _encode_files()
@@ -190,6 +194,60 @@ def test_encode_one_call_equals_separate_calls(ops, N, K, D, metric, dtype):
     wq = ops.normalize_rows(w) if metric == 'Cosine' else w
     xe = xq_ref.float() if metric == 'Cosine' else x
     assert torch.equal(got, ops.argmin_exact(xe, wq, metric))
+
+
+@pytest.mark.parametrize('path', AUTOCAST_FILES, ids=[os.path.basename(p)[:-4] for p in AUTOCAST_FILES])
+def test_bf16_autocast_cosine_matches_reference(ops, path):
+    """VQHIP_METRIC_COS_BF16 (opt-in: CosineDistance(autocast='bf16')) against the reference's own CosineDistance run
+    inside torch.autocast(bf16) (fixtures) and against the oracle's definition: row argmin through the one-call
+    encode, the separate calls and the fp32-only route, the bf16-valued minima, and NearestAnchor's column argmin."""
+    z = np.load(path)
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs(spec['kind'], spec['seed'], spec['N'], spec['K'], spec['D'])
+    want = z['quant'].astype(np.int64)
+    xd, wd = dev(x), dev(w)
+    got, cb, xq = ops.encode(xd, wd, 'CosineBF16')
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    xn = ops.normalize_rows(xd).bfloat16().float()
+    wn = ops.normalize_rows(wd).bfloat16().float()
+    assert torch.equal(xq, xn) and torch.equal(cb.exact_rows(), wn)
+    np.testing.assert_array_equal(ops.argmin(xn, ops.prepare_codebook(wd, 'CosineBF16')).cpu().numpy(), want)
+    idx2, dmin = ops.argmin_exact(xn, wn, 'CosineBF16', return_min=True)
+    np.testing.assert_array_equal(idx2.cpu().numpy(), want)
+    np.testing.assert_array_equal(dmin.cpu().numpy(), z['mind'])
+    np.testing.assert_array_equal(ops.col_argmin(xn, wn, 'CosineBF16').cpu().numpy(), z['col_idx'].astype(np.int64))
+    o_idx, o_min = co.cos_bf16_argmin(x, w, with_min=True)
+    np.testing.assert_array_equal(o_idx, want)
+    # the materialised matrix holds the bf16 values of the reference's distance tensor
+    d = ops.distance(xn, wn, 'CosineBF16')
+    assert torch.equal(d, d.bfloat16().float())
+    np.testing.assert_array_equal(d.min(1).values.cpu().numpy(), z['mind'])
+
+
+def test_bf16_autocast_cosine_module_and_larger_shapes(ops):
+    """The quantizer module with CosineDistance(autocast='bf16') on BASELINE configs[2]'s shape (and a D = 256 one) against
+    the oracle's definition on a row sample and against the fp32-only route everywhere."""
+    from vector_quantization_amd import build_quantizer, Config
+    for N, K, D in ((100352, 8192, 32), (20000, 16384, 256)):
+        g = torch.Generator(device='cuda').manual_seed(N + D)
+        w = torch.randn(K, D, device='cuda', generator=g)
+        x = torch.randn(N, D, device='cuda', generator=g)
+        q = build_quantizer(dict(type='VQGANQuantizer',
+                                 embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=D),
+                                 distance=dict(type='CosineDistance', autocast='bf16'),
+                                 losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+        q.init_weights(Config(type='vqgan')); q = q.cuda().eval()
+        with torch.no_grad():
+            q.embedding.weight.copy_(w)
+            _, _, memo = q(x, {})
+        quant = memo['quant'].reshape(-1)
+        xn = ops.normalize_rows(x).bfloat16().float()
+        wn = ops.normalize_rows(w).bfloat16().float()
+        assert torch.equal(quant, ops.argmin_exact(xn, wn, 'CosineBF16'))
+        sample = slice(0, 400)
+        np.testing.assert_array_equal(quant[sample].cpu().numpy(), co.cos_bf16_argmin(x[sample].cpu().numpy(), w.cpu().numpy()))
+        fp32 = ops.encode(x, w, 'Cosine')[0]
+        assert 0 < int((fp32 != quant).sum()) < N // 5        # the mode changes a few percent of the rows, not most
 
 
 def test_hist_scatter_gather(ops):

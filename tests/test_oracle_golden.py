@@ -23,9 +23,14 @@ def _cases(golden_dir):
     for p in sorted(glob.glob(os.path.join(golden_dir, '*.npz'))):
         z = np.load(p)
         if 'spec' in z.files and 'quant' in z.files and 'distance' in json.loads(str(z['spec'])) \
-                and 'kind' in json.loads(str(z['spec'])):
+                and 'kind' in json.loads(str(z['spec'])) and json.loads(str(z['spec']))['distance'] != 'CosineBF16':
             out.append(p)
     return out
+
+
+def autocast_cases(golden_dir):
+    """Fixtures of the reference's CosineDistance under bf16 autocast (oracle/make_golden.py: autocast_cases)."""
+    return sorted(glob.glob(os.path.join(golden_dir, 'cosbf16_*.npz')))
 
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -104,6 +109,23 @@ def test_oracle_matches_reference_ops(path):
     else:
         loss = co.mse(co.normalize_rows(zz), co.normalize_rows(xe))
     assert abs(float(loss) - float(z['loss'])) <= 1e-5 * max(1.0, abs(float(z['loss'])))
+
+
+@pytest.mark.parametrize('path', autocast_cases(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_bf16_autocast_cosine_matches_reference(path):
+    """oracle cos_bf16_argmin (the definition behind VQHIP_METRIC_COS_BF16) against the reference's own CosineDistance
+    executed inside torch.autocast(bf16): every index and every minimum, bit for bit."""
+    z = np.load(path)
+    spec = json.loads(str(z['spec']))
+    x, w = synth.make_inputs(spec['kind'], spec['seed'], spec['N'], spec['K'], spec['D'])
+    assert synth.sha(x) == str(z['x_sha']) and synth.sha(w) == str(z['w_sha'])
+    idx, mind = co.cos_bf16_argmin(x, w, with_min=True)
+    np.testing.assert_array_equal(idx, z['quant'].astype(np.int64))
+    np.testing.assert_array_equal(mind, z['mind'])
+    if spec['kind'] != 'int':
+        assert int(z['differs_from_fp32']) > 0          # the mode is not a no-op on these inputs
+        assert (idx != co.cos_argmin(x, w)).sum() == int(z['differs_from_fp32'])
 
 
 def test_nonfinite_semantics(golden_dir):

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQHIP_LIB') or os.path.join(_HERE, 'libvqhip.so')   # VQHIP_LIB: experiment builds
 
-METRIC_L2, METRIC_COS = 0, 1
+METRIC_L2, METRIC_COS, METRIC_COS_BF16 = 0, 1, 5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float

@@ -381,7 +381,7 @@ static int codebook_prepare_impl(const float *e, int64_t K, int D, int metric, v
 }
 
 int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
-    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS))
+    if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16))
         return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
     return codebook_prepare_impl(e, K, D, metric, cb, stream);
 }
@@ -496,21 +496,22 @@ int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t 
                  int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream) {
     if (N == 0) return e && cb && K > 0 && D > 0 ? vqhip_codebook_prepare(e, K, D, metric, cb, stream) : fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
     if (!x || !e || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
-    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_encode: metric");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: metric");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: x_dtype");
-    if (metric == VQHIP_METRIC_COS && !xq) return fail(VQHIP_EINVAL, "vqhip_encode: the cosine metric needs the xq buffer");
+    if (VQ_IS_COS(metric) && !xq) return fail(VQHIP_EINVAL, "vqhip_encode: the cosine metric needs the xq buffer");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_encode: N or K too large");
     if (!vq_coarse_supported(D)) {          // no fp16 proposal image for this D: the separate entry points do the work
         if (int rc = vqhip_codebook_prepare(e, K, D, metric, cb, stream)) return rc;
         const void *rows = x; int rows_dtype = x_dtype;
-        if (metric == VQHIP_METRIC_COS) {
+        if (VQ_IS_COS(metric)) {
+            if (VQ_IS_BF16(metric)) return fail(VQHIP_EINVAL, "vqhip_encode: the bf16-autocast cosine metric needs D <= 1024, D % 8 == 0");
             if (int rc = vqhip_normalize_rows(x, x_dtype, N, D, 1e-12f, xq, stream)) return rc;
             rows = xq; rows_dtype = VQHIP_DTYPE_F32;
         }
         return vqhip_argmin(rows, rows_dtype, e, cb, N, K, D, metric, idx, hist, ws, stream);
     }
     hipStream_t s = (hipStream_t)stream;
-    const bool cos = metric == VQHIP_METRIC_COS;
+    const bool cos = VQ_IS_COS(metric);
     if (int rc = encode_fused_front(x, x_dtype, N, e, K, D, metric, cb, ws, cos, xq, s)) return rc;
     VqCbLayout L = vq_cb_layout(K, D);
     const float *e_exact = cos ? (const float *)((const char *)cb + L.off_eexact) : e;
@@ -523,12 +524,12 @@ int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int
                  int64_t *idx, int32_t *hist, void *ws, void *stream) {
     if (N == 0) return VQHIP_OK;
     if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
-    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
     if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
     VqCbLayout L = vq_cb_layout(K, D);
-    const float *e_exact = (metric == VQHIP_METRIC_COS) ? (const float *)((const char *)cb + L.off_eexact) : e;
+    const float *e_exact = VQ_IS_COS(metric) ? (const float *)((const char *)cb + L.off_eexact) : e;
     if (!vq_coarse_supported(D)) {
         // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
         VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
@@ -582,7 +583,7 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
     if (!x || !e || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_col_argmin: bad argument");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin: N or K too large");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
-    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS) return fail(VQHIP_EINVAL, "vqhip_col_argmin: metric");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: metric");
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
     if (vq_coarse_supported(D)) {
@@ -602,7 +603,7 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
             VQ_CHECK_LAUNCH("bf16_to_f32_kernel");
             codes = copy;
         }
-        const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : VQ_METRIC_DOT;
+        const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : (VQ_METRIC_DOT | (metric & VQ_METRIC_BF16));
         // statistics of the latents-as-codebook and the token side of the codes-as-rows in one launch, then the image
         int rc = encode_fused_front(e, VQHIP_DTYPE_F32, K, codes, N, D, m, img, pipe_ws, false, nullptr, s);
         if (rc) return rc;

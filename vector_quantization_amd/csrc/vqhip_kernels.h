@@ -18,6 +18,8 @@ typedef unsigned long long u64;
 // row/column-swapped NearestAnchor pass), bit 8 = the L2 finishing adds the CODE norm first: (c + |code|^2) + |row|^2
 #define VQ_METRIC_DOT 2
 #define VQ_METRIC_SWAP 0x100
+#define VQ_METRIC_BF16 0x4          // with COS / DOT: bf16-autocast semantics (VQHIP_METRIC_COS_BF16 = COS | BF16)
+#define VQ_IS_BF16(m) (((m) & VQ_METRIC_BF16) != 0)
 #define VQ_IS_L2(m) (((m) & 3) == VQHIP_METRIC_L2)
 #define VQ_IS_COS(m) (((m) & 3) == VQHIP_METRIC_COS)
 #define VQ_SWAPPED(m) (((m) & VQ_METRIC_SWAP) != 0)
@@ -75,6 +77,19 @@ template <> struct RawVec<1> {
         v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xFFFF0000u);
     }
 };
+
+// fp32 -> nearest bf16 (ties to even), returned as fp32: torch's rounding (NaN / Inf pass through)
+__device__ __forceinline__ float bf16_rne(float v) {
+    uint32_t b = __float_as_uint(v);
+    if ((b & 0x7F800000u) == 0x7F800000u) return v;
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return __uint_as_float(b & 0xFFFF0000u);
+}
+// 1 - similarity; bf16-autocast semantics round the similarity and the difference to bf16 (include/vqhip.h)
+__device__ __forceinline__ float cos_distance(float c, int metric) {
+    if (((metric) & 0x4) != 0) return bf16_rne(1.0f - bf16_rne(c));
+    return 1.0f - c;
+}
 
 // single-instruction max (hipcc otherwise wraps fmaxf on MFMA results in canonicalising v_max pairs)
 __device__ __forceinline__ float vmax(float a, float b) {
@@ -289,6 +304,7 @@ __device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64
             float q2 = 0.0f;
             for (int d = lane; d < D; d += 64) {
                 float a = e[(k0 + c) * D + d] / den;
+                if (VQ_IS_BF16(metric)) a = bf16_rne(a);            // bf16-autocast: the einsum sees bf16(normalize(e))
                 ex[(k0 + c) * D + d] = a;
                 amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
             }
@@ -428,7 +444,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
                                             char *__restrict__ ximg, float *__restrict__ xh2,
                                             float *__restrict__ rho2, float *__restrict__ xn,
                                             int *__restrict__ counters, int *__restrict__ arrive, int narrive,
-                                            float *__restrict__ xq, float eps) {
+                                            float *__restrict__ xq, float eps, int xround = 0) {
     __shared__ float red[2][8][32];
     __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
     __shared__ float den_s[32];
@@ -486,7 +502,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
             load8<DT>(x, trow * D + d0, v);
             if constexpr (XNORM) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] / den;
+                for (int j = 0; j < 8; ++j) { v[j] = v[j] / den; if (xround) v[j] = bf16_rne(v[j]); }
                 *(f32x4 *)(xq + trow * D + d0) = f32x4{v[0], v[1], v[2], v[3]};
                 *(f32x4 *)(xq + trow * D + d0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
@@ -544,7 +560,8 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
                                                   int *__restrict__ counters, int *__restrict__ arrive, int narrive,
                                                   float *__restrict__ xq, float eps) {
     if ((int)blockIdx.x < nblk_stats) cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
-    else x_prep_body<DT, XNORM>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps);
+    else x_prep_body<DT, XNORM>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
+                                VQ_IS_BF16(metric) ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1075,7 +1092,7 @@ __device__ float oracle_distance(const void *x, int64_t xoff, const float *erow,
         return sqrtf(t);
     }
     for (int d = 0; d < D; ++d) c = fmaf(load_elem<DT>(x, xoff + d), erow[d], c);
-    return 1.0f - c;
+    return cos_distance(c, metric);
 }
 
 // torch.argmin order on (distance, index): NaN first, then smaller distance, then smaller index
@@ -1113,6 +1130,9 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
     } else {
         float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax);
         m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
+        // bf16-autocast semantics: every similarity s that rounds to the best one's bf16 distance ties with it (lowest index
+        // wins), and s_best - s <= ulp_bf16(s) + ulp_bf16(1 - s) <= 2^-7 (|s| + |1 - s|) <= 3 * 2^-7 for |s| <= 1 (+ rounding slop)
+        if (VQ_IS_BF16(metric)) m += 3.0f * 0.0078125f * 1.01f * fmaxf(1.0f, Xn * Emax);
     }
     m = m * se * infl + 1e-37f;
     return isfinite(m) ? m : -1.0f;
@@ -1513,7 +1533,7 @@ __device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave,
                 t = (t < 0.0f) ? 0.0f : t;
                 dist = sqrtf(t);
             } else {
-                dist = 1.0f - c;
+                dist = cos_distance(c, metric);
             }
             key = dist_key(dist, code);
         }
@@ -1669,7 +1689,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                     t = (t < 0.0f) ? 0.0f : t;
                     d = sqrtf(t);
                 } else {
-                    d = 1.0f - acc[c][q];
+                    d = cos_distance(acc[c][q], metric);
                 }
                 if (MODE == 0) {
                     if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
@@ -1842,7 +1862,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                     t = (t < 0.0f) ? 0.0f : t;
                     d = sqrtf(t);
                 } else {
-                    d = 1.0f - acc[c][q];
+                    d = cos_distance(acc[c][q], metric);
                 }
                 if (MODE == 0) {
                     if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }

@@ -11,9 +11,11 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import METRIC_COS, METRIC_L2, check
+from ._lib import METRIC_COS, METRIC_COS_BF16, METRIC_L2, check
 
-METRICS = {'L2': METRIC_L2, 'Cosine': METRIC_COS, METRIC_L2: METRIC_L2, METRIC_COS: METRIC_COS}
+# 'CosineBF16': cosine as the reference's GPU runs evaluate it under bf16 autocast (include/vqhip.h, VQHIP_METRIC_COS_BF16)
+METRICS = {'L2': METRIC_L2, 'Cosine': METRIC_COS, 'CosineBF16': METRIC_COS_BF16,
+           METRIC_L2: METRIC_L2, METRIC_COS: METRIC_COS, METRIC_COS_BF16: METRIC_COS_BF16}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -96,7 +98,7 @@ class PreparedCodebook:
     def exact_rows(self) -> Optional[torch.Tensor]:
         """Cosine images: the fp32 rows F.normalize(weight) the exact definition consumes, as a view into the image
         (bit-identical to ``normalize_rows(weight)``); None for L2 (the weight itself is the operand)."""
-        if self.metric != METRICS['Cosine']:
+        if self.metric not in (METRIC_COS, METRIC_COS_BF16):
             return None
         off = _lib.lib().vqhip_codebook_exact_offset(self.K, self.D)
         return self.image[off:off + self.K * self.D * 4].view(torch.float32).view(self.K, self.D)
@@ -157,7 +159,7 @@ def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.T
     L = _lib.lib()
     image = _bytes(L.vqhip_codebook_bytes(K, D), e.device)
     idx = torch.empty(N, dtype=torch.int64, device=x.device)
-    xq = torch.empty(N, D, dtype=torch.float32, device=x.device) if metric == 'Cosine' else None
+    xq = torch.empty(N, D, dtype=torch.float32, device=x.device) if m in (METRIC_COS, METRIC_COS_BF16) else None
     ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
     if hist is not None:
         assert hist.dtype == torch.int32 and hist.numel() == K and hist.is_contiguous()

@@ -45,16 +45,16 @@ class _DotMatrix(Function):
     """d = 1 - xn @ en^T on operands that are already normalised (CosineDistance: distances.py:39-46)."""
 
     @staticmethod
-    def forward(ctx, xn: torch.Tensor, en: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, xn: torch.Tensor, en: torch.Tensor, metric: str = 'Cosine') -> torch.Tensor:
         ctx.save_for_backward(xn, en)
-        return ops.distance(xn, en, 'Cosine')
+        return ops.distance(xn, en, metric)
 
     @staticmethod
     def backward(ctx, g):
         xn, en = ctx.saved_tensors
         gx = -(g @ en) if ctx.needs_input_grad[0] else None
         ge = -(g.t() @ xn) if ctx.needs_input_grad[1] else None
-        return gx, ge
+        return gx, ge, None
 
 
 class LazyDistance(torch.Tensor):
@@ -203,30 +203,57 @@ class L2Distance(BaseDistance):
         return self._fused_encode(x, e, hist, stash)
 
 
+def _bf16_valued(t: torch.Tensor) -> torch.Tensor:
+    return t.bfloat16().float()
+
+
 @VQITQuantizerDistanceRegistry.register_()
 class CosineDistance(BaseDistance):
-    metric = 'Cosine'
+    """``autocast='bf16'`` (extension, default None = the fp32 definition of distances.py:35-46): the values the
+    reference's GPU runs compute under its autocast callback (vq/runners/base.py:30-48) — normalisation in fp32, the
+    einsum on bf16 operands with a bf16 result, ``1 - s`` in bf16, hence the lowest index among equal bf16 distances
+    (5.7 % of the rows have such ties).  The products are summed in the fp32 definition's order, so a
+    row can differ from one particular GEMM's summation order only where the fp32 sum straddles a bf16 rounding
+    boundary.  Gradients of a materialised matrix are those of the fp32 definition (straight through the rounding)."""
+
+    def __init__(self, *args, autocast: Optional[str] = None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        if autocast not in (None, 'bf16'):
+            raise ValueError(f"CosineDistance: autocast must be None or 'bf16', got {autocast!r}")
+        self._autocast = autocast
+
+    @property
+    def metric(self) -> str:
+        return 'CosineBF16' if self._autocast == 'bf16' else 'Cosine'
+
+    def _operand(self, t: torch.Tensor) -> torch.Tensor:
+        n = ops.normalize_rows(t.detach())
+        return _bf16_valued(n) if self._autocast == 'bf16' else n
 
     def exact_operands(self, x: torch.Tensor, e: torch.Tensor):
-        return ops.normalize_rows(x.detach()), ops.normalize_rows(e.detach())
+        return self._operand(x), self._operand(e)
 
     def exact_codebook(self, e: torch.Tensor) -> torch.Tensor:
-        return ops.normalize_rows(e.detach())
+        return self._operand(e)
 
     @staticmethod
     def cosine_similarity(x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         """normalize(x) @ normalize(e).T, returned as 1 - distance (the distance kernel's own value)."""
-        return 1 - _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
+        return 1 - _DotMatrix.apply(VF.normalize(x), VF.normalize(e), 'Cosine')
 
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
-        return _DotMatrix.apply(VF.normalize(x), VF.normalize(e))
+        xn, en = VF.normalize(x), VF.normalize(e)
+        if self._autocast == 'bf16':            # bf16-valued operands, gradients straight through the rounding
+            xn = xn + (_bf16_valued(xn.detach()) - xn.detach())
+            en = en + (_bf16_valued(en.detach()) - en.detach())
+        return _DotMatrix.apply(xn, en, self.metric)
 
     def encode(self, x, e, hist=None, stash=None):
         return self._fused_encode(x, e, hist, stash)
 
     def argmin(self, x, e, hist=None, prepared=None, stash=None):
         cb = prepared if prepared is not None else self.prepare(e)
-        xn = ops.normalize_rows(x.detach())
+        xn = self._operand(x)
         if stash is not None:
             stash['xq'] = xn
             stash['eq'] = cb.exact_rows()          # normalize(e), as the image made from e holds it
