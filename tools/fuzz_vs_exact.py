@@ -22,7 +22,7 @@ while time.time() < t_end:
     K = [ri(1, 64), ri(64, 4096), 8192, 16384, ri(4096, 20000)][ri(0, 5)]
     N = [ri(1, 512), ri(512, 70000), 65536, ri(70000, 300000)][ri(0, 4)]
     if N * K * D > 3e12: N = max(1, int(3e12 / (K * D)))
-    metric = 'L2' if ri(0, 3) else 'Cosine'
+    metric = 'L2' if ri(0, 3) else ('Cosine' if ri(0, 3) else 'CosineBF16')     # CosineBF16: the bf16-autocast semantics (opt-in)
     kind = ri(0, 6)
     scale = 10.0 ** ri(-4, 5)
     w = torch.randn(K, D, device='cuda', generator=g)
@@ -40,9 +40,11 @@ while time.time() < t_end:
     x, w = x * scale, w * scale
     if os.environ.get('VQ_FUZZ_VERBOSE'): print(f'trial {trials + 1}: N={N} K={K} D={D} {metric} kind={kind} scale={scale}', flush=True)
     xd = x.bfloat16() if ri(0, 3) == 0 else x
-    if metric == 'Cosine':
+    if metric != 'L2':
         xq = ops.normalize_rows(xd); wq = ops.normalize_rows(w)
-        got = ops.argmin(xq, ops.prepare_codebook(w, metric))
+        if metric == 'CosineBF16':
+            xq, wq = xq.bfloat16().float(), wq.bfloat16().float()
+        got = ops.argmin(xq, ops.prepare_codebook(w, metric)) if ri(0, 2) else ops.encode(xd, w, metric)[0]
         ref = ops.argmin_exact(xq, wq, metric)
     else:
         got = ops.argmin(xd, ops.prepare_codebook(w, metric))
@@ -50,7 +52,7 @@ while time.time() < t_end:
     nb = int((got != ref).sum().item())
     # NearestAnchor's column argmin (role-swapped pipeline) against the materialised fp32 distance matrix
     if N * K <= 1.5e8 and ri(0, 2) == 0:
-        if metric == 'Cosine':
+        if metric != 'L2':
             d = ops.distance(xq, wq, metric); col = ops.col_argmin(xq, wq, metric)
         else:
             d = ops.distance(xd, w, metric); col = ops.col_argmin(xd, w, metric)

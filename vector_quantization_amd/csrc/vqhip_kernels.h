@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
 // fp16 MFMA proposal pass
 // ------------------------------------------------------------------------------------------------
 struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
-__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2);
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2, float *bf16_part = nullptr);
 
 // where the decision stage writes (one struct: the proposal kernel carries it as a single argument)
 struct VqDecideOut {
@@ -1107,7 +1107,10 @@ __device__ __forceinline__ u64 dist_key(float d, uint32_t k) {
 
 // Rigorous per-row margin (in scaled score units) between the proposal score and the fp32 definition.
 // Returns a negative value when the bound cannot be formed (non-finite data): the row is then flagged.
-__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2) {
+// bf16_part (optional): receives the share of the returned margin that is the worst-case width of a bf16 tie bucket
+// (VQ_METRIC_BF16), so that the decision stage, which knows the row's best score, can put the actual width in its place.
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2, float *bf16_part) {
+    if (bf16_part) *bf16_part = 0.0f;
     if (st->nonfinite != 0 || !isfinite(X2) || !isfinite(R2)) return -1.0f;
     const float infl = 1.0f + 1e-5f;
     float se = cb_scale(st);
@@ -1132,10 +1135,15 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
         m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
         // bf16-autocast semantics: every similarity s that rounds to the best one's bf16 distance ties with it (lowest index
         // wins), and s_best - s <= ulp_bf16(s) + ulp_bf16(1 - s) <= 2^-7 (|s| + |1 - s|) <= 3 * 2^-7 for |s| <= 1 (+ rounding slop)
-        if (VQ_IS_BF16(metric)) m += 3.0f * 0.0078125f * 1.01f * fmaxf(1.0f, Xn * Emax);
+        if (VQ_IS_BF16(metric)) {
+            const float wworst = 3.0f * 0.0078125f * 1.01f * fmaxf(1.0f, Xn * Emax);
+            m += wworst;
+            if (bf16_part) *bf16_part = wworst * se * infl;
+        }
     }
     m = m * se * infl + 1e-37f;
-    return isfinite(m) ? m : -1.0f;
+    if (!isfinite(m)) { if (bf16_part) *bf16_part = 0.0f; return -1.0f; }
+    return m;
 }
 
 #define VQ_RESCAN_CAP 32     // candidate slots per rescanned row
@@ -1157,12 +1165,26 @@ __device__ __forceinline__ float rec_load(const float *p) {
     else return *p;
 }
 
+// VQ_METRIC_BF16: the margin carries the WORST-CASE width of a bf16 tie bucket (3 * 2^-7: row_margin).  Knowing the row's best
+// score s (similarity = score / scale, up to the proposal error the rest of the margin covers), every s' that ties with it
+// satisfies s - s' <= ulp(bf16(s)) + ulp(bf16(1 - s)) <= 2^-7 (|s| + |1 - s|) (1 + 2^-6): three times narrower for s in [0, 1].
+__device__ __forceinline__ float bf16_tight_margin(float m, float bf16_worst, float gbest, const VqCbStats *st) {
+    if (!(bf16_worst > 0.0f) || !(m > 0.0f) || !isfinite(gbest)) return m;
+    const float se = cb_scale(st);
+    const float s = gbest / se, err = (m - bf16_worst) / se;            // similarity as proposed, and how far off it can be
+    // |s| + |1 - s| = 1 for s in [0, 1]; outside, twice the excursion more (err: the proposal's own uncertainty)
+    const float spread = 1.0f + 2.0f * (fmaxf(err, 0.0f) + fmaxf(-s, 0.0f) + fmaxf(s - 1.0f, 0.0f));
+    const float width = 0.0078125f * 1.02f * spread * se * 1.0001f;
+    return width < bf16_worst ? m - bf16_worst + width : m;
+}
+
 template <int NSL, bool AGENT>
 __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                                  const float *rec, const float *xh2, const float *rho2, int64_t Np,
                                                  const VqDecideOut &o, int *wcount, int *wbase) {
     const VqCbStats stv = cb_stats_view(st);
-    const float m = row_margin(&stv, Dp, metric, xh2[n], rho2[n]);
+    float bf16_worst = 0.0f;
+    float m = row_margin(&stv, Dp, metric, xh2[n], rho2[n], &bf16_worst);
     bool invalid = !(m > 0.0f);
     float gbest = -INFINITY;
     int nc = 0;
@@ -1180,6 +1202,7 @@ __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCb
 #pragma unroll
         for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
         if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
+        m = bf16_tight_margin(m, bf16_worst, gbest, &stv);
         thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
@@ -1190,6 +1213,7 @@ __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCb
     } else {
         for (int s = 0; s < nslices; ++s) gbest = fmaxf(gbest, rec_load<AGENT>(rec + (int64_t)s * VQ_REC_FIELDS * Np + n));
         if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
+        m = bf16_tight_margin(m, bf16_worst, gbest, &stv);
         thr = gbest - m;
         for (int s = 0; s < nslices; ++s) {
             const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
