@@ -20,10 +20,17 @@ def run(name, cfg, N, K, D, iters=30):
         z, loss, memo = q(x, {})
         (loss + z.mean()).backward()
     for _ in range(5): it()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ts = []                 # each step on its own (launch to completion) ...
+    for _ in range(iters):
+        torch.cuda.synchronize(); t1 = time.perf_counter(); it(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+    ts.sort(); lat = ts[len(ts) // 2]
+    if os.environ.get('VQ_PER_ITER'):
+        print('   per step ms:', ' '.join(f'{v * 1e3:.2f}' for v in ts))
+    torch.cuda.synchronize(); t0 = time.perf_counter()          # ... and back to back (the host runs ahead of the GPU)
     for _ in range(iters): it()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / iters
-    print(f'{name}: N={N} K={K} D={D}: {t*1e3:.3f} ms per training step ({N/t/1e6:.1f} Mtok/s)', flush=True)
+    print(f'{name}: N={N} K={K} D={D}: {lat*1e3:.3f} ms per training step, median of {iters} synchronised steps ({N/lat/1e6:.1f} Mtok/s); '
+          f'{t*1e3:.3f} ms back to back', flush=True)
 
 emb = lambda K, D: dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=D)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
