@@ -86,7 +86,8 @@ static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B meas
 // key 6: 1 = the proposal kernel runs the decision stage itself (last workgroup of a token block, arrival tickets).
 // Measured neutral (tools/ab_key.py 6: -1.6 % .. +1.4 % over seven shapes; the release/acquire fences cost what the
 // launch saves), so the stand-alone launch stays the default; results are identical either way.
-static std::atomic<int> g_tune_fused_decide{0};
+// (2 = only where ONE slice covers the codebook: the workgroup then decides its own tokens, no ticket and no fence involved)
+static std::atomic<int> g_tune_fused_decide{2};
 static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
@@ -225,7 +226,11 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         int ns = pick_slices(ntb, L.nstages, (NS) <= 8 ? VQ_MIN_SLICES_FILTER : 2);                 \
         *nslices_out = ns;                                                                          \
         const int tpb = (ns == 1) ? balanced_tiles_per_block(N, (W) * (TT)) : (W) * (TT);           \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec, 0, pad_stage, tpb, s); \
+        const int fmode = g_tune_fused_decide.load();                                               \
+        VqDecideOut dsel = dec;                                                                     \
+        if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;                            \
+        *fused_decide_out = dsel.idx != nullptr ? 1 : 0;                                            \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, 0, pad_stage, tpb, s); \
     }
     // stream-K form (D <= 32): equal shares of the (token block x stage) space, two workgroups per CU
 #define VQ_CFG_SK(NS, TT, W, ...)                                                                   \
@@ -422,10 +427,8 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     }
     // the proposal kernel also runs the decision stage (the workgroup that completes a token block merges its slices)
     VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive};
-    const bool fused_decide = g_tune_fused_decide.load() != 0;
-    VqDecideOut dec_arg = dec;
-    if (!fused_decide) dec_arg.idx = nullptr;
-    int fused_done = fused_decide ? 1 : 0;       // the stream-K form always leaves the decision stage to its own launch
+    VqDecideOut dec_arg = dec;                   // launch_coarse decides (knob 6, slice count) whether the proposal kernel runs the
+    int fused_done = 0;                          // decision stage itself and reports it here
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s);
     if (rc) return rc;
     if (!fused_done) {
@@ -944,7 +947,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 3) g_tune_gather_grid = value > 0 ? value : 0;
     else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
     else if (key == 5) g_tune_filter = value != 0;
-    else if (key == 6) g_tune_fused_decide = value != 0;
+    else if (key == 6) g_tune_fused_decide = (value >= 0 && value <= 2) ? value : 0;
     else if (key == 7) g_tune_streamk = value != 0;
     else if (key == 8) g_tune_noaux = value != 0;
     else if (key == 9) g_tune_groups = value != 0;

@@ -463,8 +463,25 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) pn[j] = 0.0f;
     float den = 1.0f;
+    constexpr int KEEP = 4;              // pieces a thread keeps in registers between the two passes (D <= 256)
+    float kept[KEEP][8];
+    const bool keep = XNORM && ns32 * 4 <= KEEP * 8;
     if constexpr (XNORM) {
-        for (int piece = g; piece < ns32 * 4; piece += 8) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kept[i][j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int piece = g + 8 * i;
+            const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
+            if (piece < ns32 * 4 && tvalid && d0 < D) {
+                load8<DT>(x, trow * D + d0, kept[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pn[j] = fmaf(kept[i][j], kept[i][j], pn[j]);
+            }
+        }
+        for (int piece = g + 8 * KEEP; piece < ns32 * 4; piece += 8) {
             const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
             if (tvalid && d0 < D) {
                 float v[8];
@@ -499,7 +516,19 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
         half8 f;
         if (tvalid && d0 < D) {
             float v[8];
-            load8<DT>(x, trow * D + d0, v);
+            bool have = false;
+            if constexpr (XNORM) {
+                if (keep) {                        // second pass over registers instead of memory
+#pragma unroll
+                    for (int i = 0; i < KEEP; ++i)
+                        if (piece == g + 8 * i) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = kept[i][j];
+                            have = true;
+                        }
+                }
+            }
+            if (!have) load8<DT>(x, trow * D + d0, v);
             if constexpr (XNORM) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { v[j] = v[j] / den; if (xround) v[j] = bf16_rne(v[j]); }
