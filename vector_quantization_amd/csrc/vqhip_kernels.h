@@ -969,14 +969,6 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
                 f32x4 acc[RB][2];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-#ifdef VQ_DEBUG_REPLAY
-                    if (T[i] / TPS >= (uint32_t)nstages) {
-                        if (need && t1[t] == T[i])
-                            printf("replay: bad tile %u (stages %lld, slice %d [%lld,%lld)) block %d lane %d t %d b1 %g b2 %g top %g mg %g\n", T[i],
-                                   (long long)nstages, sl, (long long)st0, (long long)st1, (int)blockIdx.x, lane, t, b1[t], b2[t], top, mg[t]);
-                        T[i] = (uint32_t)(st0 * TPS);
-                    }
-#endif
                     const int64_t rst = T[i] / TPS;
                     const int rti = (int)(T[i] % TPS);
                     const char *sb = frag + rst * (int64_t)STAGE_BYTES;
