@@ -56,6 +56,11 @@ int64_t vqhip_codebook_bytes(int64_t K, int D);
  *   ws: vqhip_workspace_bytes(N,K,D).  Results are those of the separate calls, bit for bit. */
 int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
                  int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream);
+/* The same with flags: VQHIP_ENCODE_ZERO_HIST — `hist` is zeroed by the call's first launch (no separate fill), so the
+ * histogram on return is exactly this call's code counts. */
+#define VQHIP_ENCODE_ZERO_HIST 1
+int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
+                    int64_t *idx, int32_t *hist, float *xq, void *ws, int flags, void *stream);
 
 /* Byte offset, inside an image prepared with VQHIP_METRIC_COS, of the fp32 [K, D] rows F.normalize(e, dim=1) the exact
  * definition consumes (bit-identical to vqhip_normalize_rows(e)); 256-byte aligned.  Lets a caller that needs the

@@ -189,6 +189,10 @@ def test_encode_one_call_equals_separate_calls(ops, N, K, D, metric, dtype):
         assert torch.equal(xq, xq_ref) and torch.equal(cb2.exact_rows(), cb.exact_rows())
     else:
         assert xq is None
+    # zero_hist: the histogram buffer may hold anything, the call's first launch zeroes it
+    hg = torch.full((K,), 12345, dtype=torch.int32, device='cuda')
+    got2, _, _ = ops.encode(x, w, metric, hist=hg, zero_hist=True)
+    assert torch.equal(got2, ref) and torch.equal(hg, h_ref)
     # the image made by the fused front serves later argmin calls like any other
     assert torch.equal(ops.argmin(xq_ref, cb2), ref)
     wq = ops.normalize_rows(w) if metric == 'Cosine' else w

@@ -476,7 +476,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
 // token side (they are independent), then the image kernel.  `rows` are the N rows to quantize (normalised into `xq`
 // first when xnorm), `codes` the Kc rows the image is made from, `ws` the workspace of argmin_pipeline(N rows, Kc codes).
 static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const float *codes, int64_t Kc, int D, int cb_metric,
-                              void *cb, void *ws, bool xnorm, float *xq, hipStream_t s) {
+                              void *cb, void *ws, bool xnorm, float *xq, hipStream_t s, int32_t *hist_zero = nullptr) {
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
@@ -485,7 +485,7 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
     char *ximg = w + W.off_ximg;
-#define VQ_PRE(DT, XN) pre_kernel<DT, XN><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f)
+#define VQ_PRE(DT, XN) pre_kernel<DT, XN><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero)
     if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true); else VQ_PRE(0, false); }
     else { if (xnorm) VQ_PRE(1, true); else VQ_PRE(1, false); }
 #undef VQ_PRE
@@ -497,6 +497,15 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
 
 int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
                  int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream) {
+    return vqhip_encode_ex(x, x_dtype, e, N, K, D, metric, cb, idx, hist, xq, ws, 0, stream);
+}
+
+int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
+                    int64_t *idx, int32_t *hist, float *xq, void *ws, int flags, void *stream) {
+    const bool zero_hist = hist != nullptr && (flags & VQHIP_ENCODE_ZERO_HIST) != 0;
+    if (N == 0 || !vq_coarse_supported(D)) {                 // paths without the fused front: plain memset
+        if (zero_hist && K > 0) VQ_HIP(hipMemsetAsync(hist, 0, (size_t)K * 4, (hipStream_t)stream));
+    }
     if (N == 0) return e && cb && K > 0 && D > 0 ? vqhip_codebook_prepare(e, K, D, metric, cb, stream) : fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
     if (!x || !e || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: metric");
@@ -515,7 +524,7 @@ int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t 
     }
     hipStream_t s = (hipStream_t)stream;
     const bool cos = VQ_IS_COS(metric);
-    if (int rc = encode_fused_front(x, x_dtype, N, e, K, D, metric, cb, ws, cos, xq, s)) return rc;
+    if (int rc = encode_fused_front(x, x_dtype, N, e, K, D, metric, cb, ws, cos, xq, s, zero_hist ? hist : nullptr)) return rc;
     VqCbLayout L = vq_cb_layout(K, D);
     const float *e_exact = cos ? (const float *)((const char *)cb + L.off_eexact) : e;
     // from here on the rows are what vqhip_argmin would have been given: the normalised fp32 rows for cosine

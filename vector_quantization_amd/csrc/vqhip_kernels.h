@@ -444,8 +444,13 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
                                             char *__restrict__ ximg, float *__restrict__ xh2,
                                             float *__restrict__ rho2, float *__restrict__ xn,
                                             int *__restrict__ counters, int *__restrict__ arrive, int narrive,
-                                            float *__restrict__ xq, float eps, int xround = 0) {
+                                            float *__restrict__ xq, float eps, int xround = 0,
+                                            int32_t *__restrict__ hist_zero = nullptr, int64_t hist_len = 0,
+                                            int64_t nblocks = 1) {
     __shared__ float red[2][8][32];
+    // vqhip_encode(VQHIP_ENCODE_ZERO_HIST): the code-hit histogram the later kernels of this call add into starts from zero
+    if (hist_zero != nullptr)
+        for (int64_t i = blk * 256 + threadIdx.x; i < hist_len; i += nblocks * 256) hist_zero[i] = 0;
     __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
     __shared__ float den_s[32];
     if (blk == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // housekeeping for the later kernels of this call (stream-ordered)
@@ -587,10 +592,10 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
                                                   char *__restrict__ ximg, float *__restrict__ xh2,
                                                   float *__restrict__ rho2, float *__restrict__ xn,
                                                   int *__restrict__ counters, int *__restrict__ arrive, int narrive,
-                                                  float *__restrict__ xq, float eps) {
+                                                  float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero) {
     if ((int)blockIdx.x < nblk_stats) cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
     else x_prep_body<DT, XNORM>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
-                                VQ_IS_BF16(metric) ? 1 : 0);
+                                VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)gridDim.x - nblk_stats);
 }
 
 // ------------------------------------------------------------------------------------------------

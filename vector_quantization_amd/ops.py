@@ -143,7 +143,7 @@ def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] =
 
 
 @_on_tensor_device
-def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None):
+def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None, zero_hist: bool = False):
     """``prepare_codebook`` + (cosine: ``normalize_rows(x)``) + ``argmin`` as ONE library call with two launches less:
     the training-time encode, where the codebook changes every step.  x are the latents as the quantizer receives them
     (not normalised).  Returns (idx, prepared codebook, xq) — xq = the normalised latents for cosine, None for L2;
@@ -163,8 +163,9 @@ def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.T
     ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
     if hist is not None:
         assert hist.dtype == torch.int32 and hist.numel() == K and hist.is_contiguous()
-    check(L.vqhip_encode(_ptr(x), dt, _ptr(e), N, K, D, m, _ptr(image), _ptr(idx), _ptr(hist), _ptr(xq), _ptr(ws),
-                         _stream()), 'vqhip_encode')
+    # zero_hist: `hist` may be uninitialised memory — the call's first launch zeroes it (no separate fill kernel)
+    check(L.vqhip_encode_ex(_ptr(x), dt, _ptr(e), N, K, D, m, _ptr(image), _ptr(idx), _ptr(hist), _ptr(xq), _ptr(ws),
+                            1 if (zero_hist and hist is not None) else 0, _stream()), 'vqhip_encode_ex')
     return idx, PreparedCodebook(image, e, K, D, m), xq
 
 

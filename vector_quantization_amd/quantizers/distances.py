@@ -164,15 +164,17 @@ class BaseDistance(nn.Module, ABC):
         return ops.prepare_codebook(e, self.metric)
 
     def encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
-               stash: Optional[dict] = None) -> torch.Tensor:
+               stash: Optional[dict] = None, zero_hist: bool = False) -> torch.Tensor:
         """``argmin`` for a codebook that has no prepared image yet (it changes every training step).  The shipped
         distances do image, token side and, for cosine, the normalisation of x in one library call (``_fused_encode``);
         a subclass that only customises ``prepare`` / ``argmin`` gets exactly those."""
+        if zero_hist and hist is not None:
+            hist.zero_()
         return self.argmin(x, e, hist=hist, prepared=self.prepare(e), stash=stash)
 
     def _fused_encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor],
-                      stash: Optional[dict]) -> torch.Tensor:
-        quant, cb, xq = ops.encode(x.detach(), e.detach(), self.metric, hist=hist)
+                      stash: Optional[dict], zero_hist: bool = False) -> torch.Tensor:
+        quant, cb, xq = ops.encode(x.detach(), e.detach(), self.metric, hist=hist, zero_hist=zero_hist)
         if stash is not None:
             stash['xq'] = xq if xq is not None else x.detach()
             rows = cb.exact_rows()
@@ -199,8 +201,8 @@ class L2Distance(BaseDistance):
         """torch.cdist(x, e) (mm path), fp32, differentiable."""
         return _L2Matrix.apply(x, e)
 
-    def encode(self, x, e, hist=None, stash=None):
-        return self._fused_encode(x, e, hist, stash)
+    def encode(self, x, e, hist=None, stash=None, zero_hist=False):
+        return self._fused_encode(x, e, hist, stash, zero_hist)
 
 
 def _bf16_valued(t: torch.Tensor) -> torch.Tensor:
@@ -248,8 +250,8 @@ class CosineDistance(BaseDistance):
             en = en + (_bf16_valued(en.detach()) - en.detach())
         return _DotMatrix.apply(xn, en, self.metric)
 
-    def encode(self, x, e, hist=None, stash=None):
-        return self._fused_encode(x, e, hist, stash)
+    def encode(self, x, e, hist=None, stash=None, zero_hist=False):
+        return self._fused_encode(x, e, hist, stash, zero_hist)
 
     def argmin(self, x, e, hist=None, prepared=None, stash=None):
         cb = prepared if prepared is not None else self.prepare(e)

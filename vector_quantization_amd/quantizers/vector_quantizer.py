@@ -114,13 +114,16 @@ class VectorQuantizer(BaseQuantizer):
         x2 = x.detach().reshape(-1, x.shape[-1])
         # the code-hit histogram is a by-product of the re-rank epilogue; only the training callbacks consume it
         hist = None
-        if self.training and len(self._callbacks.callbacks) > 0:
-            hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
+        want_hist = self.training and len(self._callbacks.callbacks) > 0
         stash = {}
         if self._cache_codebook:
+            if want_hist:
+                hist = torch.zeros(self.codebook_size, dtype=torch.int32, device=x.device)
             quant = self._distance.argmin(x2, w, hist=hist, prepared=self._prepare(w), stash=stash)
         else:                                   # the codebook may have changed since the last call: image made in the same call
-            quant = self._distance.encode(x2, w, hist=hist, stash=stash)
+            if want_hist:                       # zeroed by the call's first launch: no separate fill kernel
+                hist = torch.empty(self.codebook_size, dtype=torch.int32, device=x.device)
+            quant = self._distance.encode(x2, w, hist=hist, stash=stash, zero_hist=True)
         # memo['distance'] stays symbolic.  With autograd on, its operands keep their graph (EntropyLoss differentiates
         # through the matrix: losses.py:130-153); the codebook operand is an alias of the CURRENT weight storage, so the
         # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
