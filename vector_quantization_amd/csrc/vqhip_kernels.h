@@ -774,7 +774,9 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
 #ifdef VQ_STAMPS
         VQ_STAMP(ts_a);
 #endif
+#ifndef VQ_EXP_NODMA           // (timing-only experiment builds, results garbage: profiles/r02_mfma32x32_d32.txt)
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+#endif
 #ifdef VQ_STAMPS
         VQ_STAMP(ts_b); acc_issue += ts_b - ts_a;
 #endif
@@ -891,11 +893,13 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
             }
         }
       };   // run_stage
+#ifndef VQ_EXP_NOBODY
         if constexpr (NOAUX) {
             if (st == (int64_t)pad_stage) run_stage(std::true_type{}); else run_stage(std::false_type{});
         } else {
             run_stage(std::true_type{});
         }
+#endif
         if constexpr (FILTER && (!GROUPS || GBRANCH)) {   // refresh the skip thresholds: best score among the token's four lanes, less the margin
 #pragma unroll
             for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
