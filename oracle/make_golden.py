@@ -180,6 +180,50 @@ def autocast_cases():
         print(f"{name:28s} rows that differ from the fp32 argmin: {int(rec['differs_from_fp32'])}/{N}", flush=True)
 
 
+def autocast_module_cases():
+    """The UNCHANGED VQ-KD and CVQ-VAE quantizer configs (configs/vqkd/model.py:20-26 with configs/vq/interface.py's
+    `distance='Cosine'`; configs/cvqvae/quantizer.py:1-6) executed the way the reference's GPU trainers execute them: every
+    step inside torch.autocast(bf16) (vq/runners/base.py:30-48 appends the AutocastCallback).  Real reference modules,
+    CPU autocast on fp32 inputs — on this path CPU and CUDA autocast cast the same ops (einsum -> bf16; cdist / mse_loss
+    -> fp32; F.normalize stays fp32 because its input is fp32).  Pins the product's `CosineDistance(autocast='auto')`."""
+    x, w = update_inputs()
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    ac = lambda: torch.autocast('cpu', dtype=torch.bfloat16)    # noqa: E731
+    # eval-mode forward of the VQ-KD quantizer (a validator's step)
+    q = ref_quantizer(UPD['K'], UPD['D'], 'Cosine', 'commitment_norm', VQKD_CB, w)
+    with torch.no_grad(), ac():
+        z_eval, loss_eval, memo = q(xt, {})
+    assert memo['encode']['distance'].dtype == torch.bfloat16
+    quant_eval = memo['quant']
+    with torch.no_grad():
+        quant_fp32 = q(xt, {})[2]['quant']
+    # train steps
+    with ac():
+        o = vqkd_step(x, w)
+        r = tr.vqkd_train_step(xt, wt, UPD['ema_decay'])
+    check_restatement('autocast_vqkd', r, o, ('quant', 'w_new', 'loss', 'grad_x'))
+    with ac():
+        s1, s2 = cvq_steps(x, w, 'Cosine')
+        rc = tr.cvq_train_steps(xt, wt, 'Cosine', UPD['ema_decay'], UPD['eps'], steps=2)
+    for got, want, tag in ((rc[0], s1, 'step1'), (rc[1], s2, 'step2')):
+        check_restatement(f'autocast_cvq.{tag}', got, want, ('quant', 'col_idx', 'p', 'w_new', 'anchors', 'decay'))
+    np.savez_compressed(
+        os.path.join(OUT, 'autocast_modules.npz'), x_sha=synth.sha(x), w_sha=synth.sha(w),
+        eval_quant=quant_eval.numpy().astype(np.int32), eval_loss=np.float32(loss_eval.item()),
+        eval_differs_from_fp32=np.int32(int((quant_eval != quant_fp32).sum())),
+        vqkd_quant=o['quant'].numpy().astype(np.int32), vqkd_w_new=o['w_new'].numpy(), vqkd_loss=np.float32(o['loss'].item()),
+        vqkd_grad_x_head=o['grad_x'].numpy()[:8], vqkd_grad_x_sha=synth.sha(o['grad_x'].numpy()),
+        cvq_quant=s1['quant'].numpy().astype(np.int32), cvq_col_idx=s1['col_idx'].numpy().astype(np.int32),
+        cvq_p1=s1['p'].numpy(), cvq_w_new=s1['w_new'].numpy(),
+        cvq_quant2=s2['quant'].numpy().astype(np.int32), cvq_col_idx2=s2['col_idx'].numpy().astype(np.int32),
+        cvq_p2=s2['p'].numpy(), cvq_w_new2=s2['w_new'].numpy(),
+        spec=json.dumps(dict(UPD, distance='Cosine', autocast='bf16', source='reference-import',
+                             reference=['vq/runners/base.py:30-48', 'vq/algorithms/vq/distances.py:35-46'] + CITE_VQKD + CITE_CVQ,
+                             configs=['configs/vqkd/model.py:20-26', 'configs/cvqvae/quantizer.py:1-6'])))
+    print(f"autocast_modules            eval rows that differ from the fp32 argmin: {int((quant_eval != quant_fp32).sum())}/{UPD['N']}",
+          flush=True)
+
+
 def special_case():
     """NaN / Inf handling of cdist + argmin (torch: NaN is the minimum, first NaN wins) through the real _encode."""
     N, K, D = 32, 64, 32
@@ -512,6 +556,7 @@ def main(only=(), out_dir=None, quiet=False):
         print_(f'{c[0]:28s} loss={float(rec["loss"]):.6f} used={int((rec["hist"] > 0).sum())}/{c[4]}', flush=True)
     if not only or 'autocast' in only:
         autocast_cases()
+        autocast_module_cases()
     if not only or 'special' in only:
         special_case()
     if not only or 'update' in only:

@@ -227,3 +227,26 @@ def test_composed_callback_threads_values_in_priority_order():
     sentinel = object()
     cc.bind(sentinel)
     assert cc.quantizer is sentinel and all(cb.quantizer is sentinel for cb in cc.callbacks)
+
+
+def test_cosine_distance_follows_autocast(monkeypatch):
+    """CosineDistance() built from an unchanged config ('auto'): the bf16-autocast metric exactly while the caller is inside
+    torch.autocast('cuda', bfloat16) — the region the reference's AutocastCallback opens (vq/runners/base.py:30-48) — and
+    the fp32 definition otherwise (fp16 autocast included).  No GPU here: the autocast state is stubbed."""
+    from vector_quantization_amd.quantizers import distances as DM
+    q = build_quantizer(dict(type='VQKDQuantizer', embedding=dict(type=EMB, num_embeddings=8, embedding_dim=4),
+                             distance=dict(type='CosineDistance'), callbacks=[dict(type='VQKDCallback', ema=dict())],
+                             losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True)))))
+    d = q.distance
+    assert d.metric == 'Cosine'
+    state = dict(on=True, dtype=torch.bfloat16)
+    monkeypatch.setattr(torch, 'is_autocast_enabled', lambda *a: state['on'])
+    monkeypatch.setattr(torch, 'get_autocast_dtype', lambda *a: state['dtype'])
+    assert DM.autocast_bf16_active() and d.metric == 'CosineBF16'
+    assert Q.CosineDistance(autocast=None).metric == 'Cosine' and Q.L2Distance().metric == 'L2'
+    state['dtype'] = torch.float16
+    assert d.metric == 'Cosine'
+    state['on'] = False
+    assert d.metric == 'Cosine' and Q.CosineDistance(autocast='bf16').metric == 'CosineBF16'
+    with pytest.raises(ValueError):
+        Q.CosineDistance(autocast='fp16')

@@ -128,6 +128,39 @@ def test_oracle_bf16_autocast_cosine_matches_reference(path):
         assert (idx != co.cos_argmin(x, w)).sum() == int(z['differs_from_fp32'])
 
 
+def test_oracle_autocast_modules(golden_dir):
+    """The unchanged VQ-KD / CVQ-VAE configs as the reference's GPU trainers run them — inside torch.autocast(bf16)
+    (fixture: the real reference modules, oracle/make_golden.py: autocast_module_cases) — against the C oracle's
+    bf16-autocast cosine definition chained the way the callbacks chain it."""
+    z = np.load(os.path.join(golden_dir, 'autocast_modules.npz'))
+    spec = json.loads(str(z['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    assert synth.sha(x) == str(z['x_sha']) and synth.sha(w) == str(z['w_sha'])
+    # VQ-KD: NormalizeCallback.before_encode normalises x and W (twice: normalize.py:27, callbacks.py:73-75) first
+    xn = co.normalize_rows(x)
+    w0 = co.normalize_rows(co.normalize_rows(w))
+    quant = co.cos_bf16_argmin(xn, w0)
+    np.testing.assert_array_equal(quant, z['eval_quant'].astype(np.int64))
+    np.testing.assert_array_equal(quant, z['vqkd_quant'].astype(np.int64))
+    assert int(z['eval_differs_from_fp32']) == int((quant != co.cos_argmin(xn, w0)).sum()) > 0
+    xs = co.normalize_rows(xn)
+    e = co.normalize_rows(co.ema(w0, co.normalize_rows(co.kmeans_centroids(xs, quant, w0)), 0.99))
+    np.testing.assert_allclose(e, z['vqkd_w_new'], rtol=0, atol=2e-6)
+    # CVQ-VAE: cosine row argmin and NearestAnchor's column argmin on the bf16 matrix
+    q1 = co.cos_bf16_argmin(x, w)
+    np.testing.assert_array_equal(q1, z['cvq_quant'].astype(np.int64))
+    freq = (co.bincount(q1, K) / np.int64(N)).astype(np.float32)
+    p1 = co.ema(np.zeros(K, np.float32), freq, 0.99)
+    np.testing.assert_allclose(p1, z['cvq_p1'], rtol=1e-6, atol=1e-9)
+    # column argmin = the role-swapped row argmin (lowest token among equal bf16 distances)
+    col = co.cos_bf16_argmin(w, x)
+    np.testing.assert_array_equal(col, z['cvq_col_idx'].astype(np.int64))
+    w_new = co.ema(w, x[col], co.cvq_decay(p1, K, 0.99, 1e-3))
+    np.testing.assert_allclose(w_new, z['cvq_w_new'], rtol=0, atol=2e-6)
+
+
 def test_nonfinite_semantics(golden_dir):
     z = np.load(os.path.join(golden_dir, 'special_nonfinite.npz'))
     x, w, wn = z['x'], z['w'], z['w_nan']

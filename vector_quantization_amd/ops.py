@@ -18,6 +18,14 @@ METRICS = {'L2': METRIC_L2, 'Cosine': METRIC_COS, 'CosineBF16': METRIC_COS_BF16,
            METRIC_L2: METRIC_L2, METRIC_COS: METRIC_COS, METRIC_COS_BF16: METRIC_COS_BF16}
 
 
+_METRIC_NAMES = {METRIC_L2: 'L2', METRIC_COS: 'Cosine', METRIC_COS_BF16: 'CosineBF16'}
+
+
+def metric_name(metric) -> str:
+    """'L2' / 'Cosine' / 'CosineBF16' for a metric given by name or by its include/vqhip.h code."""
+    return _METRIC_NAMES[METRICS[metric]]
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -73,14 +73,19 @@ class LazyDistance(torch.Tensor):
 
     @staticmethod
     def __new__(cls, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor, xq: Optional[torch.Tensor] = None,
-                eq: Optional[torch.Tensor] = None):
-        return torch.Tensor._make_wrapper_subclass(cls, (x.shape[0], e.shape[0]), dtype=torch.float32, device=x.device)
+                eq: Optional[torch.Tensor] = None, metric: Optional[str] = None):
+        # under the reference's bf16 autocast the cosine matrix IS a bf16 tensor (distances.py:39-46 on autocast's list)
+        dtype = torch.bfloat16 if (metric or distance.metric) == 'CosineBF16' else torch.float32
+        return torch.Tensor._make_wrapper_subclass(cls, (x.shape[0], e.shape[0]), dtype=dtype, device=x.device)
 
     def __init__(self, distance: 'BaseDistance', x: torch.Tensor, e: torch.Tensor,
-                 xq: Optional[torch.Tensor] = None, eq: Optional[torch.Tensor] = None) -> None:
+                 xq: Optional[torch.Tensor] = None, eq: Optional[torch.Tensor] = None, metric: Optional[str] = None) -> None:
         """``xq`` / ``eq``: the latents / the codebook in the form the exact definition consumes (normalised for
-        cosine), when the encode that produced this handle has already computed them."""
+        cosine), when the encode that produced this handle has already computed them.  ``metric``: the metric the encode
+        ran with — fixed here, so a consumer that touches the handle outside the autocast region of the encode still sees
+        that encode's matrix."""
         self._distance, self._x, self._e, self._xq, self._eq = distance, x, e, xq, eq
+        self._metric = metric or distance.metric
         self._value: Optional[torch.Tensor] = None
 
     @property
@@ -89,22 +94,25 @@ class LazyDistance(torch.Tensor):
 
     @property
     def metric(self) -> str:
-        return self._distance.metric
+        return self._metric
 
     def materialize(self) -> torch.Tensor:
         if self._value is None:
-            self._value = self._distance(self._x, self._e)
+            self._value = self._distance.matrix(self._x, self._e, self._metric)
         return self._value
 
     def fused_argmin(self, dim: int) -> torch.Tensor:
         if dim == 0:        # NearestAnchor: d.argmin(0) — nearest latent per code
             if self._xq is not None:
                 xq = self._xq
-                eq = self._eq if self._eq is not None else self._distance.exact_codebook(self._e)
+                eq = self._eq if self._eq is not None else self._distance.exact_codebook(self._e, self._metric)
             else:
-                xq, eq = self._distance.exact_operands(self._x, self._e)
-            return ops.col_argmin(xq, eq, self.metric)
-        return self._distance.argmin(self._x, self._e)
+                xq, eq = self._distance.exact_operands(self._x, self._e, self._metric)
+            return ops.col_argmin(xq, eq, self._metric)
+        if self._metric == self._distance.metric:
+            return self._distance.argmin(self._x, self._e)
+        # touched outside the autocast region of its encode: the image of that encode's metric
+        return self._distance.argmin(self._x, self._e, prepared=self._distance.prepare(self._e, self._metric))
 
     def __repr__(self):
         return f'LazyDistance({self.metric}, shape={tuple(self.shape)}, materialized={self._value is not None})'
@@ -152,16 +160,20 @@ class BaseDistance(nn.Module, ABC):
     def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         pass
 
-    def exact_operands(self, x: torch.Tensor, e: torch.Tensor):
+    def matrix(self, x: torch.Tensor, e: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
+        """``forward`` under a metric fixed by the caller (a LazyDistance materialising after its encode)."""
+        return self(x, e)
+
+    def exact_operands(self, x: torch.Tensor, e: torch.Tensor, metric: Optional[str] = None):
         """Operands of the fp32 definition (normalised for cosine)."""
         return x.detach(), e.detach()
 
-    def exact_codebook(self, e: torch.Tensor) -> torch.Tensor:
+    def exact_codebook(self, e: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
         """The codebook operand of the fp32 definition alone."""
         return e.detach()
 
-    def prepare(self, e: torch.Tensor) -> ops.PreparedCodebook:
-        return ops.prepare_codebook(e, self.metric)
+    def prepare(self, e: torch.Tensor, metric: Optional[str] = None) -> ops.PreparedCodebook:
+        return ops.prepare_codebook(e, metric or self.metric)
 
     def encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
                stash: Optional[dict] = None, zero_hist: bool = False) -> torch.Tensor:
@@ -180,6 +192,7 @@ class BaseDistance(nn.Module, ABC):
             rows = cb.exact_rows()
             stash['eq'] = rows if rows is not None else e.detach()
             stash['prepared'] = cb
+            stash['metric'] = ops.metric_name(cb.metric)
         return quant
 
     def argmin(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
@@ -190,6 +203,7 @@ class BaseDistance(nn.Module, ABC):
         if stash is not None:
             stash['xq'] = x.detach()
             stash['eq'] = e.detach()
+            stash['metric'] = ops.metric_name(cb.metric)
         return ops.argmin(x.detach(), cb, hist=hist)
 
 
@@ -209,54 +223,80 @@ def _bf16_valued(t: torch.Tensor) -> torch.Tensor:
     return t.bfloat16().float()
 
 
+def autocast_bf16_active() -> bool:
+    """True inside ``torch.autocast('cuda', dtype=torch.bfloat16)`` — the region the reference's AutocastCallback opens
+    around every GPU train / validation step (vq/runners/base.py:30-48; bf16 wherever the device supports it, which
+    MI355X does).  fp16 autocast has no counterpart in the library: the fp32 definition is used."""
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
 @VQITQuantizerDistanceRegistry.register_()
 class CosineDistance(BaseDistance):
-    """``autocast='bf16'`` (extension, default None = the fp32 definition of distances.py:35-46): the values the
-    reference's GPU runs compute under its autocast callback (vq/runners/base.py:30-48) — normalisation in fp32, the
-    einsum on bf16 operands with a bf16 result, ``1 - s`` in bf16, hence the lowest index among equal bf16 distances
-    (5.7 % of the rows have such ties).  The products are summed in the fp32 definition's order, so a
-    row can differ from one particular GEMM's summation order only where the fp32 sum straddles a bf16 rounding
-    boundary.  Gradients of a materialised matrix are those of the fp32 definition (straight through the rounding)."""
+    """distances.py:35-46, INCLUDING what torch autocast makes of it.  The reference's GPU trainers and validators run
+    every step inside ``torch.autocast('cuda', bfloat16)`` (vq/runners/base.py:30-48 appends an AutocastCallback):
+    ``F.normalize`` is on autocast's fp32 list, the einsum on its bf16 list — normalisation in fp32, the contraction on
+    bf16 operands with a bf16 result, ``1 - s`` in bf16, hence the lowest index among equal bf16 distances (SURVEY.md
+    §7-7: 5.7 % of the rows have such ties).  ``autocast`` (extension; configs need not name it):
 
-    def __init__(self, *args, autocast: Optional[str] = None, **kwargs) -> None:
+      'auto' (default) — follow the caller: bf16 semantics (``VQHIP_METRIC_COS_BF16``) while
+                         ``torch.is_autocast_enabled('cuda')`` with dtype bfloat16, the fp32 definition otherwise —
+                         so an unchanged VQ-KD / CVQ-VAE / cluster config returns the reference's indices in both modes;
+      None             — always the fp32 definition;   'bf16' — always the autocast values.
+
+    The products are summed in the fp32 definition's order, so a row can differ from one particular GEMM's summation
+    order only where the fp32 sum straddles a bf16 rounding boundary.  Gradients of a materialised matrix are those of
+    the fp32 definition (straight through the rounding)."""
+
+    def __init__(self, *args, autocast: Optional[str] = 'auto', **kwargs) -> None:
         super().__init__(*args, **kwargs)
-        if autocast not in (None, 'bf16'):
-            raise ValueError(f"CosineDistance: autocast must be None or 'bf16', got {autocast!r}")
+        if autocast not in (None, 'auto', 'bf16'):
+            raise ValueError(f"CosineDistance: autocast must be 'auto', None or 'bf16', got {autocast!r}")
         self._autocast = autocast
+
+    def _bf16(self) -> bool:
+        if self._autocast == 'auto':
+            return autocast_bf16_active()
+        return self._autocast == 'bf16'
 
     @property
     def metric(self) -> str:
-        return 'CosineBF16' if self._autocast == 'bf16' else 'Cosine'
+        return 'CosineBF16' if self._bf16() else 'Cosine'
 
-    def _operand(self, t: torch.Tensor) -> torch.Tensor:
+    def _operand(self, t: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
         n = ops.normalize_rows(t.detach())
-        return _bf16_valued(n) if self._autocast == 'bf16' else n
+        return _bf16_valued(n) if (metric or self.metric) == 'CosineBF16' else n
 
-    def exact_operands(self, x: torch.Tensor, e: torch.Tensor):
-        return self._operand(x), self._operand(e)
+    def exact_operands(self, x: torch.Tensor, e: torch.Tensor, metric: Optional[str] = None):
+        return self._operand(x, metric), self._operand(e, metric)
 
-    def exact_codebook(self, e: torch.Tensor) -> torch.Tensor:
-        return self._operand(e)
+    def exact_codebook(self, e: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
+        return self._operand(e, metric)
 
     @staticmethod
     def cosine_similarity(x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
         """normalize(x) @ normalize(e).T, returned as 1 - distance (the distance kernel's own value)."""
         return 1 - _DotMatrix.apply(VF.normalize(x), VF.normalize(e), 'Cosine')
 
-    def forward(self, x: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+    def matrix(self, x: torch.Tensor, e: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
+        return self(x, e, metric)
+
+    def forward(self, x: torch.Tensor, e: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
+        metric = metric or self.metric
         xn, en = VF.normalize(x), VF.normalize(e)
-        if self._autocast == 'bf16':            # bf16-valued operands, gradients straight through the rounding
+        if metric == 'CosineBF16':              # bf16-valued operands, gradients straight through the rounding
             xn = xn + (_bf16_valued(xn.detach()) - xn.detach())
             en = en + (_bf16_valued(en.detach()) - en.detach())
-        return _DotMatrix.apply(xn, en, self.metric)
+            return _DotMatrix.apply(xn, en, metric).bfloat16()     # exact: the kernel's values are bf16 values
+        return _DotMatrix.apply(xn, en, metric)
 
     def encode(self, x, e, hist=None, stash=None, zero_hist=False):
         return self._fused_encode(x, e, hist, stash, zero_hist)
 
     def argmin(self, x, e, hist=None, prepared=None, stash=None):
         cb = prepared if prepared is not None else self.prepare(e)
-        xn = self._operand(x)
+        xn = self._operand(x, ops.metric_name(cb.metric))
         if stash is not None:
             stash['xq'] = xn
             stash['eq'] = cb.exact_rows()          # normalize(e), as the image made from e holds it
+            stash['metric'] = ops.metric_name(cb.metric)
         return ops.argmin(xn, cb, hist=hist)   # the image holds normalize(e)

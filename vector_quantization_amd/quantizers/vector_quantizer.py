@@ -100,7 +100,7 @@ class VectorQuantizer(BaseQuantizer):
     def _prepare(self, w: torch.Tensor) -> ops.PreparedCodebook:
         if not self._cache_codebook:
             return self._distance.prepare(w)
-        key = (w.data_ptr(), w._version, tuple(w.shape), w.device)
+        key = (w.data_ptr(), w._version, tuple(w.shape), w.device, self._distance.metric)
         if self._prepared is None or self._prepared_key != key:
             self._prepared = self._distance.prepare(w)
             self._prepared_key = key
@@ -129,9 +129,11 @@ class VectorQuantizer(BaseQuantizer):
         # values are those of encode time even after a callback rebinds weight.data (the reference clones them: :97).
         if torch.is_grad_enabled() and (x.requires_grad or self._embedding.weight.requires_grad):
             weight = self._embedding.weight
-            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight), xq=stash.get('xq'), eq=stash.get('eq'))
+            memo['distance'] = LazyDistance(self._distance, x.reshape(-1, x.shape[-1]), weight.view_as(weight),
+                                            xq=stash.get('xq'), eq=stash.get('eq'), metric=stash.get('metric'))
         else:
-            memo['distance'] = LazyDistance(self._distance, x2, w, xq=stash.get('xq'), eq=stash.get('eq'))
+            memo['distance'] = LazyDistance(self._distance, x2, w, xq=stash.get('xq'), eq=stash.get('eq'),
+                                            metric=stash.get('metric'))
         if hist is not None:
             memo['hist'] = hist
         return quant.reshape(shape), memo
