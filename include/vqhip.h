@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VQHIP_VERSION 100
+#define VQHIP_VERSION 300   /* round 3: + sparse CVQ-VAE anchors, packed exchange, checked workspace sizes */
 
 #define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
 #define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
@@ -178,6 +178,44 @@ int vqhip_cvq_step(const float *w_in, float *w_out, const float *p_in, float *p_
 int vqhip_cvq_decay(const float *p, int64_t K, float ema_decay, float eps, float *decay, void *stream);
 int vqhip_cvq_update_rows(float *w, const float *p, const int64_t *rows, const float *anchors_sub, int64_t M, int64_t K, int D,
                           float ema_decay, float eps, void *stream);
+/* ---- the ONE exchange step of a training forward --------------------------------------------------
+ * Packed fp32 buffer = [counts: low 16 bits, K floats][counts: bits above, K floats][token count in 16-bit pieces, 3 floats]
+ * [0][payload rows M x D], vqhip_pack_floats(K, M, D) floats in all.  Each count piece is an integer < 2^16, so a SUM
+ * all-reduce over up to 256 ranks adds them EXACTLY in fp32 whatever the order: the code-hit histogram and the token
+ * count (QuantStatistics' two int64 all-reduces, vq/algorithms/vq/utils.py:34-35) travel in the same collective as the fp32
+ * payload (VQ-KD centroid sums, vqkd/quantizers/callbacks.py:63-64; CVQ-VAE anchors, cvqvae/anchors.py:65-67).
+ * vqhip_pack_counts writes the header from an int32 (hist_is_int64 = 0) or int64 histogram; vqhip_unpack_counts turns an
+ * all-reduced header back into int64 out[K+1] = counts ‖ token count. */
+int64_t vqhip_pack_floats(int64_t K, int64_t M, int D);
+int vqhip_pack_counts(const void *hist, int hist_is_int64, int64_t numel, int64_t K, float *packed, void *stream);
+int vqhip_unpack_counts(const float *packed, int64_t K, int64_t *out, void *stream);
+
+/* CVQ-VAE with anchors for the codes that can need one (quantizer_callback.py:85-103, NearestAnchor anchors.py:83-84).
+ * decay_k == 1.0f — every code in regular use — multiplies the code's anchor by exactly 0.  vqhip_cvq_rows lists, from the
+ * probabilities BEFORE this step's update, the codes whose decay can still come out below 1 (the coming p is >= p*ema_decay
+ * and decay is monotone in p; a safety factor of 14 on the rounding boundary: vqhip_exchange_kernels.h): rows[0..count)
+ * ascending, slot[k] = position of code k in rows or -1, count[0] — all DEVICE int32 (rows, slot: K entries).  The set
+ * depends only on the synchronised p, so every rank derives the same one before anything is exchanged.
+ * vqhip_col_argmin_rows: col_idx[i] = nearest latent of code rows[i] for i < count — vqhip_col_argmin's pipeline and
+ *   arithmetic on the listed codes; the launches are sized for `cap` (>= the count; the host need not know it: a HIP graph
+ *   captures cap = K), rows past the count cost an early exit; ws = vqhip_col_rows_workspace_bytes(N, cap, D).
+ * vqhip_cvq_pack: this rank's packed buffer — header from the int32 epilogue histogram, payload row i = x[col_idx[i]]
+ *   for i < count, zeros up to cap.  All-reduce the first vqhip_pack_floats(K, cap, D) floats.
+ * vqhip_cvq_apply: p_out = p_in*g + (hist/numel)*(1-g); decay as above; w_out[k] = w_in[k]*decay + a*(1-decay) for listed
+ *   codes, w_in[k]*decay (= w_in[k]) for the others.  packed != NULL: counts and anchor sums from the all-reduced buffer,
+ *   a = sum/world; packed == NULL (one rank): counts from hist/numel, a = x[col_idx[slot[k]]].  Outputs may alias inputs.
+ *   Bit-identical to vqhip_cvq_update / vqhip_cvq_step on finite data (a non-listed code keeps w_k instead of w_k*1 + a*0:
+ *   only a negative-zero weight or a non-finite anchor could tell the difference). */
+int vqhip_cvq_rows(const float *p, int64_t K, float ema_decay, float eps, int32_t *rows, int32_t *slot, int32_t *count,
+                   void *stream);
+int64_t vqhip_col_rows_workspace_bytes(int64_t N, int64_t cap, int D);
+int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
+                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, void *stream);
+int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtype, const int64_t *col_idx, const int32_t *count,
+                   int64_t cap, int64_t K, int D, float *packed, void *stream);
+int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
+                    const void *x, int x_dtype, const int64_t *col_idx, const float *packed, int world, const int32_t *slot,
+                    int64_t K, int D, float ema_decay, float eps, void *stream);
 /* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
 int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
                       void *stream);

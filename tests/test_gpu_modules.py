@@ -107,7 +107,7 @@ def test_normalize_callback_llamagen_shape():
     np.testing.assert_array_equal(memo['quant'].cpu().numpy(), co.l2_argmin(xo, wo))
     gz = np.load(os.path.join(GOLDEN, 'norml2_llamagen_d8.npz'))
     assert abs(loss.item() - float(gz['loss'])) <= 1e-5
-    assert (memo['quant'].cpu().numpy() != gz['quant']).mean() < 0.01        # vs reference ops: envelope rows only
+    np.testing.assert_array_equal(memo['quant'].cpu().numpy(), gz['quant'].astype(np.int64))   # vs the reference's ATen ops: 0 rows differ
 
 
 def vqkd_cfg(K, D):
@@ -343,30 +343,122 @@ def test_deterministic_mode_reproducible_codebook_gradient():
 @pytest.mark.gpu
 @pytest.mark.parametrize('dist', ['L2', 'Cosine'])
 def test_cvq_sparse_anchor_exchange_same_result(dist):
-    """CVQVAECallback(sparse_anchors=True): anchors only for the codes whose decay is below 1 (the others are multiplied
-    by exactly 0).  Several training steps give bit-identical codebooks and probabilities to the dense data flow."""
+    """CVQVAECallback's default data flow — anchors only for the codes whose decay can come out below 1, listed on the
+    device (vqhip_cvq_rows), column argmin over those (vqhip_col_argmin_rows), one fused update (vqhip_cvq_apply) — against
+    the reference's dense flow (sparse_anchors=False): bit-identical codebooks, probabilities and tokens step after step,
+    a list that shrinks as codes come into use, and no host synchronisation after the first step."""
     N, K, D = 3000, 2048, 64
     g = synth.rng(31)
     w0 = synth.unit_rows(g.standard_normal((K, D), dtype=np.float32))
-    xs = [g.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + w0[g.integers(0, K // 8, N)] for _ in range(4)]
+    xs = [g.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + w0[g.integers(0, K // 8, N)] for _ in range(6)]
     outs = []
-    for sparse in (False, True):
+    for sparse in (False, None):
         cfg = vqgan_cfg(K, D, dist, callbacks=[dict(type='CVQVAECallback', ema=dict(), sparse_anchors=sparse,
                                                     anchor=dict(type='NearestAnchor'))])
         q = build(cfg, train=True, init=dict(type='vqgan'))
         set_weight(q, w0)
-        quants = []
+        quants, rows = [], []
         for x in xs:                                     # most tokens sit on an eighth of the codes: the rest go stale
             _, _, memo = q(torch.from_numpy(x).cuda(), {})
             quants.append(memo['quant'].clone())
-        outs.append((q.embedding.weight.detach().clone(), q.get_buffer('_probability').clone(), quants))
+            rows.append(q._callbacks.callbacks[0].last_exchange_rows)
+        outs.append((q.embedding.weight.detach().clone(), q.get_buffer('_probability').clone(), quants, rows))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+    rows = outs[1][3]
+    assert outs[0][3] == [None] * 6 and rows[0] == K and rows[-1] < rows[0], rows
     from vector_quantization_amd import ops
-    decay = ops.cvq_decay(outs[1][1].contiguous(), K, 0.99, 1e-3)
-    frac = float((decay < 1.0).float().mean())
-    assert 0.0 < frac < 1.0, frac                         # the test exercises both kinds of code
+    # the list is a superset of {decay < 1} for the step it serves, and tight: nothing with decay == 1 far inside
+    p_prev = outs[1][1].contiguous()
+    r, slot, count = ops.cvq_rows(p_prev, K, 0.99, 1e-3)
+    listed = torch.zeros(K, dtype=torch.bool, device='cuda')
+    listed[r[: int(count)].long()] = True
+    assert torch.equal(slot >= 0, listed) and torch.equal(r[: int(count)].long(), torch.nonzero(listed).reshape(-1))
+    for freq in (torch.zeros(K, device='cuda'), torch.rand(K, device='cuda') / K):
+        p_next = p_prev * 0.99 + freq * (1 - 0.99)
+        decay = ops.cvq_decay(p_next.contiguous(), K, 0.99, 1e-3)
+        assert bool((decay[~listed] == 1.0).all())
+    assert 0 < int(count) < K
+
+
+def test_sparse_anchor_pieces_match_the_dense_ops():
+    """vqhip_col_argmin_rows == vqhip_col_argmin on the listed codes (every metric, bf16 latents, a capacity above the
+    count), the packed count header survives a float SUM exactly, and vqhip_cvq_apply == vqhip_cvq_step."""
+    from vector_quantization_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(5)
+    N, K, D = 3072, 4096, 64
+    x = torch.randn(N, D, device='cuda', generator=g)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    p = torch.rand(K, device='cuda', generator=g) * 4e-5            # decay arguments straddle the threshold
+    rows, slot, count = ops.cvq_rows(p, K, 0.99, 1e-3)
+    M = int(count)
+    assert 0 < M < K
+    for metric, xx, ww in (('L2', x, w), ('L2', x.bfloat16(), w), ('Cosine', ops.normalize_rows(x), ops.normalize_rows(w)),
+                           ('CosineBF16', ops.normalize_rows(x).bfloat16().float(), ops.normalize_rows(w).bfloat16().float())):
+        full = ops.col_argmin(xx, ww, metric)
+        for cap in (M, K, min(K, M + 77)):
+            sub = ops.col_argmin_rows(xx, ww, rows, count, cap, metric)
+            assert torch.equal(sub[:M], full[rows[:M].long()]), (metric, cap)
+    # empty list: nothing is launched for the column pass, the update still runs
+    p_hot = torch.full((K,), 1e-3, device='cuda')
+    r0, s0, c0 = ops.cvq_rows(p_hot, K, 0.99, 1e-3)
+    assert int(c0) == 0 and bool((s0 == -1).all())
+    # packed counts: 3 "ranks" summed in fp32, counts far beyond 2^24 in total
+    hists = [torch.randint(0, 2 ** 31 - 1, (K,), device='cuda', dtype=torch.int64, generator=g).to(torch.int32) for _ in range(3)]
+    numels = [2 ** 31 - 5, 12345, 2 ** 40 + 17]
+    acc = torch.zeros(ops.pack_floats(K, 0, D), device='cuda')
+    for h, n in zip(hists, numels):
+        buf = torch.empty_like(acc)
+        ops.pack_counts(h, n, buf)
+        assert float(buf[:2 * K + 3].max()) < 65536 or n >= 2 ** 32
+        acc += buf
+    out = ops.unpack_counts(acc, K)
+    assert torch.equal(out[:K], sum(h.to(torch.int64) for h in hists)) and int(out[K]) == sum(numels)
+    h64 = hists[0].to(torch.int64) * 3
+    buf = torch.empty_like(acc)
+    ops.pack_counts(h64, 7, buf)
+    assert torch.equal(ops.unpack_counts(buf, K)[:K], h64)
+    # one-rank apply == cvq_step (dense) given the same column indices
+    hist = torch.bincount(torch.randint(0, K, (N,), device='cuda', generator=g), minlength=K).to(torch.int32)
+    col_full = ops.col_argmin(x, w, 'L2')
+    w_a, p_a = torch.empty_like(w), torch.empty_like(p)
+    ops.cvq_step(w, w_a, p, p_a, hist, N, x, col_full, 0.99, 1e-3)
+    w_b, p_b = torch.empty_like(w), torch.empty_like(p)
+    ops.cvq_apply(w, w_b, p, p_b, slot, 0.99, 1e-3, hist32=hist, numel=N, x=x, col_idx=ops.col_argmin_rows(x, w, rows, count, K, 'L2'))
+    assert torch.equal(w_a, w_b) and torch.equal(p_a, p_b)
+    # packed apply with world = 1 payload == the same
+    packed = ops.cvq_pack(hist, N, x, col_full[rows[:M].long()].contiguous(), count, M, K)
+    assert packed.numel() == 2 * K + 4 + M * D
+    w_c, p_c = torch.empty_like(w), torch.empty_like(p)
+    ops.cvq_apply(w, w_c, p, p_c, slot, 0.99, 1e-3, packed=packed, world=1)
+    assert torch.equal(w_a, w_c) and torch.equal(p_a, p_c)
+
+
+def test_graphed_quantizer_follows_weight_changes():
+    """a GraphedQuantizer built on a quantizer with cache_codebook=True used to replay the codebook image frozen
+    at capture.  The constructor now switches the cache off; a weight changed between replays (optimizer step,
+    load_state_dict) is what the next replay quantizes against."""
+    from vector_quantization_amd.graphs import GraphedQuantizer
+    N, K, D = 2048, 1024, 64
+    gen = synth.rng(23)
+    w0 = gen.standard_normal((K, D), dtype=np.float32)
+    w1 = gen.standard_normal((K, D), dtype=np.float32)
+    x = gen.standard_normal((N, D), dtype=np.float32)
+    q = build(vqgan_cfg(K, D, cache_codebook=True), train=False, init=dict(type='vqgan'))
+    set_weight(q, w0)
+    xd = torch.from_numpy(x).cuda()
+    gq = GraphedQuantizer(q, xd)
+    assert q._cache_codebook is False
+    _, _, quant = gq(xd)
+    np.testing.assert_array_equal(quant.cpu().numpy(), co.l2_argmin(x, w0))
+    set_weight(q, w1)                                    # in-place change of the live parameter
+    _, _, quant = gq(xd)
+    np.testing.assert_array_equal(quant.cpu().numpy(), co.l2_argmin(x, w1))
+    q.load_state_dict({k: (torch.from_numpy(w0).cuda() if k == '_embedding.weight' else v) for k, v in q.state_dict().items()})
+    z, loss, quant = gq(xd)
+    np.testing.assert_array_equal(quant.cpu().numpy(), co.l2_argmin(x, w0))
+    np.testing.assert_array_equal(z.cpu().numpy(), co.gather_ste(x, w0, co.l2_argmin(x, w0))[1])
 
 
 # ---- rows that were "partial" in round 1: EntropyLoss with autograd, alternative anchors, k-means lazy init --------

@@ -76,8 +76,10 @@ def test_encode_matches_oracle_and_golden(ops, path):
     got = idx.cpu().numpy()
     np.testing.assert_array_equal(got, oracle_idx)                       # bit-exact vs oracle, every case
     tiny = spec['N'] <= 25 and spec['K'] <= 25
-    if spec['kind'] in EXACT_KINDS and not tiny and not spec['normalize']:
-        np.testing.assert_array_equal(got, z['quant'].astype(np.int64))   # and vs the reference ops
+    # and vs the reference's own ATen ops (fixture): every row of every case, except 8 of the 512 rows of the ill-conditioned
+    # U(+-1/K) init at K = 16 384 (two GEMM orders differ there by <= 1 ulp of distance: tests/test_oracle_golden.py)
+    known = {'l2_c2_vqganinit_s3407': 8}
+    assert int((got != z['quant'].astype(np.int64)).sum()) == known.get(spec['name'], 0)
     # the fp32-only entry point agrees bit for bit
     wq = ops.normalize_rows(wd) if spec['distance'] == 'Cosine' else wd
     idx2, dmin = ops.argmin_exact(xq, wq, spec['distance'], return_min=True)

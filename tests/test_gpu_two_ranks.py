@@ -83,6 +83,32 @@ def _worker(rank, world, port, outdir):
             rec[f'{tag}_w_new'] = q.embedding.weight.detach().cpu().numpy()
             rec[f'{tag}_p'] = q.get_buffer('_probability').cpu().numpy()
             rec[f'{tag}_quant'] = memo['quant'].cpu().numpy()
+    # several CVQ-VAE steps with the packed sparse exchange (default) against the reference's dense data flow: bit-identical
+    # codebooks, ONE collective per step, and an exchange that shrinks with the codes that are in regular use
+    from vector_quantization_amd.utils import exchange_log
+    gen = synth.rng(100)
+    wk = synth.unit_rows(gen.standard_normal((K, D), dtype=np.float32))
+    steps = [(gen.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + wk[gen.integers(0, K // 8, N)])[rank::world]
+             for _ in range(5)]
+    runs = {}
+    for sparse in (None, False):
+        cfg = _cfg('cvq', K, D, 'Cosine', False)
+        cfg['callbacks'][0]['sparse_anchors'] = sparse
+        q = build(cfg, init=dict(type='vqgan'), weight=wk)
+        calls, nbytes, rows = [], [], []
+        for xs in steps:
+            exchange_log.start()
+            q(torch.from_numpy(xs).cuda(), {})
+            st = exchange_log.stop()
+            calls.append(st['calls']); nbytes.append(st['bytes']); rows.append(q._callbacks.callbacks[0].last_exchange_rows)
+        assert is_sync(q.embedding.weight.detach())
+        runs[sparse] = (q.embedding.weight.detach().clone(), q.get_buffer('_probability').clone(), calls, nbytes, rows)
+    assert torch.equal(runs[None][0], runs[False][0]) and torch.equal(runs[None][1], runs[False][1])
+    assert runs[None][2] == [1] * 5 and runs[False][2] == [2] * 5, (runs[None][2], runs[False][2])
+    assert runs[None][3] == [4 * (2 * K + 4 + m * D) for m in runs[None][4]]
+    assert runs[None][4][0] == K and runs[None][4][-1] < K, runs[None][4]       # first step: p = 0, every code listed
+    rec['sparse_rows'] = np.asarray(runs[None][4])
+    rec['sparse_w'] = runs[None][0].cpu().numpy()
     # lazy k-means init: gather to rank 0, Lloyd iterations there, broadcast (callbacks.py:77-112).  DRY_RUN off, as in
     # the reference run (rank 0 alone calls _update_embedding inside the loop)
     os.environ['DRY_RUN'] = ''
@@ -100,8 +126,9 @@ def test_callbacks_at_world_size_two(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (dict(np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))) for r in range(2))
+    np.testing.assert_array_equal(r0['sparse_rows'], r1['sparse_rows'])                  # every rank sized the same exchange
     for k in r0:
-        if k.endswith('w_new') or k.endswith('_p') or k == 'lazy_w':
+        if k.endswith('w_new') or k.endswith('_p') or k in ('lazy_w', 'sparse_w'):
             assert r0[k].tobytes() == r1[k].tobytes(), f'ranks disagree on {k}'          # bit-identical codebooks
     g = np.load(os.path.join(GOLDEN, 'update_vqkd.npz'))
     np.testing.assert_array_equal(r0['vqkd_quant'], g['quant_rank0'].astype(np.int64))

@@ -61,6 +61,9 @@ def oracle_encode(spec, x, w):
     return x, w, idx, mind, d
 
 
+KNOWN_ENVELOPE_ROWS = {'l2_c2_vqganinit_s3407': 8}
+
+
 def envelope(spec, x, w, d):
     """Per-row tolerance on the distance value: a few ulps of the cancelling terms, mapped through sqrt."""
     eps = np.float32(2.0 ** -23)
@@ -89,7 +92,9 @@ def test_oracle_matches_reference_ops(path):
     gap = d[rows, gq].astype(np.float64) - d[rows, idx].astype(np.float64)
     assert (gap >= 0).all(), 'oracle argmin is not the minimum of its own distances'
     assert (gap <= env).all(), f'reference pick outside envelope: max gap {gap.max():.3e}'
-    assert neq.mean() <= 0.05
+    # the measured truth, pinned: the oracle equals the reference's ATen indices on every row of every fixture except 8 of
+    # the 512 rows of the ill-conditioned U(+-1/K) init at K = 16 384 (inside the envelope checked above)
+    assert int(neq.sum()) == KNOWN_ENVELOPE_ROWS.get(spec['name'], 0), f"{spec['name']}: {int(neq.sum())} rows differ"
     # the minimum distance itself agrees to fp32 rounding
     np.testing.assert_allclose(mind, z['mind'], rtol=2e-5, atol=float(env.max()))
     # row argmin of the materialised matrix == fused argmin (oracle self-consistency)

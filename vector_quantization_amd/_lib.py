@@ -12,6 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQHIP_LIB') or os.path.join(_HERE, 'libvqhip.so')   # VQHIP_LIB: experiment builds
 
+ABI_VERSION = 300          # VQHIP_VERSION of include/vqhip.h this binding was written against
 METRIC_L2, METRIC_COS, METRIC_COS_BF16 = 0, 1, 5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
@@ -51,6 +52,14 @@ SIGNATURES = {
     'vqhip_cvq_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_cvq_decay': (_i32, [_vp, _i64, _f32, _f32, _vp, _vp]),
     'vqhip_cvq_update_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp]),
+    'vqhip_pack_floats': (_i64, [_i64, _i64, _i32]),
+    'vqhip_pack_counts': (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    'vqhip_unpack_counts': (_i32, [_vp, _i64, _vp, _vp]),
+    'vqhip_cvq_rows': (_i32, [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    'vqhip_col_rows_workspace_bytes': (_i64, [_i64, _i64, _i32]),
+    'vqhip_col_argmin_rows': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'vqhip_cvq_pack': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    'vqhip_cvq_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),
     'vqhip_token_order': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_segsum_workspace_bytes': (_i64, [_i64, _i32]),
@@ -93,6 +102,9 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)            # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.vqhip_version() != ABI_VERSION:
+            raise VqhipError(f'{LIB_PATH} has ABI version {L.vqhip_version()}, this package binds {ABI_VERSION}: '
+                             'rebuild it with vector_quantization_amd/csrc/build.sh')
         _lib = L
     return _lib
 

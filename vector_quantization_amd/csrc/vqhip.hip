@@ -397,8 +397,10 @@ int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, in
 // The proposal + decision pipeline: N rows `x` against the K codes whose prepared image is `cb` and whose fp32 rows
 // (as used by the exact definition) are `e_exact`.  `metric` may carry the internal words (DOT, SWAP).
 // x_prepared: the token side (x_prep) was already produced into `ws` by pre_kernel (encode_fused_front)
+// n_dev (nullable DEVICE int): only rows [0, min(N, *n_dev)) are live; the launches are sized for N
 static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, const void *cb, int64_t N, int64_t K, int D,
-                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream, bool x_prepared = false) {
+                           int metric, int64_t *idx, int32_t *hist, void *ws, void *stream, bool x_prepared = false,
+                           const int *n_dev = nullptr) {
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     VqWsLayout W = vq_ws_layout(N, K, D);
@@ -426,7 +428,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("x_prep_kernel");
     }
     // the proposal kernel also runs the decision stage (the workgroup that completes a token block merges its slices)
-    VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive};
+    VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive, n_dev};
     VqDecideOut dec_arg = dec;                   // launch_coarse decides (knob 6, slice count) whether the proposal kernel runs the
     int fused_done = 0;                          // decision stage itself and reports it here
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s);
@@ -644,6 +646,49 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
     return VQHIP_OK;
 }
 
+int64_t vqhip_col_rows_workspace_bytes(int64_t N, int64_t cap, int D) {
+    if (N <= 0 || cap <= 0 || D <= 0 || !vq_coarse_supported(D)) return 0;
+    // [pipeline workspace for cap rows against N codes][image of the latents as codes][the listed codebook rows][fp32 copy of bf16 latents]
+    const int64_t a = (vq_ws_layout(cap, N, D).total + 1023) / 1024 * 1024;
+    const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+    const int64_t c = (cap * (int64_t)D * 4 + 1023) / 1024 * 1024;
+    return a + b + c + N * (int64_t)D * 4;
+}
+
+int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
+                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, void *stream) {
+    if (!x || !e || !rows || !count || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0 || cap < 0 || cap > K)
+        return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: bad argument");
+    if (cap == 0) return VQHIP_OK;
+    if (!vq_coarse_supported(D)) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: needs D <= 1024, D % 8 == 0 (use vqhip_col_argmin)");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: N or K too large");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: x_dtype");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: metric");
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)ws;
+    const int64_t a = (vq_ws_layout(cap, N, D).total + 1023) / 1024 * 1024;
+    const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
+    const int64_t c = (cap * (int64_t)D * 4 + 1023) / 1024 * 1024;
+    char *pipe_ws = w, *img = w + a;
+    float *esub = (float *)(w + a + b);
+    gather_listed_rows_kernel<<<waves_grid(cap, 4), 256, 0, s>>>(e, rows, count, cap, D, esub);
+    VQ_CHECK_LAUNCH("gather_listed_rows_kernel");
+    const float *codes = (const float *)x;
+    if (x_dtype == VQHIP_DTYPE_BF16) {
+        float *copy = (float *)(w + a + b + c);
+        int64_t n = N * (int64_t)D;
+        int grid = (int)((n + 255) / 256); grid = grid > 4096 ? 4096 : grid;
+        bf16_to_f32_kernel<<<grid, 256, 0, s>>>((const uint16_t *)x, n, copy);
+        VQ_CHECK_LAUNCH("bf16_to_f32_kernel");
+        codes = copy;
+    }
+    // the role-swapped pipeline of vqhip_col_argmin on the listed codes: sized for `cap` rows, live for *count of them
+    const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : (VQ_METRIC_DOT | (metric & VQ_METRIC_BF16));
+    int rc = encode_fused_front(esub, VQHIP_DTYPE_F32, cap, codes, N, D, m, img, pipe_ws, false, nullptr, s);
+    if (rc) return rc;
+    return argmin_pipeline(esub, VQHIP_DTYPE_F32, codes, img, cap, N, D, m, col_idx, nullptr, pipe_ws, stream, /*x_prepared=*/true, count);
+}
+
 int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, float *d, void *ws,
                    void *stream) {
     if (!x || !e || !d || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_distance: bad argument");
@@ -784,6 +829,67 @@ int vqhip_cvq_update_rows(float *w, const float *p, const int64_t *rows, const f
     if (M == 0) return VQHIP_OK;
     cvq_update_rows_kernel<<<waves_grid(M, 4), 256, 0, (hipStream_t)stream>>>(w, p, rows, anchors_sub, M, K, D, ema_decay, eps);
     VQ_CHECK_LAUNCH("cvq_update_rows_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_rows(const float *p, int64_t K, float ema_decay, float eps, int32_t *rows, int32_t *slot, int32_t *count,
+                   void *stream) {
+    if (!p || !rows || !slot || !count || K <= 0 || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_cvq_rows: bad argument");
+    cvq_rows_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(p, K, ema_decay, eps, rows, slot, count);
+    VQ_CHECK_LAUNCH("cvq_rows_kernel");
+    return VQHIP_OK;
+}
+
+int64_t vqhip_pack_floats(int64_t K, int64_t M, int D) {
+    if (K <= 0 || M < 0 || D <= 0) return 0;
+    return VQ_PACK_HEADER(K) + M * (int64_t)D;
+}
+
+int vqhip_pack_counts(const void *hist, int hist_is_int64, int64_t numel, int64_t K, float *packed, void *stream) {
+    if (!hist || !packed || K <= 0 || numel < 0) return fail(VQHIP_EINVAL, "vqhip_pack_counts: bad argument");
+    const int grid = (int)((K + 255) / 256);
+    if (hist_is_int64) pack_counts_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(hist, numel, K, packed);
+    else pack_counts_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(hist, numel, K, packed);
+    VQ_CHECK_LAUNCH("pack_counts_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_unpack_counts(const float *packed, int64_t K, int64_t *out, void *stream) {
+    if (!packed || !out || K <= 0) return fail(VQHIP_EINVAL, "vqhip_unpack_counts: bad argument");
+    unpack_counts_kernel<<<(int)((K + 255) / 256), 256, 0, (hipStream_t)stream>>>(packed, K, out);
+    VQ_CHECK_LAUNCH("unpack_counts_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtype, const int64_t *col_idx, const int32_t *count,
+                   int64_t cap, int64_t K, int D, float *packed, void *stream) {
+    if (!hist || !packed || K <= 0 || D <= 0 || numel <= 0 || cap < 0 || cap > K || (cap > 0 && (!x || !col_idx || !count)))
+        return fail(VQHIP_EINVAL, "vqhip_cvq_pack: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int hb = (int)((K + 255) / 256);
+    const int grid = hb + waves_grid(cap, 4);
+    if (x_dtype == VQHIP_DTYPE_BF16) cvq_pack_kernel<1><<<grid, 256, 0, s>>>(hist, numel, x, col_idx, count, cap, K, D, packed, hb);
+    else if (x_dtype == VQHIP_DTYPE_F32) cvq_pack_kernel<0><<<grid, 256, 0, s>>>(hist, numel, x, col_idx, count, cap, K, D, packed, hb);
+    else return fail(VQHIP_EINVAL, "vqhip_cvq_pack: x_dtype");
+    VQ_CHECK_LAUNCH("cvq_pack_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
+                    const void *x, int x_dtype, const int64_t *col_idx, const float *packed, int world, const int32_t *slot,
+                    int64_t K, int D, float ema_decay, float eps, void *stream) {
+    if (!w_in || !w_out || !p_in || !p_out || !slot || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (packed != nullptr) {
+        if (world < 1 || world > VQ_PACK_MAX_WORLD) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: world must be in [1, 256] (exact fp32 count sums)");
+        cvq_apply_kernel<0, true><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, nullptr, 0, nullptr, nullptr, packed, world, slot, K, D, ema_decay, eps);
+    } else {
+        if (!hist || numel <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: the one-rank form needs hist and numel");   // (x, col_idx: read for listed codes only)
+        if (x_dtype == VQHIP_DTYPE_F32) cvq_apply_kernel<0, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, K, D, ema_decay, eps);
+        else if (x_dtype == VQHIP_DTYPE_BF16) cvq_apply_kernel<1, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, K, D, ema_decay, eps);
+        else return fail(VQHIP_EINVAL, "vqhip_cvq_apply: x_dtype");
+    }
+    VQ_CHECK_LAUNCH("cvq_apply_kernel");
     return VQHIP_OK;
 }
 

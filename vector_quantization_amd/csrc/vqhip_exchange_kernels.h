@@ -1,0 +1,181 @@
+// Codebook-update kernels around the ONE exchange step of a training forward: the CVQ-VAE sparse anchor
+// set, the packed all-reduce buffer (code counts as exactly-summable fp32 pairs next to the fp32 payload), and the update
+// that consumes it.  gfx950 only.  Reference: vq/algorithms/cvqvae/quantizer_callback.py:85-103, anchors.py:50-67,83-84,
+// vq/algorithms/vq/utils.py:26-52, vq/algorithms/vqkd/quantizers/callbacks.py:44-71.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ------------------------------------------------------------------------------------------------
+// Packed exchange buffer (fp32, one SUM all-reduce):
+//   [0, K)       low 16 bits of this rank's code counts        [K, 2K)  the bits above
+//   [2K, 2K+3)   token count in 16-bit pieces                   [2K+3]   zero (keeps the payload 16-byte aligned)
+//   [2K+4, ...)  payload rows [M, D] fp32 (anchors / centroid sums)
+// Every count piece is an integer below 2^16, so sums over up to 256 ranks stay below 2^24 and are EXACT in fp32 in any
+// order — the histogram of vq/algorithms/vq/utils.py:34-35 survives the trip through a float collective bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define VQ_PACK_HEADER(K) (2 * (int64_t)(K) + 4)
+#define VQ_PACK_MAX_WORLD 256
+
+__device__ __forceinline__ int64_t unpack_count(const float *packed, int64_t K, int64_t k) {
+    return (int64_t)packed[K + k] * 65536 + (int64_t)packed[k];
+}
+__device__ __forceinline__ int64_t unpack_numel(const float *packed, int64_t K) {
+    return ((int64_t)packed[2 * K + 2] * 65536 + (int64_t)packed[2 * K + 1]) * 65536 + (int64_t)packed[2 * K];
+}
+
+// header from an int32 (HT = 0) or int64 (HT = 1) histogram
+template <int HT>
+__global__ void pack_counts_kernel(const void *hist, int64_t numel, int64_t K, float *packed) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) {
+        const int64_t h = HT ? ((const int64_t *)hist)[k] : (int64_t)((const int32_t *)hist)[k];
+        packed[k] = (float)(h & 0xFFFF);
+        packed[K + k] = (float)(h >> 16);
+    }
+    if (k == 0) {
+        packed[2 * K] = (float)(numel & 0xFFFF);
+        packed[2 * K + 1] = (float)((numel >> 16) & 0xFFFF);
+        packed[2 * K + 2] = (float)(numel >> 32);
+        packed[2 * K + 3] = 0.0f;
+    }
+}
+// the all-reduced header back as int64 [K + 1] = counts ‖ token count
+__global__ void unpack_counts_kernel(const float *packed, int64_t K, int64_t *out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = unpack_count(packed, K, k);
+    if (k == 0) out[K] = unpack_numel(packed, K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CVQ-VAE: which codes can need an anchor at all
+// ------------------------------------------------------------------------------------------------
+// quantizer_callback.py:97-102: decay_k = 1 - exp(-p_k K 10/(1-g) - eps), w_k = w_k decay_k + a_k (1 - decay_k).
+// For every code in regular use decay_k is EXACTLY 1.0f and its anchor is multiplied by 0.  The coming probability
+// p' = p g + freq (1-g) is not known before the histogram exchange, but p' >= fl(p g) (freq >= 0; every rounding involved
+// is monotone), and the exponent is a monotone function of p' — so a code whose exponent, evaluated at fl(p g) with the
+// update's own expression, is already <= -VQ_CVQ_SURE_ARG has decay == 1.0f whatever this step's histogram turns out to be:
+// 1 - exp(-20) rounds to 1.0f with a factor 14 to spare (exp(-20) = 2.1e-9 against the rounding boundary 2^-25 = 3.0e-8),
+// far beyond anything expf's last-bit behaviour could move.  The set depends on the SYNCHRONISED p only: identical on
+// every rank, known before the exchange.  NaN / negative p: kept (the comparison fails).
+#define VQ_CVQ_SURE_ARG 20.0f
+__device__ __forceinline__ bool cvq_may_need_anchor(float p_old, int64_t K, float ema_decay, float eps) {
+    const float lower = p_old * ema_decay;
+    const float arg = -lower * (float)K * 10.0f / (1.0f - ema_decay) - eps;
+    return !(arg <= -VQ_CVQ_SURE_ARG);
+}
+
+// rows[0..count) = those codes in ascending order, slot[k] = position of code k in rows or -1, count[0] = their number.
+// One 1024-thread workgroup (K is a codebook size: 16 rounds at K = 16 384); ordered compaction by ballot + scan.
+__global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict__ p, int64_t K, float ema_decay, float eps,
+                                                        int32_t *__restrict__ rows, int32_t *__restrict__ slot,
+                                                        int32_t *__restrict__ count) {
+    __shared__ int wtot[16];
+    __shared__ int woff[16];
+    __shared__ int round_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += 1024) {
+        const int64_t k = k0 + threadIdx.x;
+        const bool flag = k < K && cvq_may_need_anchor(p[k], K, ema_decay, eps);
+        const unsigned long long mask = __ballot(flag);
+        if (lane == 0) wtot[wave] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int i = 0; i < 16; ++i) { woff[i] = t; t += wtot[i]; }
+            round_total = t;
+        }
+        __syncthreads();
+        if (k < K) {
+            if (flag) {
+                const int pos = base + woff[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+                rows[pos] = (int32_t)k;
+                slot[k] = pos;
+            } else {
+                slot[k] = -1;
+            }
+        }
+        base += round_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = base;
+}
+
+// out[i] = e[rows[i]] for i < count, zeros up to cap (the role-swapped pipeline reads whole 32-row blocks)
+__global__ void gather_listed_rows_kernel(const float *__restrict__ e, const int32_t *__restrict__ rows,
+                                          const int32_t *__restrict__ count, int64_t cap, int D, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= cap) return;
+    const bool live = i < (int64_t)count[0];
+    const int64_t k = live ? rows[i] : 0;
+    for (int d = lane; d < D; d += 64) out[i * D + d] = live ? e[k * D + d] : 0.0f;
+}
+
+// Packed buffer of one rank for the CVQ-VAE exchange: header from the epilogue histogram, payload row i = the anchor
+// x[col_idx[i]] of listed code i (NearestAnchor, anchors.py:83-84) for i < count, zeros up to cap.
+template <int DT>
+__global__ void cvq_pack_kernel(const int32_t *__restrict__ hist, int64_t numel, const void *__restrict__ x,
+                                const int64_t *__restrict__ col_idx, const int32_t *__restrict__ count, int64_t cap,
+                                int64_t K, int D, float *__restrict__ packed, int header_blocks) {
+    if ((int)blockIdx.x < header_blocks) {
+        const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (k < K) {
+            const int64_t h = hist[k];
+            packed[k] = (float)(h & 0xFFFF);
+            packed[K + k] = (float)(h >> 16);
+        }
+        if (k == 0) {
+            packed[2 * K] = (float)(numel & 0xFFFF);
+            packed[2 * K + 1] = (float)((numel >> 16) & 0xFFFF);
+            packed[2 * K + 2] = (float)(numel >> 32);
+            packed[2 * K + 3] = 0.0f;
+        }
+        return;
+    }
+    const int64_t i = (int64_t)(blockIdx.x - header_blocks) * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= cap) return;
+    float *dst = packed + VQ_PACK_HEADER(K) + i * D;
+    if (i < (int64_t)count[0]) {
+        const int64_t row = col_idx[i];
+        for (int d = lane; d < D; d += 64) dst[d] = load_elem<DT>(x, row * D + d);
+    } else {
+        for (int d = lane; d < D; d += 64) dst[d] = 0.0f;
+    }
+}
+
+// The CVQ-VAE update with anchors for the listed codes only, wave per code — the expressions of cvq_update_kernel /
+// cvq_step_kernel in the same order (bit-identical results on finite data):
+//   p' = p g + (hist/numel)(1-g);  decay = 1 - exp(-p' K 10/(1-g) - eps);  w' = w decay + a (1-decay)   for listed codes,
+//   w' = w decay (decay == 1.0f by construction of the list)                                             for the others.
+// PACKED: counts, token count and the anchor SUMS over `world` ranks come from the all-reduced buffer (a = sum / world:
+// anchors.py:65-67); otherwise one rank: counts from the int32 epilogue histogram, a = x[col_idx[slot]].
+template <int DT, bool PACKED>
+__global__ void cvq_apply_kernel(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist,
+                                 int64_t numel, const void *x, const int64_t *col_idx, const float *packed, int world,
+                                 const int32_t *__restrict__ slot, int64_t K, int D, float ema_decay, float eps) {
+    const int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (k >= K) return;
+    float freq;
+    if constexpr (PACKED) freq = (float)unpack_count(packed, K, k) / (float)unpack_numel(packed, K);
+    else freq = (float)hist[k] / (float)numel;
+    const float pk = p_in[k] * ema_decay + freq * (1.0f - ema_decay);
+    const float decay = cvq_decay_of(pk, K, ema_decay, eps), om = 1.0f - decay;
+    const int s = slot[k];
+    if (s >= 0) {
+        if constexpr (PACKED) {
+            const float *a = packed + VQ_PACK_HEADER(K) + (int64_t)s * D;
+            const float ws = (float)world;
+            for (int d = lane; d < D; d += 64) w_out[k * D + d] = w_in[k * D + d] * decay + (a[d] / ws) * om;
+        } else {
+            const int64_t row = col_idx[s];
+            for (int d = lane; d < D; d += 64) w_out[k * D + d] = w_in[k * D + d] * decay + load_elem<DT>(x, row * D + d) * om;
+        }
+    } else if (w_out != w_in || decay != 1.0f) {
+        for (int d = lane; d < D; d += 64) w_out[k * D + d] = w_in[k * D + d] * decay;
+    }
+    if (lane == 0) p_out[k] = pk;
+}

@@ -610,6 +610,8 @@ struct VqDecideOut {
     int *rescan_list, *multi_list, *exact_list, *counters;
     u64 *keys; float *thr_out; int *rescan_cnt;
     int *arrive;            // one arrival counter per token block of the proposal kernel (zeroed by x_prep_kernel)
+    const int *n_dev;       // nullable DEVICE row count: only rows [0, min(N, *n_dev)) are live (vqhip_col_argmin_rows:
+                            // the launch is sized for a capacity, the actual number of listed codes stays on the device)
 };
 template <bool AGENT>
 __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
@@ -682,7 +684,12 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     // (the kernel is at its SGPR limit there): D <= 32 keeps the vector form
     const int lane = threadIdx.x & 63;
     const int wave = (VQ_SCALAR_WAVE && NSTEP > 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
-    const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image
+    const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image (of the launch's capacity)
+    if (!STREAMK && dec.n_dev != nullptr) {              // device-side row count: token blocks past it have nothing to do
+        const int64_t nd = *dec.n_dev;
+        N = nd < N ? nd : N;
+        if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
+    }
     // Work assignment.  STREAMK false: workgroup = (token block tb, codebook slice sl of nslices), one segment.
     // STREAMK true (small D): the (token block x stage) space, block-major, is cut into gridDim.x equal ranges — every
     // CU gets the same share whatever the number of token blocks — and a workgroup walks its range as one or two
@@ -1298,6 +1305,11 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
                                      const float *xh2, const float *rho2, int64_t Np, VqDecideOut o) {
     __shared__ int wcount[3 * 16];
     __shared__ int wbase[3 * 16];
+    if (o.n_dev != nullptr) {            // device-side row count (uniform: taken before any barrier)
+        const int64_t nd = *o.n_dev;
+        N = nd < N ? nd : N;
+        if ((int64_t)blockIdx.x * blockDim.x >= N) return;
+    }
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool oob = n >= N;
     if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
@@ -2625,3 +2637,5 @@ __global__ void debug_margin_kernel(const char *cb, VqCbLayout L, int64_t N, int
     if (n == 0) scale[0] = cb_scale(st);
     if (n < N) margin[n] = row_margin(st, L.Dp, metric, xh2[n], rho2[n]);
 }
+
+#include "vqhip_exchange_kernels.h"

@@ -12,6 +12,11 @@ What capture needs from the step, and how the quantizer provides it:
     every step (callbacks/update.py:56, quantizer_callback.py:72-73); a replayed graph would keep reading the old
     storage.  ``quantizer.inplace_updates = True`` makes the same callbacks write the same values INTO the existing
     storage instead (value-identical; optimizer state keyed on the Parameter is unaffected either way).
+  * a codebook image that follows the weight: ``cache_codebook`` is switched off (its Python-side key would be evaluated
+    once, at capture), so the image kernels are part of the graph;
+  * ``memo['encode']['distance']`` of a replayed step is not available (the step returns tensors only); with
+    ``inplace_updates`` its codebook operand is the live storage, i.e. a consumer that materialises the matrix AFTER the
+    update callback sees the updated codebook (the reference clones: quantizers.py:97) — no shipped config does.
 Collectives: captured as issued; RCCL ("nccl") supports capture, gloo does not — use the graph at world size 1 or on RCCL.
 """
 from __future__ import annotations
@@ -51,25 +56,36 @@ class GraphedQuantizer(nn.Module):
             raise RuntimeError('the quantizer still has a pending forward pre-hook (lazy init): run one eager step first')
         self.quantizer = quantizer
         quantizer.inplace_updates = True
+        # A cached codebook image is chosen by a Python-side key at CAPTURE time: the prepare launch would not be recorded
+        # and every replay would propose candidates from the image frozen then, whatever the weight has become.  The graph
+        # therefore always contains the image kernels (17 us at K = 16 384, D = 256) and follows the live weight.
+        if getattr(quantizer, '_cache_codebook', False):
+            quantizer._cache_codebook = False
+        if hasattr(quantizer, 'invalidate_codebook'):
+            quantizer.invalidate_codebook()
+        # scratch of the fused loss mean, owned by this graph (ops.owned_mse_scratch)
+        self._mse_scratch = torch.zeros(16, dtype=torch.uint8, device=sample_x.device)
         self._train = quantizer.training
         self._shape, self._dtype = tuple(sample_x.shape), sample_x.dtype
         saved = {k: v.detach().clone() for k, v in quantizer.state_dict().items()}
         step = _Step(quantizer)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
-        if self._train:
-            sample = sample_x.detach().clone().requires_grad_(True)
-            self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup)
-        else:
-            self._x = sample_x.detach().clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(warmup):
-                    step(self._x)
-            torch.cuda.current_stream().wait_stream(side)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph), torch.no_grad():
-                self._out = step(self._x)
+        from . import ops
+        with ops.owned_mse_scratch(self._mse_scratch):
+            if self._train:
+                sample = sample_x.detach().clone().requires_grad_(True)
+                self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup)
+            else:
+                self._x = sample_x.detach().clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(warmup):
+                        step(self._x)
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph), torch.no_grad():
+                    self._out = step(self._x)
         with torch.no_grad():                                    # undo the side effects of warm-up and capture
             for k, v in quantizer.state_dict().items():
                 v.copy_(saved[k])

@@ -26,6 +26,11 @@ def metric_name(metric) -> str:
     return _METRIC_NAMES[METRICS[metric]]
 
 
+def coarse_supported(D: int) -> bool:
+    """True where the fp16 proposal image exists (D <= 1024, D % 8 == 0: every shipped config)."""
+    return 1 <= D <= 1024 and D % 8 == 0
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -268,7 +273,30 @@ def gather_ste_loss(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z:
 _MSE_SCRATCH: dict = {}      # (device index, stream) -> 16 zeroed bytes the kernel hands back zeroed
 
 
+_MSE_SCRATCH_OWNED: list = []    # innermost `owned_mse_scratch` buffer, if any
+
+
+class owned_mse_scratch:
+    """While active, ``gather_ste_mse`` uses ``buf`` (16 zeroed device bytes the caller owns) instead of the per-stream
+    cache.  GraphedQuantizer captures with its own buffer: two captured graphs never share a scratch (they could replay
+    concurrently on different streams), and no zero-fill is captured into the graph."""
+
+    def __init__(self, buf: torch.Tensor) -> None:
+        assert buf.is_cuda and buf.numel() * buf.element_size() >= 16
+        self.buf = buf
+
+    def __enter__(self):
+        _MSE_SCRATCH_OWNED.append(self.buf)
+        return self.buf
+
+    def __exit__(self, *exc):
+        _MSE_SCRATCH_OWNED.pop()
+        return False
+
+
 def _mse_scratch(device: torch.device) -> torch.Tensor:
+    if _MSE_SCRATCH_OWNED and _MSE_SCRATCH_OWNED[-1].device == device:
+        return _MSE_SCRATCH_OWNED[-1]
     key = (device.index, _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _MSE_SCRATCH.get(key)
     if buf is None:
@@ -469,6 +497,109 @@ def cvq_update_rows_(w: torch.Tensor, p: torch.Tensor, rows: torch.Tensor, ancho
     assert anchors_sub.shape == (rows.numel(), D)
     check(_lib.lib().vqhip_cvq_update_rows(_ptr(w), _ptr(p), _ptr(rows), _ptr(anchors_sub), rows.numel(), K, D, ema_decay,
                                            eps, _stream()), 'vqhip_cvq_update_rows')
+
+
+# ---- CVQ-VAE with anchors for the codes that can need one, and the packed exchange (include/vqhip.h) ----------------
+
+@_on_tensor_device
+def cvq_rows(p: torch.Tensor, K: int, ema_decay: float, eps: float, out=None):
+    """(rows int32[K], slot int32[K], count int32[1]) — the codes whose decay can come out below 1 in the step that starts
+    from the probabilities ``p`` (ascending; slot[k] = position in rows or -1).  ``out``: reuse those three tensors."""
+    _require_cuda(p)
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.numel() == K
+    if out is None:
+        rows = torch.empty(K, dtype=torch.int32, device=p.device)
+        slot = torch.empty(K, dtype=torch.int32, device=p.device)
+        count = torch.empty(1, dtype=torch.int32, device=p.device)
+    else:
+        rows, slot, count = out
+    check(_lib.lib().vqhip_cvq_rows(_ptr(p), K, ema_decay, eps, _ptr(rows), _ptr(slot), _ptr(count), _stream()), 'vqhip_cvq_rows')
+    return rows, slot, count
+
+
+@_on_tensor_device
+def col_argmin_rows(x: torch.Tensor, e: torch.Tensor, rows: torch.Tensor, count: torch.Tensor, cap: int, metric='L2') -> torch.Tensor:
+    """NearestAnchor indices of the listed codes only: out[i] = nearest latent of code rows[i] for i < count (int64 [cap];
+    entries past the count are unspecified).  ``cap`` >= the count sizes the launches."""
+    _require_cuda(x, e, rows, count)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    assert rows.dtype == torch.int32 and count.dtype == torch.int32 and 0 <= cap <= K
+    L = _lib.lib()
+    out = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+    if cap > 0:
+        ws = _bytes(L.vqhip_col_rows_workspace_bytes(N, cap, D), x.device)
+        check(L.vqhip_col_argmin_rows(_ptr(x), dt, _ptr(e), _ptr(rows), _ptr(count), cap, N, K, D, METRICS[metric], _ptr(out),
+                                      _ptr(ws), _stream()), 'vqhip_col_argmin_rows')
+    return out[:cap]
+
+
+def pack_floats(K: int, M: int, D: int) -> int:
+    return int(_lib.lib().vqhip_pack_floats(K, M, D))
+
+
+@_on_tensor_device
+def pack_counts(hist: torch.Tensor, numel: int, packed: torch.Tensor) -> torch.Tensor:
+    """Header of the packed exchange buffer from an int32 / int64 histogram and this rank's token count."""
+    _require_cuda(hist, packed)
+    K = hist.numel()
+    assert hist.dtype in (torch.int32, torch.int64) and hist.is_contiguous()
+    assert packed.dtype == torch.float32 and packed.is_contiguous() and packed.numel() >= 2 * K + 4
+    check(_lib.lib().vqhip_pack_counts(_ptr(hist), 1 if hist.dtype == torch.int64 else 0, int(numel), K, _ptr(packed), _stream()),
+          'vqhip_pack_counts')
+    return packed
+
+
+@_on_tensor_device
+def unpack_counts(packed: torch.Tensor, K: int) -> torch.Tensor:
+    """int64 [K + 1] = code counts ‖ token count of an (all-reduced) packed buffer."""
+    _require_cuda(packed)
+    assert packed.dtype == torch.float32 and packed.is_contiguous()
+    out = torch.empty(K + 1, dtype=torch.int64, device=packed.device)
+    check(_lib.lib().vqhip_unpack_counts(_ptr(packed), K, _ptr(out), _stream()), 'vqhip_unpack_counts')
+    return out
+
+
+@_on_tensor_device
+def cvq_pack(hist32: torch.Tensor, numel: int, x: torch.Tensor, col_idx: torch.Tensor, count: torch.Tensor, cap: int, K: int) -> torch.Tensor:
+    """This rank's packed buffer for the CVQ-VAE exchange: fp32 [2K + 4 + cap*D]."""
+    _require_cuda(hist32, x)
+    x, dt = _latents(x)
+    D = x.shape[1]
+    assert hist32.dtype == torch.int32 and hist32.is_contiguous() and hist32.numel() == K
+    packed = torch.empty(pack_floats(K, cap, D), dtype=torch.float32, device=x.device)
+    check(_lib.lib().vqhip_cvq_pack(_ptr(hist32), int(numel), _ptr(x), dt, _ptr(col_idx) if cap else None, _ptr(count) if cap else None,
+                                    cap, K, D, _ptr(packed), _stream()), 'vqhip_cvq_pack')
+    return packed
+
+
+@_on_tensor_device
+def cvq_apply(w_in: torch.Tensor, w_out: torch.Tensor, p_in: torch.Tensor, p_out: torch.Tensor, slot: torch.Tensor,
+              ema_decay: float, eps: float, hist32: Optional[torch.Tensor] = None, numel: int = 0,
+              x: Optional[torch.Tensor] = None, col_idx: Optional[torch.Tensor] = None,
+              packed: Optional[torch.Tensor] = None, world: int = 1) -> None:
+    """The CVQ-VAE update with anchors for the listed codes (``slot``): from the all-reduced ``packed`` buffer of ``world``
+    ranks, or (one rank) from ``hist32`` / ``numel`` / ``x`` / ``col_idx``.  ``w_out`` / ``p_out`` may alias the inputs."""
+    _require_cuda(w_in, w_out, p_in, p_out, slot)
+    K, D = w_in.shape
+    for t in (w_in, w_out):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (K, D)
+    for t in (p_in, p_out):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == K
+    assert slot.dtype == torch.int32 and slot.numel() == K
+    dt = _lib.DTYPE_F32
+    if packed is None:
+        assert hist32 is not None and hist32.dtype == torch.int32 and hist32.is_contiguous() and numel > 0
+        if x is not None:
+            x, dt = _latents(x)
+            assert x.shape[1] == D
+    else:
+        assert packed.dtype == torch.float32 and packed.is_contiguous()
+    check(_lib.lib().vqhip_cvq_apply(_ptr(w_in), _ptr(w_out), _ptr(p_in), _ptr(p_out), _ptr(hist32), int(numel), _ptr(x), dt,
+                                     _ptr(col_idx), _ptr(packed), int(world), _ptr(slot), K, D, ema_decay, eps, _stream()),
+          'vqhip_cvq_apply')
 
 
 def _any(t: torch.Tensor):

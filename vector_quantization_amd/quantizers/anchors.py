@@ -12,7 +12,7 @@ from torch import nn
 from .. import ops
 from ..config import Config
 from ..registries import AnchorRegistry
-from ..utils import Store, all_gather, get_world_size, is_sync
+from ..utils import Store, all_gather, all_reduce_sum, get_world_size, is_sync
 from .memo import Memo
 from .distances import LazyDistance, as_distance_tensor
 
@@ -51,7 +51,7 @@ class BaseAnchor(nn.Module, ABC):
             if Store.DRY_RUN:
                 assert is_sync(anchors)
         elif get_world_size() > 1:
-            dist.all_reduce(anchors)
+            all_reduce_sum(anchors)
             anchors /= get_world_size()
         return anchors, memo
 

@@ -13,7 +13,7 @@ from typing import TYPE_CHECKING, Iterable, Mapping
 import torch
 import torch.distributed as dist
 
-from .. import ops
+from .. import exchange, ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
 from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, gather_to_rank0, get_rank,
@@ -224,11 +224,12 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
     def _statistics(self, x: torch.Tensor, quant: torch.Tensor, sync: bool):
         """Histogram + per-code sums of the assigned (already normalised) latents, all-reduced when syncing."""
         K = self.vector_quantizer.codebook_size
-        hist = ops.hist(quant, K).to(torch.int64)
+        hist = ops.hist(quant, K)
         sums = ops.scatter_add_rows(x, quant, K)
-        if sync and get_world_size() > 1:
-            hist, _, sums = all_reduce_statistics(hist, quant.numel(), sums)
-        return hist, sums
+        if sync and get_world_size() > 1:          # histogram, token count and the K x D sums in ONE collective
+            hist, _, sums = exchange.all_reduce_packed(hist, quant.numel(), sums)
+            return hist, sums
+        return hist.to(torch.int64), sums
 
     def _kmeans(self, x: torch.Tensor, quant: torch.Tensor, sync: bool) -> torch.Tensor:
         """callbacks.py:44-71 — centroids, old row kept where a code received no token."""
@@ -280,16 +281,22 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
 @VQITQuantizerCallbackRegistry.register_()
 class CVQVAECallback(UpdateMixin, BaseCallback):
 
-    def __init__(self, *args, anchor, eps: float = 1e-3, sparse_anchors: bool = False, **kwargs) -> None:
-        """``sparse_anchors`` (extension, default off = the reference's data flow): anchors are computed, all-reduced
-        and applied only for the codes whose decay is below 1 — every code in regular use has decay == 1.0f exactly
-        and its anchor is multiplied by 0.  Same result (see include/vqhip.h, vqhip_cvq_update_rows), a column argmin
-        over a fraction of the codebook and an [M, D] instead of a [K, D] all-reduce; costs one host synchronisation
-        per step (the number of such codes sizes the exchange).  NearestAnchor only."""
+    def __init__(self, *args, anchor, eps: float = 1e-3, sparse_anchors: bool | None = None, **kwargs) -> None:
+        """``sparse_anchors`` (extension; None = automatic, the default): anchors are computed, exchanged and applied only
+        for the codes whose decay can come out below 1 — every code in regular use has decay == 1.0f exactly and its anchor
+        is multiplied by 0 (include/vqhip.h, vqhip_cvq_rows).  Same codebooks bit for bit on finite data; the column argmin
+        runs over a fraction of the codebook and ONE all-reduce carries histogram, token count and [M, D] anchors instead
+        of three collectives and a [K, D] tensor.  The list is built on the device from the synchronised probabilities, so
+        every rank has the same one and nothing waits for the host: the count a step needs to size its exchange was
+        copied to pinned memory at the end of the previous step; under HIP-graph capture the launches are sized for K and
+        the device-side count decides.  Automatic = NearestAnchor without sync, fused distance, D with a proposal image.
+        False: the reference's dense data flow (a [K, D] anchor tensor, all-reduced on its own)."""
         super().__init__(*args, **kwargs)
         self._anchor = anchor
         self._eps = eps
         self._sparse_anchors = sparse_anchors
+        self._listed = None               # (p tensor, its _version, rows, slot, count, pinned host count, copy event)
+        self.last_exchange_rows = None    # M of the last training step (diagnostics: bench.py, tests)
 
     @classmethod
     def build_pre_hook(cls, config: Config, registry: RegistryMeta, item: Item) -> Config:
@@ -316,6 +323,74 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         else:
             self.quantizer.register_buffer('_probability', value)
 
+    # ---- anchors for the codes that can need one ------------------------------------------------------------------
+    def _sparse_ok(self, d, hist32) -> bool:
+        if self._sparse_anchors is False or type(self._anchor) is not NearestAnchor:
+            return False
+        if self._anchor._sync and get_world_size() > 1:          # global nearest token: gathered latents (anchors.py:50-57)
+            return False
+        p = self.probability
+        return (isinstance(d, LazyDistance) and hist32 is not None and p.is_cuda and p.dtype == torch.float32
+                and ops.coarse_supported(self.quantizer.embedding_dim))
+
+    def _listed_codes(self, p: torch.Tensor, K: int, capturing: bool):
+        """(rows, slot, count, cap): the device-side list for the step that starts from ``p`` and a host-known bound on its
+        length.  Eager: the list and its length were produced at the end of the previous step (`_prefetch_listed`); a
+        first step, or a ``p`` changed from outside, computes them now (one synchronisation).  Capture: sized for K."""
+        if capturing:
+            rows, slot, count = ops.cvq_rows(p, K, self._ema.decay, self._eps)
+            return rows, slot, count, K
+        st = self._listed
+        if st is not None and st[0] is p and st[1] == p._version:
+            st[6].synchronize()                                   # the copy was queued a whole step ago
+            return st[2], st[3], st[4], int(st[5][0])
+        rows, slot, count = ops.cvq_rows(p, K, self._ema.decay, self._eps)
+        return rows, slot, count, int(count.item())
+
+    def _prefetch_listed(self, p_new: torch.Tensor, K: int) -> None:
+        rows, slot, count = ops.cvq_rows(p_new, K, self._ema.decay, self._eps)
+        host = self._listed[5] if self._listed is not None else torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._listed = (p_new, p_new._version, rows, slot, count, host, ev)
+
+    def _sparse_step(self, x: torch.Tensor, quant: torch.Tensor, d: LazyDistance, hist32: torch.Tensor) -> None:
+        K = self.quantizer.codebook_size
+        world = get_world_size()
+        weight = self.vector_quantizer.embedding.weight
+        w_in, p_in = weight.detach().contiguous(), self.probability.contiguous()
+        capturing = torch.cuda.is_current_stream_capturing()
+        rows, slot, count, cap = self._listed_codes(p_in, K, capturing)
+        self.last_exchange_rows = cap
+        xr = x.detach()
+        col = None
+        if cap > 0:
+            xq, eq = (d._xq, d._eq) if d._xq is not None and d._eq is not None else d._distance.exact_operands(d._x, d._e, d.metric)
+            col = ops.col_argmin_rows(xq, eq, rows, count, cap, d.metric)
+        inplace = self.quantizer.inplace_updates
+        w_out = w_in if inplace else torch.empty_like(w_in)
+        p_out = p_in if inplace else torch.empty_like(p_in)
+        if world <= 1:
+            ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, hist32=hist32, numel=quant.numel(),
+                          x=xr, col_idx=col)
+        else:                                                    # histogram ‖ token count ‖ [cap, D] anchors: one all-reduce
+            packed = exchange.cvq_exchange(hist32, quant.numel(), xr, col, count, cap, K)
+            ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, packed=packed, world=world)
+        if inplace:
+            if p_out is not self.probability:                    # (a non-contiguous buffer was copied above)
+                self.probability.copy_(p_out)
+            if w_out.data_ptr() != weight.data_ptr():
+                weight.data.copy_(w_out)
+            if Store.DRY_RUN:
+                assert is_sync(w_out)
+            self.vector_quantizer.invalidate_codebook()
+        else:
+            self._update_probability(p_out)
+            self._update_embedding(w_out)
+        if not capturing:
+            self._prefetch_listed(self.probability, K)
+
     def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
         quant = super().after_encode(x, quant, memo)
         if not self.quantizer.training:
@@ -323,12 +398,14 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         K = self.quantizer.codebook_size
         d = memo['encode']['distance']
         hist32 = memo['encode'].get('hist')
+        if self._sparse_ok(d, hist32):
+            self._sparse_step(x, quant, d, hist32)
+            return quant
         if (get_world_size() <= 1 and type(self._anchor) is NearestAnchor and not self._anchor._sync
-                and not self._sparse_anchors and isinstance(d, LazyDistance) and hist32 is not None
+                and isinstance(d, LazyDistance) and hist32 is not None
                 and self.probability.is_cuda and self.probability.dtype == torch.float32):
-            # one rank: nothing is exchanged between the probability update and the blend, so the whole update is one
-            # launch on the epilogue histogram, the column argmin and the latents (vqhip_cvq_step; bit-identical to the
-            # staged form below, which stays for the multi-rank case where hist and anchors are all-reduced in between)
+            # one rank, dense form: the whole update in one launch on the epilogue histogram, the column argmin and the
+            # latents (vqhip_cvq_step; bit-identical to the staged form below)
             weight = self.vector_quantizer.embedding.weight
             col = d.argmin(0)
             w_in, p_in = weight.detach(), self.probability
@@ -345,22 +422,13 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
                     assert is_sync(w_out)
                 self.vector_quantizer.invalidate_codebook()
             return quant
+        # the reference's data flow: statistics exchange, probability update, anchor sampler with its own exchange, blend
         e = self.quantizer.embeddings
         stats = QuantStatistics(quant=quant, codebook_size=K, sync=True, hist=memo['encode'].get('hist'))
         hist, numel = stats.bin_count(), stats._statistics()[1]
         p = self.probability.to(device=e.device, dtype=torch.float32).clone()
         ops.cvq_update_(e, p, hist, numel, None, self._ema.decay, self._eps, stage=1)      # p = ema(p, hist/numel)
         self._update_probability(p)
-        if self._sparse_anchors and isinstance(self._anchor, NearestAnchor) and isinstance(d, LazyDistance):
-            decay = ops.cvq_decay(p, K, self._ema.decay, self._eps)
-            rows = torch.nonzero(decay < 1.0).reshape(-1)      # host sync; the same set on every rank (p is synchronised)
-            if rows.numel():
-                e_sub = e.index_select(0, rows)
-                d_sub = LazyDistance(d._distance, x.detach(), e_sub)
-                anchors, memo = self._anchor(x.detach(), e_sub, d_sub, quant, p.index_select(0, rows), memo=memo)
-                ops.cvq_update_rows_(e, p, rows, anchors, self._ema.decay, self._eps)
-            self._update_embedding(e)
-            return quant
         anchors, memo = self._anchor(x.detach(), e, d, quant, p, memo=memo)
         # decay = 1 - exp(-p*K*10/(1-ema.decay) - eps); e = e*decay + anchors*(1-decay)
         ops.cvq_update_(e, p, None, None, anchors, self._ema.decay, self._eps, stage=2)

@@ -111,6 +111,61 @@ def is_sync(t: torch.Tensor) -> bool:
     return bool(torch.equal(lo, hi))
 
 
+# ---- accounting of the data-path collectives (bench.py: exchange_bytes_per_step, collective_ms) ----
+
+class _ExchangeLog:
+    """Bytes, call count and (optionally) device time of the codebook-update collectives.  Off by default: one attribute
+    test per collective.  ``timing=True`` brackets every collective with events on the current stream (the collective
+    itself runs on the backend's stream; the second event waits for it)."""
+
+    def __init__(self) -> None:
+        self.enabled = False
+        self.timing = False
+        self.reset()
+
+    def reset(self) -> None:
+        self.calls = 0
+        self.bytes = 0
+        self._events = []
+
+    def start(self, timing: bool = False) -> None:
+        self.reset()
+        self.enabled, self.timing = True, timing
+
+    def stop(self) -> dict:
+        ms = None
+        if self.timing and self._events:
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in self._events)
+        out = dict(calls=self.calls, bytes=self.bytes, ms=ms)
+        self.enabled = self.timing = False
+        self._events = []
+        return out
+
+    def collective(self, fn, tensor: torch.Tensor, *args, **kwargs):
+        if not self.enabled:
+            return fn(tensor, *args, **kwargs)
+        self.calls += 1
+        self.bytes += tensor.numel() * tensor.element_size()
+        if self.timing and tensor.is_cuda and not torch.cuda.is_current_stream_capturing():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(tensor, *args, **kwargs)
+            b.record()
+            self._events.append((a, b))
+            return out
+        return fn(tensor, *args, **kwargs)
+
+
+exchange_log = _ExchangeLog()
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce of one tensor, in place, counted by ``exchange_log``."""
+    exchange_log.collective(dist.all_reduce, t)
+    return t
+
+
 # ---- one exchange step of the codebook update (SURVEY.md §8e) ----
 
 def all_reduce_statistics(hist: torch.Tensor, numel: Optional[int] = None, sums: Optional[torch.Tensor] = None):
@@ -128,9 +183,9 @@ def all_reduce_statistics(hist: torch.Tensor, numel: Optional[int] = None, sums:
     packed = torch.empty(K + 1, dtype=torch.int64, device=hist.device)
     packed[:K] = hist
     packed[K] = numel if numel is not None else hist.sum()
-    dist.all_reduce(packed)
+    all_reduce_sum(packed)
     if sums is not None:
         if not sums.is_contiguous():
             sums = sums.contiguous()
-        dist.all_reduce(sums)
+        all_reduce_sum(sums)
     return packed[:K], packed[K], sums
