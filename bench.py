@@ -4,9 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--workload vqgan|cvq|tokenize]
 
 `--gpus N` with N > 1 from a bare invocation (no WORLD_SIZE in the environment) starts the N ranks itself: the parent —
-which makes NO GPU call — runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process,
-relays rank 0's JSON line and exits with the child's code (the reference's analogue: `auto_torchrun`, docs/training.md:15).
-Under an external launcher (RANK/WORLD_SIZE set) it is one rank of the job.
+which makes NO GPU call — checks that N devices exist, runs `python -m torch.distributed.run --nproc-per-node N bench.py
+...` as a child process, relays rank 0's JSON line and exits with the child's code (the reference's analogue:
+`auto_torchrun`, docs/training.md:15).  Under an external launcher (RANK/WORLD_SIZE set) it is one rank of the job.
 
 Workloads (BASELINE.json configs; each "step" is one pass of the hot path over one HBM-resident synthetic batch):
 
@@ -15,18 +15,26 @@ Workloads (BASELINE.json configs; each "step" is one pass of the hot path over o
            2048}; --images selects another).  One step = `VQGANQuantizer.forward(x, memo)` of the drop-in nn.Module in
            eval mode: codebook preparation, fused distance+argmin, embedding gather, straight-through output, VQGAN
            loss.  Ranks are independent (tokens shard embarrassingly): weak scaling, no data-path
-           collective.  The same step through the tensor-level `ops` layer and a train-mode forward+backward are
-           timed next to it (`ops_step`, `module_train`).
+           collective.  With more than one rank the line ALSO carries `cvq` — the communicating workload below at 3072
+           and 65 536 tokens per rank — so that a scaling run shows the one exchange step of the path, not only
+           independent shards.
   cvq      (configs[3]) CVQ-VAE training step: VQGANQuantizer + CVQVAECallback(NearestAnchor), cosine, K=16384 D=256,
-           per-rank batch 12 images = 3072 tokens (configs/vqgan/interface.py:8 over 8 ranks); forward (encode, histogram
-           all-reduce, column argmin, anchor all-reduce, EMA update, decode, loss) + backward.  Weak scaling; the
-           collective is RCCL all-reduce of int64[K+1] and fp32[K,D].
+           per-rank batch 12 images = 3072 tokens (configs/vqgan/interface.py:8 over 8 ranks); forward (encode, sparse
+           anchor list, column argmin over the listed codes, ONE packed all-reduce of histogram ‖ token count ‖ anchors,
+           EMA update, decode, loss) + backward from a given upstream gradient.  Weak scaling.
   tokenize (configs[4]) LlamaGen bulk tokenization: 2048 images per step IN TOTAL, sharded over the ranks
            (`encode` only, D=8 + NormalizeCallback + L2: configs/llamagen/vqgan.py:10-20).  Strong scaling, no collective.
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides and
+reduced with MAX over the ranks; blocks repeat until --min-seconds of timed GPU work have accumulated (the GPU is then
+visible to an external sampler and box-to-box variance shows); `value` / `ms_per_step` are those of the MEDIAN block, all
+blocks are listed in `repeats`.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     — the dominant kernel (fp16-MFMA proposal pass) against the dense MFMA peak, timed live with HIP events
                  recorded on the launch stream (libvqhip's vqhip_profile_* hooks)
+  parity       — the timed batch's indices checked, outside the timed region, against the all-fp32 route on every row and
+                 against the CPU oracle on a row sample; which path every row took
   cpu_baseline — the reference's ATen composition (oracle/torch_ref.py, byte-identical to the reference's own files on
                  every fixture: tests/test_reference_pin.py) timed on this box's host cores on a bounded sample.
 """
@@ -34,6 +42,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import socket
@@ -60,7 +69,11 @@ def parse():
                     help='images per GPU per step (256 tokens each); default 2048 (vqgan), 12 (cvq); '
                          'tokenize: images per step over ALL ranks, default 2048')
     ap.add_argument('--workload', choices=('vqgan', 'cvq', 'tokenize'), default='vqgan')
+    ap.add_argument('--min-seconds', type=float, default=2.0,
+                    help='repeat the K-step block until this much timed GPU work has accumulated (0: one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-verify', action='store_true', help='skip the parity self-check after the timed region')
+    ap.add_argument('--no-cvq', action='store_true', help='world > 1, vqgan workload: skip the communicating cvq block')
     return ap.parse_args()
 
 
@@ -75,6 +88,12 @@ def _free_port() -> int:
 
 
 def launch_ranks(n: int) -> int:
+    import torch
+    have = torch.cuda.device_count()            # counts devices without initialising the GPU runtime in this process
+    if have < n and os.environ.get('VQ_BENCH_SHARE_GPU') != '1':      # (share mode: a plumbing check, every rank on cuda:0 over gloo)
+        print(f'bench.py: {n}-rank launch failed: --gpus {n} but this node has {have} GPU(s); refusing to start '
+              f'(never a silent smaller run)', file=sys.stderr)
+        return 2
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
@@ -168,52 +187,250 @@ def build_module(cfg, dev, w, train):
     return q
 
 
+class Bench:
+    """Process-wide context of one rank: device, process group, timing helpers."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank = int(os.environ.get('RANK', '0'))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        if self.world > 1 and self.world != args.gpus:
+            args.gpus = self.world
+        assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU path)'
+        # VQ_BENCH_SHARE_GPU=1 is a plumbing check for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
+        # collectives run over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+        self.share_gpu = os.environ.get('VQ_BENCH_SHARE_GPU') == '1'
+        if self.share_gpu:
+            local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            sys.exit(f'bench.py: rank {self.rank} has no device {local_rank} (node has {torch.cuda.device_count()})')
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device('cuda', local_rank)
+        self.distributed = self.world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # launched by torch.distributed.run
+        self.backend = None
+        if self.distributed:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            self.backend = 'gloo' if self.share_gpu else 'nccl'
+            if self.share_gpu:
+                dist.init_process_group('gloo')
+            else:
+                dist.init_process_group('nccl', device_id=self.dev)
+        self.coll_dev = 'cpu' if self.share_gpu else self.dev
+        # ranks that really take part in the collectives (all-reduce of ones)
+        self.rccl_ranks = 1
+        if self.distributed:
+            ones = torch.ones(1, dtype=torch.int64, device=self.coll_dev)
+            dist.all_reduce(ones)
+            self.rccl_ranks = int(ones.item())
+            assert self.rccl_ranks == self.world, f'{self.rccl_ranks} ranks answered the all-reduce, expected {self.world}'
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def all_ranks(self, ok: bool) -> bool:
+        """True iff `ok` on every rank (MIN all-reduce): decisions that change which collectives a rank issues."""
+        if not self.distributed:
+            return ok
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def timed(self, fn, steps, warmup, profile=False):
+        """W warm-up steps, then EXACTLY `steps` steps between barrier + synchronize; MAX over the ranks."""
+        from vector_quantization_amd import _lib
+        L = _lib.lib()
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        if profile:
+            L.vqhip_profile_enable(1)
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        self.barrier()
+        t1 = time.perf_counter()
+        prof = None
+        if profile:
+            ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
+            _lib.check(L.vqhip_profile_collect(ctypes.byref(ms_sum), ctypes.byref(launches)), 'vqhip_profile_collect')
+            L.vqhip_profile_enable(0)
+            prof = (ms_sum.value, launches.value)
+        el = self.torch.tensor([t1 - t0], dtype=self.torch.float64, device=self.coll_dev)
+        if self.distributed:
+            self.dist.all_reduce(el, op=self.dist.ReduceOp.MAX)
+        return float(el.item()), out, prof
+
+    def timed_blocks(self, fn, steps, warmup, min_seconds, max_blocks=200):
+        """Blocks of exactly `steps` steps until `min_seconds` of timed work; the proposal kernel is event-timed in the
+        first block.  Returns (per-block seconds, last output, (kernel ms sum, launches))."""
+        el, out, prof = self.timed(fn, steps, warmup, profile=True)
+        blocks = [el]
+        while sum(blocks) < min_seconds and len(blocks) < max_blocks:
+            el, out, _ = self.timed(fn, steps, 0)
+            blocks.append(el)
+        return blocks, out, prof
+
+
+def _median_block(blocks):
+    s = sorted(blocks)
+    return s[(len(s) - 1) // 2]             # an actual block (lower median), not an interpolation
+
+
+def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, graphs: bool = True, settle: int = 150):
+    """The CVQ-VAE training step at `tokens` per rank (module + callbacks, forward + backward from a given upstream
+    gradient), eager and replayed from HIP graphs; exchange accounting; codebook-in-sync check."""
+    torch, dist = B.torch, B.dist
+    from vector_quantization_amd.utils import exchange_log
+    K, D, dev = K_CODES, DIM, B.dev
+    w = torch.nn.functional.normalize(torch.randn(K, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3407)))
+    g = torch.Generator(device=dev).manual_seed(3407 + B.rank)
+    # codebook identical on all ranks, latents per rank.  A pool of up to 128 batches drawn around the rows of the initial
+    # codebook, another one every step: what the quantizer of a training run sees — data that changes from step to step and a
+    # codebook most of whose codes are in use.  (With ONE fixed batch the same <= `tokens` codes are hit for ever, the dead
+    # ones are moved onto tokens that already have a code and stay dead: 13 000 codes listed at every step.  A real run is not
+    # in that state; `exchange_rows_first_step` reports the worst case — every code listed — which is what step 1 costs.)
+    pool = [(w[torch.randint(0, K, (tokens,), device=dev, generator=g)] + 0.05 * torch.randn(tokens, D, device=dev, generator=g))
+            .requires_grad_(True) for _ in range(max(8, min(128, (1 << 19) // tokens)))]
+    x = pool[0]
+    gz = torch.randn(tokens, D, device=dev, generator=g) / (tokens * D)          # what the decoder's backward would hand back
+    turn = [0]
+    cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
+    q = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
+    q_params = list(q.parameters())
+    cvq_cb = q._callbacks.callbacks[0]
+
+    def make_step(module_call, params):
+        def step():
+            xin = pool[turn[0] % len(pool)]
+            turn[0] += 1
+            for p_ in params:
+                p_.grad = None
+            xin.grad = None
+            z, loss, extra_ = module_call(xin)
+            torch.autograd.backward([loss, z], [None, gz])
+            return z, loss, extra_
+        return step
+
+    step = make_step(lambda xin: q(xin, {}), q_params)
+    # settle: the probabilities start at 0 (every code listed, a [K, D] exchange); a training run spends its life in the
+    # steady state, where only codes that have gone unused for ~100 steps are listed
+    rows_first = None
+    for i in range(settle):
+        step()
+        if i == 0:
+            rows_first = cvq_cb.last_exchange_rows
+    blocks, out, prof = B.timed_blocks(step, steps, warmup, min_seconds)
+    el = _median_block(blocks)
+    rec = {'tokens_per_rank': tokens, 'ms_per_step': el / steps * 1e3, 'tokens_per_s': tokens * B.world * steps / el,
+           'blocks': len(blocks), 'ms_per_step_min': min(blocks) / steps * 1e3, 'ms_per_step_max': max(blocks) / steps * 1e3,
+           'settle_steps': settle, 'exchange_rows_first_step': rows_first, 'exchange_rows': cvq_cb.last_exchange_rows}
+    # exchange accounting on a few extra steps (events around the collective: not part of the timed blocks)
+    exchange_log.start(timing=B.distributed and not B.share_gpu)
+    n_acc = 10
+    for _ in range(n_acc):
+        step()
+    st = exchange_log.stop()
+    rec['collectives_per_step'] = st['calls'] / n_acc
+    rec['exchange_bytes_per_step'] = st['bytes'] / n_acc
+    rec['collective_ms'] = (st['ms'] / n_acc) if st['ms'] is not None else None
+    rec['dense_exchange_bytes_per_step'] = 8 * (K + 1) + 4 * K * D if B.world > 1 else 0     # int64[K+1] + fp32[K, D]: the reference's flow
+    rec['loss'] = float(out[1].item())
+    rec['kernel_ms'] = prof[0] / max(1, prof[1])
+    rec['kernel_launches_per_step'] = prof[1] / max(1, steps)
+    # HIP-graph replay of the same step (graphs.py); gloo cannot be captured.  Every rank must take the same branch: the
+    # graphs contain the collective
+    if graphs and (not B.distributed or B.backend == 'nccl'):
+        from vector_quantization_amd.graphs import GraphedQuantizer
+        qg = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
+        qg.load_state_dict(q.state_dict())
+        err = None
+        try:
+            gq = GraphedQuantizer(qg, x.detach())
+        except Exception as exc:                          # reported, never silently dropped
+            gq, err = None, f'{type(exc).__name__}: {exc}'
+        if B.all_ranks(gq is not None):
+            gstep = make_step(lambda xin: gq(xin), list(qg.parameters()))
+            gblocks, _, _ = B.timed_blocks(gstep, steps, 3, min_seconds)
+            ge = _median_block(gblocks)
+            rec['ms_per_step_graphed'] = ge / steps * 1e3
+            rec['tokens_per_s_graphed'] = tokens * B.world * steps / ge
+            rec['graphed_note'] = ('GraphedQuantizer: forward (with the in-place codebook update and the packed all-reduce) and '
+                                   'backward replayed from HIP graphs; launches sized for K listed codes, the device-side count decides')
+        else:
+            rec['graphed_error'] = err or 'graph capture failed on another rank'
+    wsum = q.embedding.weight.detach().double().sum().reshape(1).to(B.coll_dev)
+    if B.distributed:                                         # the reference's is_sync invariant (callbacks/update.py:54-55)
+        lo, hi = wsum.clone(), wsum.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rec['codebook_in_sync'] = bool(lo.item() == hi.item())
+        assert rec['codebook_in_sync'], 'codebooks diverged across ranks'
+    used = out[2].get('encode', {}).get('hist') if isinstance(out[2], dict) else None
+    rec['used_codes'] = int((used > 0).sum().item()) if used is not None else None
+    return rec, prof
+
+
+def verify_vqgan(B: Bench, q, x, w, out, N, K, D):
+    """Outside the timed region: the timed batch's tokens against the all-fp32 route (every row) and the CPU oracle (a row
+    sample); the loss against a float64 evaluation; which path the rows took."""
+    torch = B.torch
+    from oracle import c_oracle as co
+    from vector_quantization_amd import ops
+    quant = out[2]['quant'].reshape(-1)
+    exact = ops.argmin_exact(x, w, 'L2')
+    mism = int((quant != exact).sum().item())
+    rows = torch.linspace(0, N - 1, 256, device=x.device).long()
+    ref = co.l2_argmin(x[rows].float().cpu().numpy(), w.cpu().numpy())
+    omis = int((quant[rows].cpu().numpy() != ref).sum())
+    idx2, st = ops.argmin(x, ops.prepare_codebook(w, 'L2'), return_stats=True)
+    same_again = bool(torch.equal(idx2, quant))
+    st = st.cpu().tolist()
+    zf = w[exact].double()
+    loss64 = float(1.25 * ((zf - x.double()) ** 2).mean().item())
+    loss = float(out[1].item())
+    rec = {'parity_checked_rows': N, 'mismatches': mism, 'checked_against': 'vqhip_argmin_exact (all-fp32 MFMA route) on every row of the timed batch',
+           'oracle_rows': int(rows.numel()), 'oracle_mismatches': omis, 'oracle': 'oracle/vq_oracle.c l2_argmin on evenly spaced rows',
+           'paths': {'second_proposal_pass_rows': st[0], 'multi_candidate_rerank_rows': st[1], 'whole_codebook_fp32_rows': st[2],
+                     'single_candidate_rows': N - st[0] - st[1] - st[2]},
+           'deterministic_rerun': same_again, 'loss': loss, 'loss_float64': loss64,
+           'loss_rel_err': abs(loss - loss64) / max(1e-30, abs(loss64))}
+    assert mism == 0 and omis == 0 and same_again, f'bench.py parity self-check failed: {rec}'
+    assert rec['loss_rel_err'] <= 1e-5, rec
+    return rec
+
+
+def lib_sha256() -> str:
+    from vector_quantization_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         sys.exit(launch_ranks(args.gpus))          # parent: no torch.cuda / HIP call has been made
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and world != args.gpus:
-        args.gpus = world
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU path)'
-    # VQ_BENCH_SHARE_GPU=1 is a plumbing check for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
-    # collectives run over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
-    share_gpu = os.environ.get('VQ_BENCH_SHARE_GPU') == '1'
-    if share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    distributed = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # launched by torch.distributed.run
-    backend = None
-    if distributed:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        backend = 'gloo' if share_gpu else 'nccl'
-        if share_gpu:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-    coll_dev = 'cpu' if share_gpu else dev
+    B = Bench(args)
+    torch, dist = B.torch, B.dist
+    rank, world, dev = B.rank, B.world, B.dev
 
     from vector_quantization_amd import _lib, ops
-
-    # ranks that really take part in the collectives (all-reduce of ones)
-    rccl_ranks = 1
-    if distributed:
-        ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        assert rccl_ranks == world, f'{rccl_ranks} ranks answered the all-reduce, expected {world}'
 
     g = torch.Generator(device=dev).manual_seed(3407 + rank)
     extra = {}
     wl = args.workload
+    L = _lib.lib()
+    if 'VQHIP_TUNE_SLICES' in os.environ:                   # A/B knob (results unchanged): codebook slices
+        L.vqhip_set_tuning(2, int(os.environ['VQHIP_TUNE_SLICES']))
+
+    parity = None
     if wl == 'vqgan':
         images = args.images or 2048
         N, K, D = images * TOK_PER_IMAGE, K_CODES, DIM
@@ -241,6 +458,25 @@ def main():
             z, loss, _ = qt(xt, {})
             (loss + z.float().mean()).backward()
 
+        blocks, out, prof = B.timed_blocks(step, args.steps, args.warmup, args.min_seconds)
+        loss = float(out[1].item())
+        hist = ops.hist(out[2]['quant'], K)                   # code-usage statistics outside the timed region
+        used_codes = int((hist > 0).sum().item())
+        if not args.no_verify:
+            parity = verify_vqgan(B, q, x, w, out, N, K, D)
+        side_steps = max(5, args.steps // 5)
+        e_ops, _, _ = B.timed(ops_step, side_steps, 2)
+        e_tr, _, _ = B.timed(train_step, side_steps, 2)
+        extra['ops_step'] = {'ms_per_step': e_ops / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_ops,
+                             'what': 'the same forward through the tensor-level ops layer (round-1 bench step)'}
+        extra['module_train'] = {'ms_per_step': e_tr / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_tr,
+                                 'what': 'VQGANQuantizer.forward in train mode + backward (fused HIP backward, codebook gradient)'}
+        if world > 1 and not args.no_cvq:
+            # the communicating workload of the path, so that a scaling run is interpretable
+            extra['cvq'] = {}
+            for toks in (12 * TOK_PER_IMAGE, 256 * TOK_PER_IMAGE):
+                rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), settle=120)
+                extra['cvq'][str(toks)] = rec
         tokens_per_step_global = N * world
         scaling = 'weak'
         workload = ('VQGAN K=16384 D=256, 256x256 images -> 16x16 tokens, bf16 latents, VQGANQuantizer.forward of the '
@@ -250,43 +486,17 @@ def main():
     elif wl == 'cvq':
         images = args.images or 12
         N, K, D = images * TOK_PER_IMAGE, K_CODES, DIM
-        w = torch.nn.functional.normalize(torch.randn(K, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3407)))
-        x = torch.randn(N, D, device=dev, generator=g).requires_grad_(True)     # codebook identical on all ranks, latents per rank
-        cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
-        q = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
-        q_params = list(q.parameters())
-
-        def step():
-            for p_ in q_params:
-                p_.grad = None
-            x.grad = None
-            z, loss, memo = q(x, {})
-            (loss + z.mean()).backward()
-            return z, loss, memo
-
-        ops_step = train_step = None
-        graph_step = None
-        if not distributed or backend == 'nccl':            # HIP-graph replay of the same step (graphs.py); gloo cannot be captured
-            from vector_quantization_amd.graphs import GraphedQuantizer
-            qg = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
-            xg = x.detach().clone().requires_grad_(True)
-            qg_params = list(qg.parameters())
-            try:
-                gq = GraphedQuantizer(qg, xg.detach())
-
-                def graph_step():
-                    for p_ in qg_params:
-                        p_.grad = None
-                    xg.grad = None
-                    z, loss, _ = gq(xg)
-                    (loss + z.mean()).backward()
-            except Exception as exc:                          # reported, never silently dropped
-                extra['module_graphed'] = {'error': f'{type(exc).__name__}: {exc}'}
+        rec, prof = run_cvq(B, N, args.steps, args.warmup, args.min_seconds)
+        blocks = [rec['ms_per_step'] * args.steps / 1e3]
+        extra['cvq'] = rec
+        loss, used_codes = rec['loss'], rec['used_codes']
         tokens_per_step_global = N * world
         scaling = 'weak'
         workload = ('CVQ-VAE training step K=16384 D=256 cosine, VQGANQuantizer + CVQVAECallback(NearestAnchor): forward '
-                    'with histogram + anchor all-reduce and EMA codebook update, then backward')
-        parallelism = f'dp{world} (rows sharded, codebook replicated; all-reduce of int64[K+1] and fp32[K,D] per step over {backend or "no backend"})'
+                    'with the sparse-anchor exchange (ONE packed all-reduce: histogram, token count, anchors of the listed '
+                    'codes) and EMA codebook update, then backward from a given upstream gradient')
+        parallelism = (f'dp{world} (rows sharded, codebook replicated; one fp32 all-reduce of 2K+4+M*D floats per step over '
+                       f'{B.backend or "no backend"})')
         metric = 'quantized tokens/sec, CVQ-VAE quantizer training step K=16384 D=256'
     else:
         total = args.images or 2048
@@ -301,7 +511,15 @@ def main():
             with torch.no_grad():
                 return q.encode(x, {})
 
-        ops_step = train_step = None
+        blocks, out, prof = B.timed_blocks(step, args.steps, args.warmup, args.min_seconds)
+        loss = None
+        used_codes = int((ops.hist(out[1], K) > 0).sum().item())
+        if not args.no_verify:                                   # tokens of the timed batch against the all-fp32 route
+            xn, wn = ops.normalize_rows(x), ops.normalize_rows(w)
+            mism = int((out[1].reshape(-1) != ops.argmin_exact(xn, wn, 'L2')).sum().item())
+            parity = {'parity_checked_rows': N, 'mismatches': mism,
+                      'checked_against': 'vqhip_argmin_exact on the normalised operands, every row of the timed batch'}
+            assert mism == 0, parity
         tokens_per_step_global = N * world
         scaling = 'strong'
         workload = ('LlamaGen bulk tokenization: 2048 images per step in total, sharded over the ranks; '
@@ -309,114 +527,66 @@ def main():
         parallelism = f'dp{world} (images sharded, no collective)'
         metric = 'quantized tokens/sec, LlamaGen tokenizer encode K=16384 D=8'
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn, steps, warmup, profile=False):
-        L = _lib.lib()
-        for _ in range(warmup):
-            fn()
-        barrier()
-        if profile:
-            L.vqhip_profile_enable(1)
-        t0 = time.perf_counter()
-        out = None
-        for _ in range(steps):
-            out = fn()
-        barrier()
-        t1 = time.perf_counter()
-        prof = None
-        if profile:
-            ms_sum, launches = ctypes.c_double(0), ctypes.c_int64(0)
-            _lib.check(L.vqhip_profile_collect(ctypes.byref(ms_sum), ctypes.byref(launches)), 'vqhip_profile_collect')
-            L.vqhip_profile_enable(0)
-            prof = (ms_sum.value, launches.value)
-        el = torch.tensor([t1 - t0], dtype=torch.float64, device=coll_dev)
-        if distributed:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        return float(el.item()), out, prof
-
-    L = _lib.lib()
-    if 'VQHIP_TUNE_SLICES' in os.environ:                   # A/B knob (results unchanged): codebook slices
-        L.vqhip_set_tuning(2, int(os.environ['VQHIP_TUNE_SLICES']))
-
-    elapsed, out, prof = timed(step, args.steps, args.warmup, profile=True)
-    if wl == 'vqgan':
-        loss = float(out[1].item())
-        hist = ops.hist(out[2]['quant'], K)                   # code-usage statistics outside the timed region
-        used_codes = int((hist > 0).sum().item())
-        side_steps = max(5, args.steps // 5)
-        e_ops, _, _ = timed(ops_step, side_steps, 2)
-        e_tr, _, _ = timed(train_step, side_steps, 2)
-        extra['ops_step'] = {'ms_per_step': e_ops / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_ops,
-                             'what': 'the same forward through the tensor-level ops layer (round-1 bench step)'}
-        extra['module_train'] = {'ms_per_step': e_tr / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_tr,
-                                 'what': 'VQGANQuantizer.forward in train mode + backward (fused HIP backward, codebook gradient)'}
-    elif wl == 'cvq':
-        if graph_step is not None:
-            side_steps = max(10, args.steps)
-            e_g, _, _ = timed(graph_step, side_steps, 3)
-            extra['module_graphed'] = {'ms_per_step': e_g / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_g,
-                                       'what': 'the same training step replayed from HIP graphs (GraphedQuantizer: forward with '
-                                               'in-place codebook update + backward, one launch each)'}
-        loss = float(out[1].item())
-        used_codes = int((out[2]['encode']['hist'] > 0).sum().item()) if 'hist' in out[2]['encode'] else None
-        wsum = q.embedding.weight.detach().double().sum().reshape(1).to(coll_dev)
-        if distributed:                                         # the reference's is_sync invariant (callbacks/update.py:54-55)
-            lo, hi = wsum.clone(), wsum.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            extra['codebook_in_sync'] = bool(lo.item() == hi.item())
-            assert extra['codebook_in_sync'], 'codebooks diverged across ranks'
-    else:
-        loss = None
-        used_codes = int((ops.hist(out[1], K) > 0).sum().item())
-
     if rank == 0:
+        elapsed = _median_block(blocks)
         tokens = tokens_per_step_global * args.steps
         kern_ms = prof[0] / max(1, prof[1])
         launches_per_step = prof[1] / max(1, args.steps)
         flops = 2.0 * N * K * D                                          # 2*K*D per token, per launch
-        if wl == 'cvq':
-            flops = flops                                                # row pass; the column pass is the same kernel, own launch
         achieved_tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         alg_bytes = N * (D * 2 + 8 + D * 4) + K * D * 4                  # §8(d): full forward, bf16 x, + codebook once
+        sha = lib_sha256()
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if wl == 'vqgan' and os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if int(rec.get('tokens_per_launch', -1)) == N:      # counters are per launch of THIS workload
+                if int(rec.get('tokens_per_launch', -1)) != N:
+                    traffic_source = 'profiles/pmc_latest.json was collected at another batch size: not reported'
+                elif rec.get('lib_sha256') != sha:                       # counters of ANOTHER build of the library say nothing about this one
+                    traffic_source = ('profiles/pmc_latest.json was collected with another build of libvqhip.so '
+                                      f'(sha256 {str(rec.get("lib_sha256"))[:12]}... != {sha[:12]}...): not reported')
+                else:
                     traffic = rec.get('coarse_kernel_hbm_bytes_per_launch')
-                    traffic_source = ('profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
-                                      'command, gfx950-corrected; NOT measured in this run): ' + str(rec.get('source')))
+                    traffic_source = ('profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+                                      'with this very libvqhip.so, gfx950-corrected; NOT measured in this run): ' + str(rec.get('source')))
             except Exception:
                 traffic = None
+        roofline = {'bound': 'mfma', 'kernel': 'coarse_kernel (fp16 MFMA distance+argmin proposals)',
+                    'achieved': achieved_tf, 'peak': MFMA_F16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved_tf / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': traffic,
+                    'traffic_source': traffic_source,
+                    'kernel_ms': kern_ms, 'launches_timed': prof[1], 'launches_per_step': launches_per_step,
+                    'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+        if wl == 'cvq':
+            roofline['kernel_ms_note'] = ('average over the proposal launches of a step: the row pass (N x K) and, when codes are listed, '
+                                          'the role-swapped column pass (listed codes x N) — `achieved` prices the row pass only')
+        per_step = sorted(b / args.steps * 1e3 for b in blocks)
         out_line = {
             'metric': metric,
             'value': tokens / elapsed, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': scaling, 'vs_baseline': None, 'dtype': 'f16+f32',
             'dtype_note': 'f16 MFMA (f32 accumulate) proposes candidates under a rigorous bound; the decision is exact f32',
-            'data': 'synthetic', 'rccl_ranks': rccl_ranks, 'collective_backend': backend,
+            'data': 'synthetic', 'rccl_ranks': B.rccl_ranks, 'collective_backend': B.backend,
             'config': {'workload': workload, 'images_per_gpu': images, 'tokens_per_gpu_per_step': N, 'codebook': [K, D],
                        'parallelism': parallelism},
-            'roofline': {'bound': 'mfma', 'kernel': 'coarse_kernel (fp16 MFMA distance+argmin proposals)',
-                         'achieved': achieved_tf, 'peak': MFMA_F16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tf / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_source': traffic_source,
-                         'kernel_ms': kern_ms, 'launches_timed': prof[1], 'launches_per_step': launches_per_step,
-                         'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            'timing_note': f'value / ms_per_step: the median of {len(blocks)} timed blocks of exactly {args.steps} steps each '
+                           f'(barrier + synchronize on both sides, MAX over ranks); all blocks in `repeats`',
+            'repeats': {'blocks': len(blocks), 'timed_seconds': sum(blocks), 'ms_per_step_median': elapsed / args.steps * 1e3,
+                        'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
+                        'ms_per_step_all': [round(v, 5) for v in (b / args.steps * 1e3 for b in blocks)][:64]},
+            'roofline': roofline,
+            'lib_sha256': sha,
             'loss': loss, 'used_codes': used_codes,
         }
+        if parity is not None:
+            out_line['parity'] = parity
         out_line.update(extra)
         if not args.no_cpu_baseline and world == 1:          # reported once, at N=1 (rank 0's host cores)
             out_line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out_line), flush=True)
-    if distributed:
+    if B.distributed:
         dist.barrier()
         dist.destroy_process_group()
 

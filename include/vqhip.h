@@ -130,10 +130,12 @@ int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, 
 int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
                           float *z, float *z_ste, double *sse, void *stream);
 /* The same pass with the mean finished on the device: mse[0] = mse[1] = mean((z - x)^2) as fp32 (double sum, one division,
- * one cast: what `mse_loss` of losses.py:50,62 returns for both terms).  `scratch16`: 16 bytes of device memory that are
- * ZERO on entry and are left zero on return (one scratch per stream in flight); N > 0. */
+ * one cast: what `mse_loss` of losses.py:50,62 returns for both terms), mse[2] = mse[0] + beta*mse[1] (VQGANLoss.forward,
+ * losses.py:119-127: a product and a sum, each rounded, like the reference's two ops), mse[3] = 0 — mse is fp32[4].
+ * `scratch16`: 16 bytes of device memory that are ZERO on entry and are left zero on return (one scratch per stream in
+ * flight); N > 0. */
 int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
-                         float *z, float *z_ste, float *mse, void *scratch16, void *stream);
+                         float *z, float *z_ste, float *mse, float beta, void *scratch16, void *stream);
 
 /* hist[K] int32 += bincount(idx) (utils.py:42; runners/metrics.py:40-44) */
 int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream);
@@ -236,6 +238,11 @@ int vqhip_diff(const void *a, int a_dtype, const void *b, int b_dtype, int64_t n
 int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
                       const float *g_zste, const float *g_cb, const float *g_cm, float *grad_x, float *grad_w,
                       void *stream);
+/* ... with the upstream gradient g_comb (nullable DEVICE scalar) of the combined value mse[2] = m_cb + beta*m_cm of
+ * vqhip_gather_ste_mse: the effective gradients are g_cb + g_comb and g_cm + beta*g_comb (no scalar kernels in between). */
+int vqhip_vq_backward_ex(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
+                         const float *g_zste, const float *g_cb, const float *g_cm, const float *g_comb, float beta,
+                         float *grad_x, float *grad_w, void *stream);
 int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream);
 int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv,
                              void *stream);

@@ -101,9 +101,10 @@ def test_encode_matches_oracle_and_golden(ops, path):
     # the same pass with the mean finished on the device: identical value, twice (the scratch comes back zeroed)
     want = (sse / (spec['N'] * spec['D'])).float()
     for _ in range(2):
-        _, zs2, m2 = ops.gather_ste_mse(xd, wd, idx)
+        _, zs2, m2 = ops.gather_ste_mse(xd, wd, idx, beta=0.25)
         assert torch.equal(zs2, zs) and m2.dtype == torch.float32
         assert float(m2[0]) == float(want) and float(m2[1]) == float(want)
+        assert float(m2[2]) == float(want + want * 0.25)            # VQGANLoss: codebook + beta * commitment, two roundings
     if spec['loss'] == 'vqgan' and not spec['normalize'] and spec['kind'] in EXACT_KINDS and not tiny:
         assert abs(1.25 * mse - float(z['loss'])) <= 1e-5 * max(1.0, abs(float(z['loss'])))
     print(f"{spec['name']}: rescan={int(st[0])} multi={int(st[1])} exact={int(st[2])} of {spec['N']}")

@@ -158,6 +158,8 @@ def test_bench_gpus_n_self_launch_fails_loudly_without_gpus():
     assert p.returncode != 0
     assert '"metric"' not in p.stdout
     assert '2-rank launch failed' in p.stderr
+    # ... and it is refused BEFORE anything is spawned: more ranks than devices is never turned into a smaller run
+    assert 'this node has 0 GPU(s); refusing to start' in p.stderr and 'torch.distributed' not in p.stderr
 
 
 class _StubDistance(Q.BaseDistance):

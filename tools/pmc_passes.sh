@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $out/counters_list.txt 2>&1
 run() {   # name, counters...
     name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $out/$name.log 2>&1
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-verify --min-seconds 0 --no-verify --min-seconds 0 > $out/$name.log 2>&1
     echo "$name rc=$?"
 }
 run fetch FETCH_SIZE

@@ -36,7 +36,7 @@ SIGNATURES = {
     'vqhip_row_sqnorm': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     'vqhip_normalize_rows': (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),
     'vqhip_gather_ste_loss': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
-    'vqhip_gather_ste_mse': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_gather_ste_mse': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _vp]),
     'vqhip_hist': (_i32, [_vp, _i64, _i64, _vp, _vp]),
     'vqhip_scatter_add_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     'vqhip_vqkd_update': (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
@@ -44,6 +44,7 @@ SIGNATURES = {
     'vqhip_gather_rows': (_i32, [_vp, _i32, _vp, _i64, _i32, _vp, _vp]),
     'vqhip_diff': (_i32, [_vp, _i32, _vp, _i32, _i64, _f32, _vp, _vp, _vp, _vp]),
     'vqhip_vq_backward': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_vq_backward_ex': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
     'vqhip_ste': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'vqhip_normalize_rows_bwd': (_i32, [_vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp]),
     'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),

@@ -715,7 +715,7 @@ int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_
 }
 
 static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
-                           float *z_ste, double *sse, float *mse, void *stream);
+                           float *z_ste, double *sse, float *mse, void *stream, float beta = 0.0f);
 
 int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
                           float *z_ste, double *sse, void *stream) {
@@ -724,13 +724,13 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
 }
 
 int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
-                         float *z_ste, float *mse, void *scratch16, void *stream) {
+                         float *z_ste, float *mse, float beta, void *scratch16, void *stream) {
     if (!x || !e || !idx || !mse || !scratch16 || N <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_mse: bad argument");
-    return gather_ste_impl(x, x_dtype, e, idx, N, D, z, z_ste, (double *)scratch16, mse, stream);
+    return gather_ste_impl(x, x_dtype, e, idx, N, D, z, z_ste, (double *)scratch16, mse, stream, beta);
 }
 
 static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,
-                           float *z_ste, double *sse, float *mse, void *stream) {
+                           float *z_ste, double *sse, float *mse, void *stream, float beta) {
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
     // outputs beyond the Infinity Cache (256 MiB) are streamed: non-temporal accesses and twice the waves in flight
@@ -740,7 +740,7 @@ static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int
     int cap = tune_grid > 0 ? tune_grid : (streamed ? 512 : 256);      // blocks of 16 waves
     int grid = (int)((N + 15) / 16);
     grid = grid > cap ? cap : grid;
-#define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse, mse)
+#define VQ_GATHER(DT, NT) gather_ste_loss_kernel<DT, NT><<<grid, 1024, 0, s>>>(x, e, idx, N, D, z, z_ste, sse, mse, beta)
     if (x_dtype == VQHIP_DTYPE_F32) { if (streamed) VQ_GATHER(0, 1); else VQ_GATHER(0, 0); }
     else if (x_dtype == VQHIP_DTYPE_BF16) { if (streamed) VQ_GATHER(1, 1); else VQ_GATHER(1, 0); }
     else return fail(VQHIP_EINVAL, "vqhip_gather_ste_loss: x_dtype");
@@ -916,14 +916,20 @@ int vqhip_diff(const void *a, int a_dtype, const void *b, int b_dtype, int64_t n
 
 int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, const float *g_zste,
                       const float *g_cb, const float *g_cm, float *grad_x, float *grad_w, void *stream) {
+    return vqhip_vq_backward_ex(x, x_dtype, e, idx, N, D, g_zste, g_cb, g_cm, nullptr, 0.0f, grad_x, grad_w, stream);
+}
+
+int vqhip_vq_backward_ex(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, const float *g_zste,
+                         const float *g_cb, const float *g_cm, const float *g_comb, float beta, float *grad_x, float *grad_w,
+                         void *stream) {
     if (!x || !e || !idx || N < 0 || D <= 0 || (!grad_x && !grad_w)) return fail(VQHIP_EINVAL, "vqhip_vq_backward: bad argument");
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
     int grid = (int)((N + 3) / 4); grid = grid > 2048 ? 2048 : grid;
     if (x_dtype == VQHIP_DTYPE_F32)
-        vq_backward_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+        vq_backward_kernel<0><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w, g_comb, beta);
     else if (x_dtype == VQHIP_DTYPE_BF16)
-        vq_backward_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w);
+        vq_backward_kernel<1><<<grid, 256, 0, s>>>(x, e, idx, N, D, g_zste, g_cb, g_cm, grad_x, grad_w, g_comb, beta);
     else return fail(VQHIP_EINVAL, "vqhip_vq_backward: x_dtype");
     VQ_CHECK_LAUNCH("vq_backward_kernel");
     return VQHIP_OK;

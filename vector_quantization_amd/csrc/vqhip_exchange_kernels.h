@@ -66,40 +66,35 @@ __device__ __forceinline__ bool cvq_may_need_anchor(float p_old, int64_t K, floa
 }
 
 // rows[0..count) = those codes in ascending order, slot[k] = position of code k in rows or -1, count[0] = their number.
-// One 1024-thread workgroup (K is a codebook size: 16 rounds at K = 16 384); ordered compaction by ballot + scan.
+// One 1024-thread workgroup; thread t owns the consecutive codes [t*per, (t+1)*per), per = ceil(K / 1024): flags in a
+// register, a wave scan of the per-thread counts, a 16-entry scan of the wave totals — two barriers in all (3 us at
+// K = 16 384; a round-per-1024-codes form with three barriers per round took 14).
 __global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict__ p, int64_t K, float ema_decay, float eps,
                                                         int32_t *__restrict__ rows, int32_t *__restrict__ slot,
                                                         int32_t *__restrict__ count) {
     __shared__ int wtot[16];
-    __shared__ int woff[16];
-    __shared__ int round_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int base = 0;
-    for (int64_t k0 = 0; k0 < K; k0 += 1024) {
-        const int64_t k = k0 + threadIdx.x;
-        const bool flag = k < K && cvq_may_need_anchor(p[k], K, ema_decay, eps);
-        const unsigned long long mask = __ballot(flag);
-        if (lane == 0) wtot[wave] = __popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int i = 0; i < 16; ++i) { woff[i] = t; t += wtot[i]; }
-            round_total = t;
-        }
-        __syncthreads();
-        if (k < K) {
-            if (flag) {
-                const int pos = base + woff[wave] + __popcll(mask & ((1ull << lane) - 1ull));
-                rows[pos] = (int32_t)k;
-                slot[k] = pos;
-            } else {
-                slot[k] = -1;
-            }
-        }
-        base += round_total;
-        __syncthreads();
+    const int64_t per = (K + 1023) / 1024;
+    const int64_t k0 = (int64_t)threadIdx.x * per;
+    int mine = 0;
+    for (int64_t k = k0; k < k0 + per && k < K; ++k) mine += cvq_may_need_anchor(p[k], K, ema_decay, eps) ? 1 : 0;
+    int incl = mine;                                      // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    if (threadIdx.x == 0) count[0] = base;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { if (i < wave) base += wtot[i]; total += wtot[i]; }
+    int pos = base + incl - mine;
+    for (int64_t k = k0; k < k0 + per && k < K; ++k) {
+        if (cvq_may_need_anchor(p[k], K, ema_decay, eps)) { rows[pos] = (int32_t)k; slot[k] = pos; ++pos; }
+        else slot[k] = -1;
+    }
+    if (threadIdx.x == 0) count[0] = total;
 }
 
 // out[i] = e[rows[i]] for i < count, zeros up to cap (the role-swapped pipeline reads whole 32-row blocks)

@@ -1997,10 +1997,10 @@ __device__ __forceinline__ void nt_store4(float *q, float a, float b, float c, f
 template <int DT, int NT>
 // mse != nullptr: `sse` is a 16-byte scratch {double sum; int ticket; int pad} that is zero on entry; the workgroup that
 // draws the last ticket writes mean((z - x)^2) as fp32 to mse[0] and mse[1] (the codebook and the commitment term share
-// the value) and leaves the scratch zeroed for the next call — no zero-fill, division or cast kernels around the launch.
+// the value), mse[2] = mse[0] + beta * mse[1] (VQGANLoss), mse[3] = 0, and leaves the scratch zeroed for the next call — no zero-fill, division or cast kernels around the launch.
 __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, const float *e, const int64_t *idx, int64_t N,
                                                               int D, float *z, float *zste, double *sse,
-                                                              float *mse = nullptr) {
+                                                              float *mse = nullptr, float beta = 0.0f) {
     __shared__ double red[16];                                // 16 waves per block: one atomic per 16 waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0;
@@ -2066,6 +2066,8 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
                     const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const float mean = (float)(total / ((double)N * (double)D));
                     mse[0] = mean; mse[1] = mean;
+                    const float weighted = beta * mean;            // VQGANLoss: codebook + beta * commitment (losses.py:126),
+                    mse[2] = mean + weighted; mse[3] = 0.0f;       // two roundings like the reference's two ops
                     __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -2280,10 +2282,13 @@ __global__ void normalize_bwd_kernel(const void *v, const float *g, int64_t R, i
 template <int DT>
 __global__ __launch_bounds__(256) void vq_backward_kernel(const void *x, const float *e, const int64_t *idx, int64_t N, int D,
                                                           const float *g_zste, const float *g_cb, const float *g_cm,
-                                                          float *grad_x, float *grad_w) {
+                                                          float *grad_x, float *grad_w, const float *g_comb = nullptr,
+                                                          float beta = 0.0f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float s = 2.0f / ((float)N * (float)D);
-    const float kx = (g_cm ? *g_cm : 0.0f) * s, kw = (g_cb ? *g_cb : 0.0f) * s;
+    // g_comb: upstream gradient of the combined value m_cb + beta * m_cm (VQGANLoss finished inside the forward kernel)
+    const float gc = g_comb ? *g_comb : 0.0f;
+    const float kx = ((g_cm ? *g_cm : 0.0f) + beta * gc) * s, kw = ((g_cb ? *g_cb : 0.0f) + gc) * s;
     const bool do_w = grad_w && kw != 0.0f;
     // float atomics want the 64 lanes on 256 contiguous bytes (measured: 4 consecutive floats per lane is 3.5x slower),
     // so the vector path is for the atomic-free case (grad_x only: the ordered route computes grad_w elsewhere)

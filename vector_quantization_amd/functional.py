@@ -101,29 +101,34 @@ def ste(z: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 class _FusedDecodeLoss(Function):
     """decode + straight-through + both MSE terms in one pass:
         z = W[idx];  z_ste = x + sg(z - x);  m_cb = mse(z, sg x);  m_cm = mse(sg z, x)   (same value, two graph nodes)
-    Backward is one fused kernel (vqhip_vq_backward): m_cb's gradient flows to W, m_cm's and z_ste's to x."""
+        combined = m_cb + beta * m_cm   (VQGANLoss, losses.py:119-127 — finished inside the kernel)
+    Backward is one fused kernel (vqhip_vq_backward_ex): m_cb's gradient flows to W, m_cm's and z_ste's to x, the combined
+    value's to both; gradients of unused outputs are not materialised."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor):
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, beta: float = 0.0):
+        ctx.set_materialize_grads(False)
+        ctx.beta = float(beta)
         if x.numel() == 0:
             _, z_ste, sse = ops.gather_ste_loss(x, weight, idx, need_z=False, need_ste=True, need_sse=True)
             ctx.save_for_backward(x, weight, idx)
             m = (sse / x.numel()).float().reshape(())                  # nan, as mse_loss of an empty tensor
-            return z_ste.view(x.shape), m, m.clone()
-        _, z_ste, mse = ops.gather_ste_mse(x, weight, idx)            # the mean is finished inside the kernel
+            return z_ste.view(x.shape), m, m.clone(), m + beta * m
+        _, z_ste, mse = ops.gather_ste_mse(x, weight, idx, beta=beta)   # means and their combination finished inside the kernel
         ctx.save_for_backward(x, weight, idx)
-        return z_ste.view(x.shape), mse[0], mse[1]
+        return z_ste.view(x.shape), mse[0], mse[1], mse[2]
 
     @staticmethod
-    def backward(ctx, g_zste, g_cb, g_cm):
+    def backward(ctx, g_zste, g_cb, g_cm, g_comb):
         x, weight, idx = ctx.saved_tensors
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gx, gw = ops.vq_backward(x, weight, idx, g_zste, g_cb, g_cm, need_x, need_w)
+        gx, gw = ops.vq_backward(x, weight, idx, g_zste, g_cb, g_cm, need_x, need_w, g_comb=g_comb, beta=ctx.beta)
         if gx is not None:
             gx = gx.view(x.shape).to(x.dtype)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
-def fused_decode_loss(x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor):
-    """Returns (z_ste, m_cb, m_cm): the straight-through output and the codebook / commitment MSE values."""
-    return _FusedDecodeLoss.apply(x, weight, idx)
+def fused_decode_loss(x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, beta: float = 0.0):
+    """Returns (z_ste, m_cb, m_cm, m_cb + beta*m_cm): the straight-through output, the codebook / commitment MSE values and
+    their VQGAN combination."""
+    return _FusedDecodeLoss.apply(x, weight, idx, beta)

@@ -305,9 +305,11 @@ def _mse_scratch(device: torch.device) -> torch.Tensor:
 
 
 @_on_tensor_device
-def gather_ste_mse(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: bool = False, need_ste: bool = True):
-    """(z or None, z_ste or None, mse fp32[2]) with mse[0] = mse[1] = mean((e[idx] - x)^2): `gather_ste_loss` with the mean
-    finished inside the kernel (no zero-fill, division and cast kernels around it)."""
+def gather_ste_mse(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: bool = False, need_ste: bool = True,
+                   beta: float = 0.0):
+    """(z or None, z_ste or None, mse fp32[4]) with mse[0] = mse[1] = mean((e[idx] - x)^2) and mse[2] = mse[0] + beta*mse[1]
+    (VQGANLoss): `gather_ste_loss` with the mean finished inside the kernel (no zero-fill, division, cast, scale and add
+    kernels around it)."""
     _require_cuda(x, e, idx)
     x, dt = _latents(x)
     e = _codebook(e)
@@ -316,8 +318,8 @@ def gather_ste_mse(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, need_z: 
     N, D = x.shape
     z = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_z else None
     zs = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_ste else None
-    mse = torch.empty(2, dtype=torch.float32, device=x.device)
-    check(_lib.lib().vqhip_gather_ste_mse(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(z), _ptr(zs), _ptr(mse),
+    mse = torch.empty(4, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vqhip_gather_ste_mse(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(z), _ptr(zs), _ptr(mse), float(beta),
                                           _ptr(_mse_scratch(x.device)), _stream()), 'vqhip_gather_ste_mse')
     return z, zs, mse
 
@@ -664,7 +666,7 @@ def normalize_rows_bwd(v: torch.Tensor, g: torch.Tensor, eps: float = 1e-12) -> 
 @_on_tensor_device
 def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Optional[torch.Tensor],
                 g_cb: Optional[torch.Tensor], g_cm: Optional[torch.Tensor], need_x: bool, need_w: bool,
-                ordered: Optional[bool] = None):
+                ordered: Optional[bool] = None, g_comb: Optional[torch.Tensor] = None, beta: float = 0.0):
     """Fused backward of the quantizer forward; returns (grad_x fp32 or None, grad_w fp32 [K, D] or None).  The
     codebook gradient is summed code by code in token order (``use_ordered``) or with fp32 atomics."""
     _require_cuda(x, e, idx)
@@ -679,15 +681,18 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
     gx = torch.empty(N, D, dtype=torch.float32, device=x.device) if need_x else None
     if g_zste is not None:
         g_zste = g_zste.float().contiguous()
-    scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cb, g_cm)]
+    scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cb, g_cm, g_comb)]
     ordered_w = need_w and use_ordered(K, D, ordered, N, backward=True)
+    if ordered_w and scal[2] is not None:        # the ordered kernel takes one scalar: fold the combined gradient in here
+        scal[0] = scal[2] if scal[0] is None else scal[0] + scal[2]
     gw = None
     if need_w:
         gw = torch.empty(e.shape, dtype=torch.float32, device=x.device) if ordered_w else \
             torch.zeros(e.shape, dtype=torch.float32, device=x.device)
     if need_x or (need_w and not ordered_w):
-        check(L.vqhip_vq_backward(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
-                                  _ptr(gx), None if ordered_w else _ptr(gw), _stream()), 'vqhip_vq_backward')
+        check(L.vqhip_vq_backward_ex(_ptr(x), dt, _ptr(e), _ptr(idx), N, D, _ptr(g_zste), _ptr(scal[0]), _ptr(scal[1]),
+                                     _ptr(scal[2]), float(beta), _ptr(gx), None if ordered_w else _ptr(gw), _stream()),
+              'vqhip_vq_backward_ex')
     if ordered_w:
         _, offsets, order = token_order(idx, K)
         ws = _bytes(L.vqhip_segsum_workspace_bytes(N, D), x.device)

@@ -162,12 +162,15 @@ class VectorQuantizer(BaseQuantizer):
             return z, loss, memo
         x, quant, memo = self.encode(x, memo)
         memo.update(x=x, quant=quant)
-        z_ste, m_cb, m_cm = VF.fused_decode_loss(x, self._embedding.weight, quant)
+        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
+        z_ste, m_cb, m_cm, m_vqgan = VF.fused_decode_loss(x, self._embedding.weight, quant, betas[0] if betas else 0.0)
         memo['decode'] = get_memo(memo, 'decode')
         losses = {}
         for name, loss in self._losses.items():
             if isinstance(loss, VQGANLoss):
-                losses[name] = torch.add(m_cb, m_cm, alpha=loss.beta)        # codebook + beta * commitment, one kernel
+                # codebook + beta * commitment: finished inside the gather kernel for the (one) VQGANLoss of the shipped
+                # configs; a second VQGANLoss with another beta takes the two-term form
+                losses[name] = m_vqgan if loss.beta == betas[0] else torch.add(m_cb, m_cm, alpha=loss.beta)
             elif isinstance(loss, CodebookLoss):
                 losses[name] = m_cb
             else:
