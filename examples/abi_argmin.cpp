@@ -32,11 +32,14 @@ int main() {
     HIP_OK(hipMemset(sse, 0, 8));
     hipStream_t st; HIP_OK(hipStreamCreate(&st));
 
-    VQ_OK(vqhip_codebook_prepare(e, K, D, VQHIP_METRIC_L2, cb, st));
-    VQ_OK(vqhip_argmin(x, VQHIP_DTYPE_F32, e, cb, N, K, D, VQHIP_METRIC_L2, idx, nullptr, ws, st));
+    const int64_t cb_bytes = vqhip_codebook_bytes(K, D), ws_bytes = vqhip_workspace_bytes(N, K, D);
+    VQ_OK(vqhip_codebook_prepare(e, K, D, VQHIP_METRIC_L2, cb, cb_bytes, st));
+    VQ_OK(vqhip_argmin(x, VQHIP_DTYPE_F32, e, cb, cb_bytes, N, K, D, VQHIP_METRIC_L2, idx, nullptr, ws, ws_bytes, st));
+    // an undersized workspace is refused before anything is launched
+    if (vqhip_argmin(x, VQHIP_DTYPE_F32, e, cb, cb_bytes, N, K, D, VQHIP_METRIC_L2, idx, nullptr, ws, ws_bytes - 1, st) != VQHIP_EINVAL) { std::puts("undersized ws accepted"); return 4; }
     VQ_OK(vqhip_argmin_stats(ws, stats, st));
     VQ_OK(vqhip_gather_ste_loss(x, VQHIP_DTYPE_F32, e, idx, N, D, z, zste, sse, st));
-    VQ_OK(vqhip_argmin_exact(x, VQHIP_DTYPE_F32, e, N, K, D, VQHIP_METRIC_L2, idx2, nullptr, nullptr, ws, st));
+    VQ_OK(vqhip_argmin_exact(x, VQHIP_DTYPE_F32, e, N, K, D, VQHIP_METRIC_L2, idx2, nullptr, nullptr, ws, ws_bytes, st));
     HIP_OK(hipStreamSynchronize(st));
 
     std::vector<int64_t> a(N), b(N); double hsse = 0; int hstats[4];

@@ -11,6 +11,19 @@
  * is a hipStream_t passed as void*; functions never allocate, never synchronise, never touch another
  * stream; they return 0 or a negative VQHIP_E* code.  x_dtype selects the latent storage type
  * (fp32, or bf16 as produced under autocast); codebooks are fp32 like nn.Embedding.weight.
+ * Every caller-owned scratch buffer travels with its size (`ws_bytes`, `cb_bytes`): a buffer smaller than the matching
+ * *_bytes function asks for is refused with VQHIP_EINVAL before anything is launched (vqhip_last_error names both numbers).
+ *
+ * LIMITS (checked; VQHIP_EINVAL beyond them)
+ *   N, K                 < 2^31 (row lists and candidate codes are 32-bit)
+ *   D                    >= 1; the fp16-MFMA proposal pass exists for D <= 1024 with D % 8 == 0 (every shipped config: 8, 32,
+ *                        256, 768) — other D take the all-fp32 route transparently (vqhip_argmin, vqhip_col_argmin) or are
+ *                        refused where only the proposal form exists (vqhip_col_argmin_rows, VQHIP_METRIC_COS_BF16 encode)
+ *   ordered sums         K <= 32768, D % 4 == 0, ceil(N/1024) * K < 2^31 (vqhip_token_order and the two sums built on it)
+ *   packed exchange      <= 256 ranks (count pieces stay exact in fp32), per-rank counts < 2^31, token count < 2^48
+ *   vqhip_transpose      B <= 65535 per launch
+ *   alignment            every buffer pointer 16-byte aligned (hipMalloc / torch allocations are); rows dense, no padding
+ *   device               all pointers belong to the device `stream` was created on, which is the current HIP device
  */
 #ifndef VQHIP_H_
 #define VQHIP_H_
@@ -54,13 +67,13 @@ int64_t vqhip_codebook_bytes(int64_t K, int D);
  *   xq [N,D] fp32: cosine only — receives F.normalize(x, dim=1) (bit-identical to vqhip_normalize_rows), which is also the
  *   operand of the exact re-rank: keep it alive until the call has completed on the stream; NULL for L2;
  *   ws: vqhip_workspace_bytes(N,K,D).  Results are those of the separate calls, bit for bit. */
-int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
-                 int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream);
+int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
+                 int64_t *idx, int32_t *hist, float *xq, void *ws, int64_t ws_bytes, void *stream);
 /* The same with flags: VQHIP_ENCODE_ZERO_HIST — `hist` is zeroed by the call's first launch (no separate fill), so the
  * histogram on return is exactly this call's code counts. */
 #define VQHIP_ENCODE_ZERO_HIST 1
-int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
-                    int64_t *idx, int32_t *hist, float *xq, void *ws, int flags, void *stream);
+int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
+                    int64_t *idx, int32_t *hist, float *xq, void *ws, int64_t ws_bytes, int flags, void *stream);
 
 /* Byte offset, inside an image prepared with VQHIP_METRIC_COS, of the fp32 [K, D] rows F.normalize(e, dim=1) the exact
  * definition consumes (bit-identical to vqhip_normalize_rows(e)); 256-byte aligned.  Lets a caller that needs the
@@ -69,11 +82,7 @@ int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64
 int64_t vqhip_codebook_exact_offset(int64_t K, int D);
 /* bytes of per-call scratch for vqhip_argmin / vqhip_argmin_exact / vqhip_distance over N rows.
  * (vqhip_col_argmin needs the LARGER vqhip_col_workspace_bytes, declared next to it below.)
- * Preconditions shared by every entry point (the kernels use 16-byte vector loads and do not re-check):
- *   - every buffer pointer (x, e, cb, ws, outputs) is 16-byte aligned (hipMalloc / torch allocations are);
- *   - rows are dense: x is [N, D] and e is [K, D] row-major with no padding between rows;
- *   - ws holds at least the number of bytes the matching *_bytes function returns;
- *   - all pointers are device pointers of the device that `stream` belongs to, which is the current HIP device. */
+ * (Alignment, density and device preconditions: the LIMITS block at the top of this header.) */
 int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D);
 
 /* ---- codebook preparation --------------------------------------------------------------------------
@@ -81,7 +90,7 @@ int64_t vqhip_workspace_bytes(int64_t N, int64_t K, int D);
  * for COS the normalised codebook F.normalize(e) (distances.py:41), a power-of-two-scaled fp16 copy in
  * MFMA-fragment order, and the error bounds the exact re-rank needs.  Must be re-run whenever e changes
  * (callbacks rebind weight.data every forward: vq/algorithms/vq/callbacks/update.py:56). */
-int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream);
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, int64_t cb_bytes, void *stream);
 
 /* ---- fused distance + argmin  (replaces quantizers.py:97-99: distance(x, W) → torch.argmin(d, -1)) ---
  * idx[n] = argmin_k d(x_n, e_k), lowest k on ties, bit-identical to the fp32 definition
@@ -95,18 +104,18 @@ int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *c
  * Optional outputs (nullable):
  *   hist[K] int32 += code-hit histogram (quant.bincount, vq/algorithms/vq/utils.py:42);
  * `ws` = vqhip_workspace_bytes(N,K,D) of scratch. */
-int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D,
-                 int metric, int64_t *idx, int32_t *hist, void *ws, void *stream);
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t cb_bytes, int64_t N, int64_t K, int D,
+                 int metric, int64_t *idx, int32_t *hist, void *ws, int64_t ws_bytes, void *stream);
 
 /* Same result computed entirely in fp32 (v_mfma_f32_32x32x2_f32) without the fp16 proposal pass.
  * dmin (nullable) receives the winning distance.  For COS `e` must be the normalised codebook. */
 int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
-                       int64_t *idx, float *dmin, int32_t *hist, void *ws, void *stream);
+                       int64_t *idx, float *dmin, int32_t *hist, void *ws, int64_t ws_bytes, void *stream);
 
 /* Materialise d[N,K] fp32 (memo['distance'], quantizers.py:98) for consumers that need the matrix
  * (EntropyLoss losses.py:143, MultinomialAnchor anchors.py:100).  COS: x and e already normalised. */
 int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
-                   float *d, void *ws, void *stream);
+                   float *d, void *ws, int64_t ws_bytes, void *stream);
 
 /* NearestAnchor: col_idx[k] = argmin_n d[n,k], lowest n on ties (vq/algorithms/cvqvae/anchors.py:83), same arithmetic
  * contract as vqhip_argmin (bit-identical to the fp32 definition, operand order of the reference kept); never
@@ -114,7 +123,7 @@ int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_
  * COS: x and e already normalised.  `ws` = vqhip_col_workspace_bytes(N, K, D). */
 int64_t vqhip_col_workspace_bytes(int64_t N, int64_t K, int D);
 int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
-                     int64_t *col_idx, void *ws, void *stream);
+                     int64_t *col_idx, void *ws, int64_t ws_bytes, void *stream);
 
 /* ---- row kernels ------------------------------------------------------------------------------------ */
 /* out[r] = |v_r|^2 in the oracle's order (64 interleaved fma partials + halving tree) */
@@ -212,7 +221,7 @@ int vqhip_cvq_rows(const float *p, int64_t K, float ema_decay, float eps, int32_
                    void *stream);
 int64_t vqhip_col_rows_workspace_bytes(int64_t N, int64_t cap, int D);
 int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
-                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, void *stream);
+                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, int64_t ws_bytes, void *stream);
 int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtype, const int64_t *col_idx, const int32_t *count,
                    int64_t cap, int64_t K, int D, float *packed, void *stream);
 int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
@@ -261,12 +270,12 @@ int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R
 int64_t vqhip_order_workspace_bytes(int64_t N, int64_t K);
 int64_t vqhip_segsum_workspace_bytes(int64_t N, int D);
 int vqhip_token_order(const int64_t *idx, int64_t N, int64_t K, int32_t *counts, int32_t *offsets, int32_t *order, void *ws,
-                      void *stream);
+                      int64_t ws_bytes, void *stream);
 int vqhip_segsum_rows(const float *src, const int64_t *idx, const int32_t *order, const int32_t *offsets, int64_t N, int64_t K,
-                      int D, float *dst, void *ws, void *stream);
+                      int D, float *dst, void *ws, int64_t ws_bytes, void *stream);
 int vqhip_vq_backward_w_ordered(const void *x, int x_dtype, const float *e, const int64_t *idx, const int32_t *order,
                                 const int32_t *offsets, int64_t N, int64_t K, int D, const float *g_cb, float *grad_w, void *ws,
-                                void *stream);
+                                int64_t ws_bytes, void *stream);
 
 /* ---- callers either side of the path ------------------------------------------------------
  * vqhip_transpose: in[B][R][C] -> out[B][C][R] for 2- or 4-byte elements.  With R = channels, C = h*w it is
@@ -288,7 +297,7 @@ int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream);
  * score units, negative = no usable bound), scale[1] = the power-of-two codebook scale.  A test checks the error
  * bound |score - exact score| <= margin/2 against float64. */
 int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int64_t N, int64_t K, int D, int metric,
-                                float *scores, float *margin, float *scale, void *ws, void *stream);
+                                float *scores, float *margin, float *scale, void *ws, int64_t ws_bytes, void *stream);
 
 /* Per-launch timing of the proposal (distance+argmin) kernel with HIP events recorded on the caller's stream
  * around that launch (bench.py's roofline leg).  enable(1) starts collecting, collect() synchronises on the

@@ -45,11 +45,44 @@ def test_version_and_sizes(lib):
 
 def test_bad_arguments_are_rejected_without_a_gpu(lib):
     # argument validation happens before any HIP call
-    rc = lib.vqhip_argmin(None, 0, None, None, 10, 10, 8, 0, None, None, None, None)
+    rc = lib.vqhip_argmin(None, 0, None, None, 0, 10, 10, 8, 0, None, None, None, 0, None)
     assert rc == -22
     assert b'vqhip_argmin' in lib.vqhip_last_error()
-    rc = lib.vqhip_codebook_prepare(None, 10, 8, 0, None, None)
+    rc = lib.vqhip_codebook_prepare(None, 10, 8, 0, None, 0, None)
     assert rc == -22
+
+
+def test_undersized_buffers_are_refused_before_any_launch(lib):
+    """Every scratch buffer travels with its size: one byte less than the matching *_bytes function asks for is VQHIP_EINVAL,
+    with both numbers in the message — never a kernel writing past the end of a caller's allocation.  (Pointers here are
+    fake but non-null: the size check sits in front of the first HIP call.)"""
+    import ctypes
+    fake = ctypes.c_void_p(0x1000)
+    N, K, D = 1000, 512, 64
+    cb, ws = lib.vqhip_codebook_bytes(K, D), lib.vqhip_workspace_bytes(N, K, D)
+    assert lib.vqhip_codebook_prepare(fake, K, D, 0, fake, cb - 1, None) == -22
+    assert b'cb too small' in lib.vqhip_last_error() and str(cb).encode() in lib.vqhip_last_error()
+    assert lib.vqhip_argmin(fake, 0, fake, fake, cb, N, K, D, 0, fake, None, fake, ws - 1, None) == -22
+    assert b'ws too small' in lib.vqhip_last_error() and str(ws).encode() in lib.vqhip_last_error()
+    assert lib.vqhip_argmin(fake, 0, fake, fake, cb - 1, N, K, D, 0, fake, None, fake, ws, None) == -22
+    assert lib.vqhip_encode_ex(fake, 0, fake, N, K, D, 0, fake, cb, fake, None, None, fake, ws - 1, 0, None) == -22
+    assert lib.vqhip_encode_ex(fake, 0, fake, N, K, D, 0, fake, cb - 1, fake, None, None, fake, ws, 0, None) == -22
+    assert lib.vqhip_argmin_exact(fake, 0, fake, N, K, D, 0, fake, None, None, fake, ws - 1, None) == -22
+    assert lib.vqhip_distance(fake, 0, fake, N, K, D, 0, fake, fake, ws - 1, None) == -22
+    cws = lib.vqhip_col_workspace_bytes(N, K, D)
+    assert cws > ws
+    assert lib.vqhip_col_argmin(fake, 0, fake, N, K, D, 0, fake, fake, ws, None) == -22       # the row-pass size is NOT enough
+    rws = lib.vqhip_col_rows_workspace_bytes(N, 100, D)
+    assert 0 < rws < cws
+    assert lib.vqhip_col_argmin_rows(fake, 0, fake, fake, fake, 100, N, K, D, 0, fake, fake, rws - 1, None) == -22
+    ows = lib.vqhip_order_workspace_bytes(N, K)
+    assert lib.vqhip_token_order(fake, N, K, fake, fake, fake, fake, ows - 1, None) == -22
+    sws = lib.vqhip_segsum_workspace_bytes(N, D)
+    assert lib.vqhip_segsum_rows(fake, fake, fake, fake, N, K, D, fake, fake, sws - 1, None) == -22
+    assert lib.vqhip_vq_backward_w_ordered(fake, 0, fake, fake, fake, fake, N, K, D, None, fake, fake, sws - 1, None) == -22
+    # limits
+    assert lib.vqhip_token_order(fake, N, 40000, fake, fake, fake, fake, 1 << 40, None) == -22 and b'32768' in lib.vqhip_last_error()
+    assert lib.vqhip_argmin(fake, 0, fake, fake, 1 << 40, 1 << 31, K, D, 0, fake, None, fake, 1 << 40, None) == -22
 
 
 def test_ops_refuse_cpu_tensors():

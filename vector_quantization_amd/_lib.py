@@ -24,15 +24,15 @@ SIGNATURES = {
     'vqhip_last_error': (ctypes.c_char_p, []),
     'vqhip_codebook_bytes': (_i64, [_i64, _i32]),
     'vqhip_codebook_exact_offset': (_i64, [_i64, _i32]),
-    'vqhip_encode': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'vqhip_encode_ex': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    'vqhip_encode': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'vqhip_encode_ex': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     'vqhip_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_col_workspace_bytes': (_i64, [_i64, _i64, _i32]),
-    'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
-    'vqhip_argmin': (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
-    'vqhip_argmin_exact': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    'vqhip_distance': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
-    'vqhip_col_argmin': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    'vqhip_argmin': (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'vqhip_argmin_exact': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'vqhip_distance': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    'vqhip_col_argmin': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     'vqhip_row_sqnorm': (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     'vqhip_normalize_rows': (_i32, [_vp, _i32, _i64, _i32, _f32, _vp, _vp]),
     'vqhip_gather_ste_loss': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -58,15 +58,15 @@ SIGNATURES = {
     'vqhip_unpack_counts': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_cvq_rows': (_i32, [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     'vqhip_col_rows_workspace_bytes': (_i64, [_i64, _i64, _i32]),
-    'vqhip_col_argmin_rows': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    'vqhip_col_argmin_rows': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     'vqhip_cvq_pack': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     'vqhip_cvq_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),
-    'vqhip_token_order': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_token_order': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'vqhip_segsum_workspace_bytes': (_i64, [_i64, _i32]),
-    'vqhip_segsum_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
-    'vqhip_vq_backward_w_ordered': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
-    'vqhip_debug_proposal_scores': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'vqhip_segsum_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+    'vqhip_vq_backward_w_ordered': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
+    'vqhip_debug_proposal_scores': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     'vqhip_profile_enable': (_i32, [_i32]),
     'vqhip_set_tuning': (_i32, [_i32, _i32]),
     'vqhip_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

@@ -77,6 +77,18 @@ static int ensure_dyn_lds(const void *kern, size_t bytes, LdsCache &set) {
     return VQHIP_OK;
 }
 
+// caller-owned buffers carry their size: an undersized workspace or image is refused here instead of becoming silent
+// device-memory corruption inside a kernel
+#define VQ_NEED(what, have, need)                                                                         \
+    do {                                                                                                  \
+        const int64_t need__ = (need);                                                                    \
+        if ((have) < need__) {                                                                            \
+            char msg__[160];                                                                              \
+            snprintf(msg__, sizeof(msg__), "%lld bytes given, %lld needed", (long long)(have), (long long)need__); \
+            return fail(VQHIP_EINVAL, what, msg__);                                                       \
+        }                                                                                                 \
+    } while (0)
+
 static inline int waves_grid(int64_t rows, int waves_per_block) {
     return (int)((rows + waves_per_block - 1) / waves_per_block);
 }
@@ -385,14 +397,15 @@ static int codebook_prepare_impl(const float *e, int64_t K, int D, int metric, v
     return VQHIP_OK;
 }
 
-int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, void *stream) {
+int vqhip_codebook_prepare(const float *e, int64_t K, int D, int metric, void *cb, int64_t cb_bytes, void *stream) {
     if (!e || !cb || K <= 0 || D <= 0 || (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16))
         return fail(VQHIP_EINVAL, "vqhip_codebook_prepare: bad argument");
+    VQ_NEED("vqhip_codebook_prepare: cb too small", cb_bytes, vqhip_codebook_bytes(K, D));
     return codebook_prepare_impl(e, K, D, metric, cb, stream);
 }
 
 int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
-                       float *dmin, int32_t *hist, void *ws, void *stream);
+                       float *dmin, int32_t *hist, void *ws, int64_t ws_bytes, void *stream);
 
 // The proposal + decision pipeline: N rows `x` against the K codes whose prepared image is `cb` and whose fp32 rows
 // (as used by the exact definition) are `e_exact`.  `metric` may carry the internal words (DOT, SWAP).
@@ -497,32 +510,34 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     return VQHIP_OK;
 }
 
-int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
-                 int64_t *idx, int32_t *hist, float *xq, void *ws, void *stream) {
-    return vqhip_encode_ex(x, x_dtype, e, N, K, D, metric, cb, idx, hist, xq, ws, 0, stream);
+int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
+                 int64_t *idx, int32_t *hist, float *xq, void *ws, int64_t ws_bytes, void *stream) {
+    return vqhip_encode_ex(x, x_dtype, e, N, K, D, metric, cb, cb_bytes, idx, hist, xq, ws, ws_bytes, 0, stream);
 }
 
-int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb,
-                    int64_t *idx, int32_t *hist, float *xq, void *ws, int flags, void *stream) {
+int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
+                    int64_t *idx, int32_t *hist, float *xq, void *ws, int64_t ws_bytes, int flags, void *stream) {
     const bool zero_hist = hist != nullptr && (flags & VQHIP_ENCODE_ZERO_HIST) != 0;
     if (N == 0 || !vq_coarse_supported(D)) {                 // paths without the fused front: plain memset
         if (zero_hist && K > 0) VQ_HIP(hipMemsetAsync(hist, 0, (size_t)K * 4, (hipStream_t)stream));
     }
-    if (N == 0) return e && cb && K > 0 && D > 0 ? vqhip_codebook_prepare(e, K, D, metric, cb, stream) : fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
+    if (N == 0) return e && cb && K > 0 && D > 0 ? vqhip_codebook_prepare(e, K, D, metric, cb, cb_bytes, stream) : fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
     if (!x || !e || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_encode: bad argument");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: metric");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_encode: x_dtype");
     if (VQ_IS_COS(metric) && !xq) return fail(VQHIP_EINVAL, "vqhip_encode: the cosine metric needs the xq buffer");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_encode: N or K too large");
+    VQ_NEED("vqhip_encode: cb too small", cb_bytes, vqhip_codebook_bytes(K, D));
+    VQ_NEED("vqhip_encode: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
     if (!vq_coarse_supported(D)) {          // no fp16 proposal image for this D: the separate entry points do the work
-        if (int rc = vqhip_codebook_prepare(e, K, D, metric, cb, stream)) return rc;
+        if (int rc = vqhip_codebook_prepare(e, K, D, metric, cb, cb_bytes, stream)) return rc;
         const void *rows = x; int rows_dtype = x_dtype;
         if (VQ_IS_COS(metric)) {
             if (VQ_IS_BF16(metric)) return fail(VQHIP_EINVAL, "vqhip_encode: the bf16-autocast cosine metric needs D <= 1024, D % 8 == 0");
             if (int rc = vqhip_normalize_rows(x, x_dtype, N, D, 1e-12f, xq, stream)) return rc;
             rows = xq; rows_dtype = VQHIP_DTYPE_F32;
         }
-        return vqhip_argmin(rows, rows_dtype, e, cb, N, K, D, metric, idx, hist, ws, stream);
+        return vqhip_argmin(rows, rows_dtype, e, cb, cb_bytes, N, K, D, metric, idx, hist, ws, ws_bytes, stream);
     }
     hipStream_t s = (hipStream_t)stream;
     const bool cos = VQ_IS_COS(metric);
@@ -534,31 +549,33 @@ int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64
                            stream, /*x_prepared=*/true);
 }
 
-int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t N, int64_t K, int D, int metric,
-                 int64_t *idx, int32_t *hist, void *ws, void *stream) {
+int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t cb_bytes, int64_t N, int64_t K, int D, int metric,
+                 int64_t *idx, int32_t *hist, void *ws, int64_t ws_bytes, void *stream) {
     if (N == 0) return VQHIP_OK;
     if (!x || !cb || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin: bad argument");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: metric");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin: x_dtype");
     if (metric == VQHIP_METRIC_L2 && !e) return fail(VQHIP_EINVAL, "vqhip_argmin: e is required for L2");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin: N or K too large");
+    VQ_NEED("vqhip_argmin: cb too small", cb_bytes, vqhip_codebook_bytes(K, D));
+    VQ_NEED("vqhip_argmin: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
     VqCbLayout L = vq_cb_layout(K, D);
     const float *e_exact = VQ_IS_COS(metric) ? (const float *)((const char *)cb + L.off_eexact) : e;
     if (!vq_coarse_supported(D)) {
         // no fp16 proposal image for this D: whole-codebook fp32 pass for every row
         VQ_HIP(hipMemsetAsync(ws, 0, 256, (hipStream_t)stream));
-        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, stream);
+        return vqhip_argmin_exact(x, x_dtype, e_exact, N, K, D, metric, idx, nullptr, hist, ws, ws_bytes, stream);
     }
     return argmin_pipeline(x, x_dtype, e_exact, cb, N, K, D, metric, idx, hist, ws, stream);
 }
 
 int vqhip_argmin_exact(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, int64_t *idx,
-                       float *dmin, int32_t *hist, void *ws, void *stream) {
+                       float *dmin, int32_t *hist, void *ws, int64_t ws_bytes, void *stream) {
     if (N == 0) return VQHIP_OK;
     if (!x || !e || !idx || !ws || N < 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: bad argument");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: x_dtype");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_argmin_exact: N or K too large");
-    if (N == 0) return VQHIP_OK;
+    VQ_NEED("vqhip_argmin_exact: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
     hipStream_t s = (hipStream_t)stream;
     VqWsLayout W = vq_ws_layout(N, K, D);
     char *w = (char *)ws;
@@ -593,11 +610,12 @@ int64_t vqhip_col_workspace_bytes(int64_t N, int64_t K, int D) {
 }
 
 int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric,
-                     int64_t *col_idx, void *ws, void *stream) {
+                     int64_t *col_idx, void *ws, int64_t ws_bytes, void *stream) {
     if (!x || !e || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_col_argmin: bad argument");
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin: N or K too large");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: x_dtype");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin: metric");
+    VQ_NEED("vqhip_col_argmin: ws too small", ws_bytes, vqhip_col_workspace_bytes(N, K, D));
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
     if (vq_coarse_supported(D)) {
@@ -656,7 +674,7 @@ int64_t vqhip_col_rows_workspace_bytes(int64_t N, int64_t cap, int D) {
 }
 
 int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
-                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, void *stream) {
+                          int64_t N, int64_t K, int D, int metric, int64_t *col_idx, void *ws, int64_t ws_bytes, void *stream) {
     if (!x || !e || !rows || !count || !col_idx || !ws || N <= 0 || K <= 0 || D <= 0 || cap < 0 || cap > K)
         return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: bad argument");
     if (cap == 0) return VQHIP_OK;
@@ -664,6 +682,7 @@ int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int3
     if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: N or K too large");
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: x_dtype");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_col_argmin_rows: metric");
+    VQ_NEED("vqhip_col_argmin_rows: ws too small", ws_bytes, vqhip_col_rows_workspace_bytes(N, cap, D));
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
     const int64_t a = (vq_ws_layout(cap, N, D).total + 1023) / 1024 * 1024;
@@ -690,8 +709,9 @@ int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int3
 }
 
 int vqhip_distance(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, float *d, void *ws,
-                   void *stream) {
+                   int64_t ws_bytes, void *stream) {
     if (!x || !e || !d || !ws || N <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_distance: bad argument");
+    VQ_NEED("vqhip_distance: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
     hipStream_t s = (hipStream_t)stream;
     VqWsLayout W = vq_ws_layout(N, K, D);
     char *w = (char *)ws;
@@ -943,8 +963,9 @@ int64_t vqhip_order_workspace_bytes(int64_t N, int64_t K) {
 }
 
 int vqhip_token_order(const int64_t *idx, int64_t N, int64_t K, int32_t *counts, int32_t *offsets, int32_t *order, void *ws,
-                      void *stream) {
+                      int64_t ws_bytes, void *stream) {
     if (!idx || !counts || !offsets || !order || !ws || N < 0 || K <= 0) return fail(VQHIP_EINVAL, "vqhip_token_order: bad argument");
+    VQ_NEED("vqhip_token_order: ws too small", ws_bytes, vqhip_order_workspace_bytes(N, K));
     if (K > 32768) return fail(VQHIP_EINVAL, "vqhip_token_order: K > 32768 (per-chunk histogram must fit in LDS)");
     if (N >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_token_order: N too large");
     const int64_t nchunks = (N + VQ_SORT_CHUNK - 1) / VQ_SORT_CHUNK;
@@ -975,17 +996,19 @@ int64_t vqhip_segsum_workspace_bytes(int64_t N, int D) {
 }
 
 int vqhip_segsum_rows(const float *src, const int64_t *idx, const int32_t *order, const int32_t *offsets, int64_t N, int64_t K,
-                      int D, float *dst, void *ws, void *stream) {
+                      int D, float *dst, void *ws, int64_t ws_bytes, void *stream) {
     if (!src || !idx || !order || !offsets || !dst || !ws || N < 0 || K <= 0 || D <= 0 || (D % 4) != 0)
         return fail(VQHIP_EINVAL, "vqhip_segsum_rows: bad argument (D must be a multiple of 4)");
+    VQ_NEED("vqhip_segsum_rows: ws too small", ws_bytes, vqhip_segsum_workspace_bytes(N, D));
     return run_segsum<0>(src, VQHIP_DTYPE_F32, nullptr, idx, order, offsets, N, K, D, nullptr, dst, ws, (hipStream_t)stream);
 }
 
 int vqhip_vq_backward_w_ordered(const void *x, int x_dtype, const float *e, const int64_t *idx, const int32_t *order,
                                 const int32_t *offsets, int64_t N, int64_t K, int D, const float *g_cb, float *grad_w, void *ws,
-                                void *stream) {
+                                int64_t ws_bytes, void *stream) {
     if (!x || !e || !idx || !order || !offsets || !grad_w || !ws || N < 0 || K <= 0 || D <= 0 || (D % 4) != 0)
         return fail(VQHIP_EINVAL, "vqhip_vq_backward_w_ordered: bad argument (D must be a multiple of 4)");
+    VQ_NEED("vqhip_vq_backward_w_ordered: ws too small", ws_bytes, vqhip_segsum_workspace_bytes(N, D));
     if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_vq_backward_w_ordered: x_dtype");
     return run_segsum<1>(x, x_dtype, e, idx, order, offsets, N, K, D, g_cb, grad_w, ws, (hipStream_t)stream);
 }
@@ -1034,9 +1057,10 @@ int vqhip_codebook_metrics(const int64_t *counts, int64_t K, double *out, void *
 }
 
 int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int64_t N, int64_t K, int D, int metric,
-                                float *scores, float *margin, float *scale, void *ws, void *stream) {
+                                float *scores, float *margin, float *scale, void *ws, int64_t ws_bytes, void *stream) {
     if (!x || !cb || !scores || !margin || !scale || !ws || N <= 0 || K <= 0 || !vq_coarse_supported(D))
         return fail(VQHIP_EINVAL, "vqhip_debug_proposal_scores: bad argument");
+    VQ_NEED("vqhip_debug_proposal_scores: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     VqWsLayout W = vq_ws_layout(N, K, D);

@@ -125,7 +125,7 @@ def prepare_codebook(e: torch.Tensor, metric='L2') -> PreparedCodebook:
     m = METRICS[metric]
     L = _lib.lib()
     image = _bytes(L.vqhip_codebook_bytes(K, D), e.device)
-    check(L.vqhip_codebook_prepare(_ptr(e), K, D, m, _ptr(image), _stream()), 'vqhip_codebook_prepare')
+    check(L.vqhip_codebook_prepare(_ptr(e), K, D, m, _ptr(image), image.numel(), _stream()), 'vqhip_codebook_prepare')
     return PreparedCodebook(image, e, K, D, m)
 
 
@@ -145,8 +145,8 @@ def argmin(x: torch.Tensor, cb: PreparedCodebook, hist: Optional[torch.Tensor] =
     ws = _bytes(L.vqhip_workspace_bytes(N, cb.K, D), x.device)
     if hist is not None:
         assert hist.dtype == torch.int32 and hist.numel() == cb.K and hist.is_contiguous()
-    check(L.vqhip_argmin(_ptr(x), dt, _ptr(cb.weight), _ptr(cb.image), N, cb.K, D, cb.metric, _ptr(idx),
-                         _ptr(hist), _ptr(ws), _stream()), 'vqhip_argmin')
+    check(L.vqhip_argmin(_ptr(x), dt, _ptr(cb.weight), _ptr(cb.image), cb.image.numel(), N, cb.K, D, cb.metric, _ptr(idx),
+                         _ptr(hist), _ptr(ws), ws.numel(), _stream()), 'vqhip_argmin')
     if return_stats:
         st = torch.zeros(4, dtype=torch.int32, device=x.device)
         if N > 0:
@@ -177,8 +177,8 @@ def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.T
     if hist is not None:
         assert hist.dtype == torch.int32 and hist.numel() == K and hist.is_contiguous()
     # zero_hist: `hist` may be uninitialised memory — the call's first launch zeroes it (no separate fill kernel)
-    check(L.vqhip_encode_ex(_ptr(x), dt, _ptr(e), N, K, D, m, _ptr(image), _ptr(idx), _ptr(hist), _ptr(xq), _ptr(ws),
-                            1 if (zero_hist and hist is not None) else 0, _stream()), 'vqhip_encode_ex')
+    check(L.vqhip_encode_ex(_ptr(x), dt, _ptr(e), N, K, D, m, _ptr(image), image.numel(), _ptr(idx), _ptr(hist), _ptr(xq),
+                            _ptr(ws), ws.numel(), 1 if (zero_hist and hist is not None) else 0, _stream()), 'vqhip_encode_ex')
     return idx, PreparedCodebook(image, e, K, D, m), xq
 
 
@@ -196,7 +196,7 @@ def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[t
     dmin = torch.empty(N, dtype=torch.float32, device=x.device) if return_min else None
     ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
     check(L.vqhip_argmin_exact(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(idx), _ptr(dmin), _ptr(hist),
-                               _ptr(ws), _stream()), 'vqhip_argmin_exact')
+                               _ptr(ws), ws.numel(), _stream()), 'vqhip_argmin_exact')
     return (idx, dmin) if return_min else idx
 
 
@@ -211,7 +211,7 @@ def distance(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     L = _lib.lib()
     d = torch.empty(N, K, dtype=torch.float32, device=x.device)
     ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x.device)
-    check(L.vqhip_distance(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(d), _ptr(ws), _stream()),
+    check(L.vqhip_distance(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(d), _ptr(ws), ws.numel(), _stream()),
           'vqhip_distance')
     return d
 
@@ -227,7 +227,7 @@ def col_argmin(x: torch.Tensor, e: torch.Tensor, metric='L2') -> torch.Tensor:
     L = _lib.lib()
     out = torch.empty(K, dtype=torch.int64, device=x.device)
     ws = _bytes(L.vqhip_col_workspace_bytes(N, K, D), x.device)
-    check(L.vqhip_col_argmin(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(out), _ptr(ws), _stream()),
+    check(L.vqhip_col_argmin(_ptr(x), dt, _ptr(e), N, K, D, METRICS[metric], _ptr(out), _ptr(ws), ws.numel(), _stream()),
           'vqhip_col_argmin')
     return out
 
@@ -377,7 +377,7 @@ def token_order(idx: torch.Tensor, K: int):
     offsets = torch.empty(K + 1, dtype=torch.int32, device=idx.device)
     order = torch.empty(max(N, 1), dtype=torch.int32, device=idx.device)
     ws = _bytes(L.vqhip_order_workspace_bytes(N, K), idx.device)
-    check(L.vqhip_token_order(_ptr(idx), N, K, _ptr(counts), _ptr(offsets), _ptr(order), _ptr(ws), _stream()),
+    check(L.vqhip_token_order(_ptr(idx), N, K, _ptr(counts), _ptr(offsets), _ptr(order), _ptr(ws), ws.numel(), _stream()),
           'vqhip_token_order')
     return counts, offsets, order[:N]
 
@@ -392,8 +392,8 @@ def segsum_rows(src: torch.Tensor, idx: torch.Tensor, offsets: torch.Tensor, ord
     L = _lib.lib()
     out = torch.empty(K, D, dtype=torch.float32, device=src.device)
     ws = _bytes(L.vqhip_segsum_workspace_bytes(N, D), src.device)
-    check(L.vqhip_segsum_rows(_ptr(src), _ptr(idx), _ptr(order), _ptr(offsets), N, K, D, _ptr(out), _ptr(ws), _stream()),
-          'vqhip_segsum_rows')
+    check(L.vqhip_segsum_rows(_ptr(src), _ptr(idx), _ptr(order), _ptr(offsets), N, K, D, _ptr(out), _ptr(ws), ws.numel(),
+                              _stream()), 'vqhip_segsum_rows')
     return out
 
 
@@ -534,7 +534,7 @@ def col_argmin_rows(x: torch.Tensor, e: torch.Tensor, rows: torch.Tensor, count:
     if cap > 0:
         ws = _bytes(L.vqhip_col_rows_workspace_bytes(N, cap, D), x.device)
         check(L.vqhip_col_argmin_rows(_ptr(x), dt, _ptr(e), _ptr(rows), _ptr(count), cap, N, K, D, METRICS[metric], _ptr(out),
-                                      _ptr(ws), _stream()), 'vqhip_col_argmin_rows')
+                                      _ptr(ws), ws.numel(), _stream()), 'vqhip_col_argmin_rows')
     return out[:cap]
 
 
@@ -697,7 +697,7 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
         _, offsets, order = token_order(idx, K)
         ws = _bytes(L.vqhip_segsum_workspace_bytes(N, D), x.device)
         check(L.vqhip_vq_backward_w_ordered(_ptr(x), dt, _ptr(e), _ptr(idx), _ptr(order), _ptr(offsets), N, K, D,
-                                            _ptr(scal[0]), _ptr(gw), _ptr(ws), _stream()), 'vqhip_vq_backward_w_ordered')
+                                            _ptr(scal[0]), _ptr(gw), _ptr(ws), ws.numel(), _stream()), 'vqhip_vq_backward_w_ordered')
     return gx, gw
 
 
@@ -735,5 +735,5 @@ def debug_proposal_scores(x: torch.Tensor, cb: PreparedCodebook):
     scale = torch.empty(1, dtype=torch.float32, device=x.device)
     ws = _bytes(L.vqhip_workspace_bytes(N, cb.K, D), x.device)
     check(L.vqhip_debug_proposal_scores(_ptr(x), dt, _ptr(cb.image), N, cb.K, D, cb.metric, _ptr(scores), _ptr(margin),
-                                        _ptr(scale), _ptr(ws), _stream()), 'vqhip_debug_proposal_scores')
+                                        _ptr(scale), _ptr(ws), ws.numel(), _stream()), 'vqhip_debug_proposal_scores')
     return scores, margin, scale
