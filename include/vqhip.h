@@ -75,6 +75,18 @@ int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t 
 int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
                     int64_t *idx, int32_t *hist, float *xq, void *ws, int64_t ws_bytes, int flags, void *stream);
 
+/* vqhip_encode_ex for latents that arrive as the FEATURE MAP [B, D, HW] the encoder / post_encode connector produced: the
+ * 'b c h w -> (b h w) c' rearrangement of vq/tasks/image_tokenization/models/base.py:124,140 is folded into the call's first
+ * launch (64-dim x 32-token tiles are read with the tokens along the lanes and turned through LDS), so no transpose kernel
+ * runs and the map is read once.  N = B*HW tokens, token n = (b, p) with n = b*HW + p.
+ *   xrows [N, D] in x_dtype: receives the token-major copy of the latents the rest of the step works on (the exact re-rank of
+ *   this call for L2, vqhip_gather_ste_*, vqhip_vq_backward); xq [N, D] fp32: cosine only — F.normalize(x), as in vqhip_encode
+ *   (NULL for L2).  Keep both alive until the call has completed.  D <= 1024, D % 8 == 0.  Same results as transposing and
+ *   calling vqhip_encode_ex, bit for bit. */
+int vqhip_encode_map(const void *x_map, int x_dtype, const float *e, int64_t B, int64_t HW, int64_t K, int D, int metric, void *cb,
+                     int64_t cb_bytes, int64_t *idx, int32_t *hist, void *xrows, float *xq, void *ws, int64_t ws_bytes, int flags,
+                     void *stream);
+
 /* Byte offset, inside an image prepared with VQHIP_METRIC_COS, of the fp32 [K, D] rows F.normalize(e, dim=1) the exact
  * definition consumes (bit-identical to vqhip_normalize_rows(e)); 256-byte aligned.  Lets a caller that needs the
  * normalised codebook again in the same step (NearestAnchor's column argmin, vq/algorithms/cvqvae/anchors.py:83-84)
@@ -145,6 +157,13 @@ int vqhip_gather_ste_loss(const void *x, int x_dtype, const float *e, const int6
  * flight); N > 0. */
 int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
                          float *z, float *z_ste, float *mse, float beta, void *scratch16, void *stream);
+
+/* The same with the OUTPUT written as the feature map [B, D, HW] ('(b h w) c -> b c h w' + .contiguous(), models/base.py:126-127,
+ * folded into the gather: 64 x 64 tiles turned through LDS, 256 contiguous bytes per channel and wave-instruction):
+ *   x_rows != NULL: out_map = x + (e[idx] - x) (straight-through output), mse[4] as vqhip_gather_ste_mse, scratch16 as there;
+ *   x_rows == NULL: out_map = e[idx] (decode_from_quant, image_reconstruction/models.py:97-106); mse, scratch16 unused. */
+int vqhip_gather_ste_map(const void *x_rows, int x_dtype, const float *e, const int64_t *idx, int64_t B, int64_t HW, int D,
+                         float *out_map, float *mse, float beta, void *scratch16, void *stream);
 
 /* hist[K] int32 += bincount(idx) (utils.py:42; runners/metrics.py:40-44) */
 int vqhip_hist(const int64_t *idx, int64_t N, int64_t K, int32_t *hist, void *stream);

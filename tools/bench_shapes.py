@@ -50,7 +50,7 @@ idx = ops.argmin(x, ops.prepare_codebook(w, 'L2'))
 t = timeit(lambda: ops.scatter_add_rows(x, idx, K)); print(f'scatter_add_rows: {t*1e3:.3f} ms')
 t = timeit(lambda: ops.hist(idx, K)); print(f'hist: {t*1e3:.3f} ms')
 
-# model-level quantize(): NCHW latent map (HIP transposes either side) vs channels-last (views)
+# model-level quantize(): NCHW latent map (rearrangements folded into the encode / gather kernels) vs channels-last (views)
 from vector_quantization_amd import build_quantizer, Config, tokenization as T
 B, C, H, W, K = 256, 256, 16, 16, 16384
 q = build_quantizer(dict(type='VQGANQuantizer', embedding=dict(type='torch_nn_modules_sparse_Embedding', num_embeddings=K, embedding_dim=C),

@@ -26,6 +26,8 @@ SIGNATURES = {
     'vqhip_codebook_exact_offset': (_i64, [_i64, _i32]),
     'vqhip_encode': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'vqhip_encode_ex': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    'vqhip_encode_map': (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    'vqhip_gather_ste_map': (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp]),
     'vqhip_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_col_workspace_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_codebook_prepare': (_i32, [_vp, _i64, _i32, _i32, _vp, _i64, _vp]),

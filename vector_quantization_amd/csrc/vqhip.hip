@@ -490,8 +490,10 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
 // Front of an encode whose codebook image is made in the same call: ONE launch for the codebook statistics and the whole
 // token side (they are independent), then the image kernel.  `rows` are the N rows to quantize (normalised into `xq`
 // first when xnorm), `codes` the Kc rows the image is made from, `ws` the workspace of argmin_pipeline(N rows, Kc codes).
+// hw > 0: `rows` is the feature map [N / hw, D, hw] (NCHW); the token-major rows go to `xrows` (input dtype; cosine: xq)
 static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const float *codes, int64_t Kc, int D, int cb_metric,
-                              void *cb, void *ws, bool xnorm, float *xq, hipStream_t s, int32_t *hist_zero = nullptr) {
+                              void *cb, void *ws, bool xnorm, float *xq, hipStream_t s, int32_t *hist_zero = nullptr,
+                              int64_t hw = 0, void *xrows = nullptr) {
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
@@ -500,9 +502,14 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
     char *ximg = w + W.off_ximg;
-#define VQ_PRE(DT, XN) pre_kernel<DT, XN><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero)
-    if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true); else VQ_PRE(0, false); }
-    else { if (xnorm) VQ_PRE(1, true); else VQ_PRE(1, false); }
+#define VQ_PRE(DT, XN, MAP) pre_kernel<DT, XN, MAP><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
+    if (hw > 0) {
+        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true, true); else VQ_PRE(0, false, true); }
+        else { if (xnorm) VQ_PRE(1, true, true); else VQ_PRE(1, false, true); }
+    } else {
+        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true, false); else VQ_PRE(0, false, false); }
+        else { if (xnorm) VQ_PRE(1, true, false); else VQ_PRE(1, false, false); }
+    }
 #undef VQ_PRE
     VQ_CHECK_LAUNCH("pre_kernel");
     cb_image_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(codes, Kc, D, cb_metric, c, L);
@@ -547,6 +554,30 @@ int vqhip_encode_ex(const void *x, int x_dtype, const float *e, int64_t N, int64
     // from here on the rows are what vqhip_argmin would have been given: the normalised fp32 rows for cosine
     return argmin_pipeline(cos ? (const void *)xq : x, cos ? VQHIP_DTYPE_F32 : x_dtype, e_exact, cb, N, K, D, metric, idx, hist, ws,
                            stream, /*x_prepared=*/true);
+}
+
+int vqhip_encode_map(const void *x_map, int x_dtype, const float *e, int64_t B, int64_t HW, int64_t K, int D, int metric, void *cb,
+                     int64_t cb_bytes, int64_t *idx, int32_t *hist, void *xrows, float *xq, void *ws, int64_t ws_bytes, int flags,
+                     void *stream) {
+    const int64_t N = B * HW;
+    if (!x_map || !e || !cb || !idx || !xrows || !ws || B <= 0 || HW <= 0 || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_encode_map: bad argument");
+    if (VQ_IS_COS(metric) && !xq) return fail(VQHIP_EINVAL, "vqhip_encode_map: the cosine metric needs the xq buffer");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_encode_map: metric");
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_encode_map: x_dtype");
+    if (N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_encode_map: N or K too large");
+    if (!vq_coarse_supported(D)) return fail(VQHIP_EINVAL, "vqhip_encode_map: needs D <= 1024, D % 8 == 0 (transpose and use vqhip_encode)");
+    VQ_NEED("vqhip_encode_map: cb too small", cb_bytes, vqhip_codebook_bytes(K, D));
+    VQ_NEED("vqhip_encode_map: ws too small", ws_bytes, vqhip_workspace_bytes(N, K, D));
+    hipStream_t s = (hipStream_t)stream;
+    const bool cos = VQ_IS_COS(metric);
+    const bool zero_hist = hist != nullptr && (flags & VQHIP_ENCODE_ZERO_HIST) != 0;
+    if (int rc = encode_fused_front(x_map, x_dtype, N, e, K, D, metric, cb, ws, cos, cos ? xq : nullptr, s,
+                                    zero_hist ? hist : nullptr, HW, xrows)) return rc;
+    VqCbLayout L = vq_cb_layout(K, D);
+    const float *e_exact = cos ? (const float *)((const char *)cb + L.off_eexact) : e;
+    // from here on the rows are token-major: what the front wrote (L2: the copy in the input dtype; cosine: the normalised fp32 rows)
+    return argmin_pipeline(cos ? (const void *)xq : (const void *)xrows, cos ? VQHIP_DTYPE_F32 : x_dtype, e_exact, cb, N, K, D, metric,
+                           idx, hist, ws, stream, /*x_prepared=*/true);
 }
 
 int vqhip_argmin(const void *x, int x_dtype, const float *e, const void *cb, int64_t cb_bytes, int64_t N, int64_t K, int D, int metric,
@@ -747,6 +778,22 @@ int vqhip_gather_ste_mse(const void *x, int x_dtype, const float *e, const int64
                          float *z_ste, float *mse, float beta, void *scratch16, void *stream) {
     if (!x || !e || !idx || !mse || !scratch16 || N <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_gather_ste_mse: bad argument");
     return gather_ste_impl(x, x_dtype, e, idx, N, D, z, z_ste, (double *)scratch16, mse, stream, beta);
+}
+
+int vqhip_gather_ste_map(const void *x_rows, int x_dtype, const float *e, const int64_t *idx, int64_t B, int64_t HW, int D,
+                         float *out_map, float *mse, float beta, void *scratch16, void *stream) {
+    const int64_t N = B * HW;
+    if (!e || !idx || !out_map || B <= 0 || HW <= 0 || D <= 0 || (x_rows && (!mse || !scratch16)))
+        return fail(VQHIP_EINVAL, "vqhip_gather_ste_map: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double *sse = x_rows ? (double *)scratch16 : nullptr;
+    int64_t ntiles = (N + 63) / 64;
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (!x_rows || x_dtype == VQHIP_DTYPE_F32) gather_ste_map_kernel<0><<<grid, 256, 0, s>>>(x_rows, e, idx, N, D, HW, out_map, sse, mse, beta);
+    else if (x_dtype == VQHIP_DTYPE_BF16) gather_ste_map_kernel<1><<<grid, 256, 0, s>>>(x_rows, e, idx, N, D, HW, out_map, sse, mse, beta);
+    else return fail(VQHIP_EINVAL, "vqhip_gather_ste_map: x_dtype");
+    VQ_CHECK_LAUNCH("gather_ste_map_kernel");
+    return VQHIP_OK;
 }
 
 static int gather_ste_impl(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D, float *z,

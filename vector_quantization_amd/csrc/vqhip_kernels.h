@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vqhip_layout.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -439,20 +441,26 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
 // XNORM (cosine through vqhip_encode): the rows are first normalised exactly as normalize_rows_kernel does — the
 // oracle-order |x|^2 this kernel computes anyway is that kernel's sum — written to `xq` as fp32, and everything else
 // (image, |xh|^2, residual, |x|^2) is taken from the normalised rows: one launch less, one pass over x less.
-template <int DT, bool XNORM = false>
+// NCHW (vqhip_encode_map: the latents arrive as the feature map [B, D, HW] the encoder / connector produced, the
+// reference's 'b c h w -> (b h w) c' of models/base.py:124 is folded into this kernel): every 64-dim x 32-token tile is read
+// with the tokens along the lanes (coalesced 64/128-byte segments per channel), turned through LDS, and from there on the
+// kernel is the token-major one; the rows it has in registers anyway are also written out token-major (`xrows`, in the
+// input's dtype; cosine: additionally the normalised fp32 rows `xq`) for the exact re-rank, the gather and the backward.
+template <int DT, bool XNORM = false, bool NCHW = false>
 __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict__ x, int64_t N, int D, int nstep,
                                             char *__restrict__ ximg, float *__restrict__ xh2,
                                             float *__restrict__ rho2, float *__restrict__ xn,
                                             int *__restrict__ counters, int *__restrict__ arrive, int narrive,
                                             float *__restrict__ xq, float eps, int xround = 0,
                                             int32_t *__restrict__ hist_zero = nullptr, int64_t hist_len = 0,
-                                            int64_t nblocks = 1) {
+                                            int64_t nblocks = 1, int64_t hw = 0, void *__restrict__ xrows = nullptr) {
     __shared__ float red[2][8][32];
     // vqhip_encode(VQHIP_ENCODE_ZERO_HIST): the code-hit histogram the later kernels of this call add into starts from zero
     if (hist_zero != nullptr)
         for (int64_t i = blk * 256 + threadIdx.x; i < hist_len; i += nblocks * 256) hist_zero[i] = 0;
     __shared__ float part[64][32];   // the 64 interleaved partial sums of |x|^2 (oracle order), per token
     __shared__ float den_s[32];
+    __shared__ float tile[NCHW ? 64 : 1][33];     // NCHW: 64 dims x 32 tokens of the map, turned here
     if (blk == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // housekeeping for the later kernels of this call (stream-ordered)
     // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
     if (arrive != nullptr && threadIdx.x == 0 && blk < narrive) arrive[blk] = 0;
@@ -461,6 +469,58 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
     const bool tvalid = t < N;
     const int64_t trow = tvalid ? t : (N - 1);
     const int ns32 = nstep >> 1;
+    // NCHW: element (token trow, dim d) lives at map_base + d * hw
+    const int64_t map_base = NCHW ? ((trow / hw) * (int64_t)D * hw + (trow % hw)) : 0;
+    // the 64 dims [64 it, 64 it + 64) of this block's 32 tokens -> tile (uniform: every thread of the block calls it)
+    // fast form of the tile load: the block's 32 tokens are 32 consecutive positions of ONE image (hw % 32 == 0, which also
+    // keeps every 8-token group 16/32-byte aligned): thread (channel c = tid >> 2, group tg = tid & 3) loads 8 consecutive
+    // tokens of its channel with one (bf16) or two (fp32) 16-byte loads — a wave-instruction covers 16 channels x 64/128 B
+    const int niter_stage = (ns32 * 4 + 7) / 8;
+    const bool vec_tile = NCHW && (hw % 32) == 0 && blk * 32 + 32 <= N;
+    const int64_t tile_base = NCHW ? (((blk * 32) / (hw > 0 ? hw : 1)) * (int64_t)D * hw + ((blk * 32) % (hw > 0 ? hw : 1))) : 0;
+    // (the tile after the one being consumed is already on its way: its loads are issued right behind the barrier that
+    //  publishes the current tile, so the map's latency hides behind the fp16 conversion work of the current one)
+    typename RawVec<DT>::type ahead;
+    int ahead_it = -1;
+    auto stage = [&](int it) {
+        if constexpr (NCHW) {
+            __syncthreads();                                  // the previous tile has been consumed
+            if (vec_tile) {
+                const int c = threadIdx.x >> 2, tg = threadIdx.x & 3;
+                if (ahead_it != it && 64 * it + c < D) ahead = RawVec<DT>::load(x, tile_base + (int64_t)(64 * it + c) * hw + 8 * tg);
+                float v[8];
+                if (64 * it + c < D) RawVec<DT>::unpack(ahead, v);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tile[c][8 * tg + j] = v[j];
+                __syncthreads();
+                ahead_it = it + 1;
+                if (ahead_it < niter_stage && 64 * ahead_it + c < D)
+                    ahead = RawVec<DT>::load(x, tile_base + (int64_t)(64 * ahead_it + c) * hw + 8 * tg);
+                return;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int dl = g + 8 * j, d = 64 * it + dl;   // a wave-instruction: 2 channels x 32 consecutive tokens
+                    tile[dl][r] = (tvalid && d < D) ? load_elem<DT>(x, map_base + (int64_t)d * hw) : 0.0f;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    // 8 consecutive dims of this thread's token for `piece` (dims 8*piece ..): from memory, or from the staged tile
+    auto fetch = [&](int piece, float (&v)[8]) {
+        if constexpr (NCHW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[(8 * piece + j) & 63][r];
+        } else {
+            load8<DT>(x, trow * D + 32 * (piece >> 2) + 8 * (piece & 3), v);
+        }
+    };
+    const int npieces = ns32 * 4, niter = (npieces + 7) / 8;
     float s_h = 0.0f, s_r = 0.0f;
     // thread g sees exactly the dims with d mod 64 in [8g, 8g+8), in increasing d: partial j = 8g + jj of the oracle's
     // |x|^2 (64 interleaved fma chains, then the halving tree)
@@ -480,17 +540,20 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
         for (int i = 0; i < KEEP; ++i) {
             const int piece = g + 8 * i;
             const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
-            if (piece < ns32 * 4 && tvalid && d0 < D) {
-                load8<DT>(x, trow * D + d0, kept[i]);
+            if (i < niter) stage(i);
+            if (piece < npieces && tvalid && d0 < D) {
+                fetch(piece, kept[i]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pn[j] = fmaf(kept[i][j], kept[i][j], pn[j]);
             }
         }
-        for (int piece = g + 8 * KEEP; piece < ns32 * 4; piece += 8) {
+        for (int it = KEEP; it < niter; ++it) {
+            const int piece = g + 8 * it;
             const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
-            if (tvalid && d0 < D) {
+            stage(it);
+            if (piece < npieces && tvalid && d0 < D) {
                 float v[8];
-                load8<DT>(x, trow * D + d0, v);
+                fetch(piece, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pn[j] = fmaf(v[j], v[j], pn[j]);
             }
@@ -515,9 +578,12 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) pn[j] = 0.0f;
     }
-    for (int piece = g; piece < ns32 * 4; piece += 8) {
+    for (int it = 0; it < niter; ++it) {
+        const int piece = g + 8 * it;
         const int s = piece >> 2, q4 = piece & 3;
         const int d0 = 32 * s + 8 * q4;
+        if (!(XNORM && keep)) stage(it);               // (kept in registers: the map is read once)
+        if (piece >= npieces) continue;
         half8 f;
         if (tvalid && d0 < D) {
             float v[8];
@@ -533,7 +599,21 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
                         }
                 }
             }
-            if (!have) load8<DT>(x, trow * D + d0, v);
+            if (!have) fetch(piece, v);
+            if constexpr (NCHW) {                  // the token-major rows as given, in the input's own dtype (exact: a copy)
+                if (DT == 0) {
+                    float *o = (float *)xrows + trow * D + d0;
+                    *(f32x4 *)o = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4 *)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    uint4 o;
+                    o.x = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xFFFF0000u);
+                    o.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xFFFF0000u);
+                    o.z = (__float_as_uint(v[4]) >> 16) | (__float_as_uint(v[5]) & 0xFFFF0000u);
+                    o.w = (__float_as_uint(v[6]) >> 16) | (__float_as_uint(v[7]) & 0xFFFF0000u);
+                    *(uint4 *)((uint16_t *)xrows + trow * D + d0) = o;
+                }
+            }
             if constexpr (XNORM) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { v[j] = v[j] / den; if (xround) v[j] = bf16_rne(v[j]); }
@@ -586,16 +666,17 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 }
 // vqhip_encode / vqhip_col_argmin: the codebook statistics and the token side in ONE launch (they are independent;
 // the image kernel that follows needs the former, the proposal kernel both)
-template <int DT, bool XNORM>
+template <int DT, bool XNORM, bool NCHW = false>
 __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int metric, char *cb, VqCbLayout L, int nblk_stats,
                                                   const void *__restrict__ x, int64_t N, int D, int nstep,
                                                   char *__restrict__ ximg, float *__restrict__ xh2,
                                                   float *__restrict__ rho2, float *__restrict__ xn,
                                                   int *__restrict__ counters, int *__restrict__ arrive, int narrive,
-                                                  float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero) {
+                                                  float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero,
+                                                  int64_t hw = 0, void *__restrict__ xrows = nullptr) {
     if ((int)blockIdx.x < nblk_stats) cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
-    else x_prep_body<DT, XNORM>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
-                                VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)gridDim.x - nblk_stats);
+    else x_prep_body<DT, XNORM, NCHW>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
+                                      VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)gridDim.x - nblk_stats, hw, xrows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2071,6 +2152,153 @@ __global__ __launch_bounds__(1024) void gather_ste_loss_kernel(const void *x, co
                     __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+        }
+    }
+}
+
+// The same pass with the OUTPUT written as the feature map [B, D, HW] the decoder side consumes — the reference's
+// '(b h w) c -> b c h w' + .contiguous() of models/base.py:126-127 folded into the gather: a workgroup takes 64 tokens, reads
+// codebook rows and latents token-major (256-byte rows per wave-instruction), turns 64 x 64 tiles through LDS and writes them
+// with the tokens along the lanes (256 contiguous bytes per channel).  x == nullptr: plain decode (z = e[idx], no loss).
+// Measured at 65 536 tokens x 256 channels: 43 us against 26-29 for the token-major kernel's fully contiguous rows — the
+// strided 256-byte segments are the cost (whole 1 KiB codebook rows per instruction with 128-byte output segments: 62 us;
+// non-temporal stores: 45 us; loading the next 64-channel chunk while the current one is in LDS: -1 us, kept).
+// mse / sse scratch: as gather_ste_loss_kernel.
+template <int DT>
+__global__ __launch_bounds__(256) void gather_ste_map_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                             const int64_t *__restrict__ idx, int64_t N, int D, int64_t hw,
+                                                             float *__restrict__ out_map, double *sse, float *mse, float beta) {
+    __shared__ float tile[64][65];
+    __shared__ double red[4];
+    __shared__ int64_t code_s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    const int64_t ntiles = (N + 63) / 64;
+    // vector form: 4 channels per lane on the way in (16-byte loads of codebook rows and latents), 4 tokens per lane on the
+    // way out (16-byte stores: 64 tokens of a channel = 256 contiguous bytes) — needs D % 4 == 0 and 4-token groups that stay
+    // inside one image and aligned (hw % 4 == 0)
+    const bool vec = (D % 4) == 0 && (hw % 4) == 0;
+    for (int64_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+        const int64_t n0 = tb * 64;
+        __syncthreads();
+        if (threadIdx.x < 64) code_s[threadIdx.x] = (n0 + threadIdx.x < N) ? idx[n0 + threadIdx.x] : 0;
+        __syncthreads();
+        if (vec) {
+            // chunk c0 + 64 is loaded while chunk c0 goes through LDS (two register sets)
+            const int cl = 4 * (lane & 15);
+            const int t4 = 4 * (lane & 15);
+            const int64_t nw = n0 + t4;
+            const int64_t wbase = (nw < N) ? ((nw / hw) * (int64_t)D * hw + (nw % hw)) : 0;
+            float4 zc[4], zn[4];
+            typename std::conditional<DT == 0, float4, uint2>::type xc[4], xnx[4];
+            auto load_chunk = [&](int c0, float4 (&zr)[4], decltype(xc) &xr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                 // 16 tokens per pass of the workgroup: 4 per wave, 16 lanes each
+                    const int tl = 16 * i + 4 * wave + (lane >> 4);
+                    const int64_t n = n0 + tl;
+                    if (n < N && c0 + cl < D) {
+                        zr[i] = *(const float4 *)(e + code_s[tl] * D + c0 + cl);
+                        if (x != nullptr) {
+                            if constexpr (DT == 0) xr[i] = *(const float4 *)((const float *)x + n * D + c0 + cl);
+                            else xr[i] = *(const uint2 *)((const uint16_t *)x + n * D + c0 + cl);
+                        }
+                    }
+                }
+            };
+            load_chunk(0, zc, xc);
+            for (int c0 = 0; c0 < D; c0 += 64) {
+                if (c0 + 64 < D) load_chunk(c0 + 64, zn, xnx);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tl = 16 * i + 4 * wave + (lane >> 4);
+                    const int64_t n = n0 + tl;
+                    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (n < N && c0 + cl < D) {
+                        const float4 zv = zc[i];
+                        if (x != nullptr) {
+                            float xv[4];
+                            if constexpr (DT == 0) { xv[0] = xc[i].x; xv[1] = xc[i].y; xv[2] = xc[i].z; xv[3] = xc[i].w; }
+                            else {
+                                xv[0] = __uint_as_float(xc[i].x << 16); xv[1] = __uint_as_float(xc[i].x & 0xFFFF0000u);
+                                xv[2] = __uint_as_float(xc[i].y << 16); xv[3] = __uint_as_float(xc[i].y & 0xFFFF0000u);
+                            }
+                            const float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
+                            s += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                            o[0] = xv[0] + d0; o[1] = xv[1] + d1; o[2] = xv[2] + d2; o[3] = xv[3] + d3;
+                        } else {
+                            o[0] = zv.x; o[1] = zv.y; o[2] = zv.z; o[3] = zv.w;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tile[cl + j][tl] = o[j];      // bank (cl + j + tl) % 64: conflict-free
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                 // 16 channels per pass: 4 per wave, 16 lanes (64 tokens) each
+                    const int dl = 16 * i + 4 * wave + (lane >> 4);
+                    if (c0 + dl < D && nw < N) {
+                        float *dst = out_map + wbase + (int64_t)(c0 + dl) * hw;
+                        if (nw + 3 < N) *(float4 *)dst = make_float4(tile[dl][t4], tile[dl][t4 + 1], tile[dl][t4 + 2], tile[dl][t4 + 3]);
+                        else
+                            for (int j = 0; j < 4 && nw + j < N; ++j) dst[j] = tile[dl][t4 + j];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { zc[i] = zn[i]; xc[i] = xnx[i]; }
+            }
+            continue;
+        }
+        for (int c0 = 0; c0 < D; c0 += 64) {
+            const int d = c0 + lane;
+            const int64_t nw = n0 + lane;                     // this lane's token in the write phase: its position in the map
+            const int64_t wbase = (nw < N) ? ((nw / hw) * (int64_t)D * hw + (nw % hw)) : 0;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {                    // wave w: tokens 16w .. 16w+15, lane = channel
+                const int tl = wave * 16 + i;
+                const int64_t n = n0 + tl;
+                float o = 0.0f;
+                if (n < N && d < D) {
+                    const float zv = e[code_s[tl] * D + d];
+                    if (x != nullptr) {
+                        const float xv = load_elem<DT>(x, n * D + d);
+                        const float df = zv - xv;
+                        s += (double)(df * df);
+                        o = xv + df;
+                    } else {
+                        o = zv;
+                    }
+                }
+                tile[lane][tl] = o;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {                    // wave w: channels w, w+4, ...; lane = token
+                const int dl = wave + 4 * i;
+                if (nw < N && c0 + dl < D) out_map[wbase + (int64_t)(c0 + dl) * hw] = tile[dl][lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (sse != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double t = (red[0] + red[1]) + (red[2] + red[3]);
+            int *ticket = (int *)(sse + 1);
+            const double before = atomicAdd(sse, t);          // (returning atomic: complete before the ticket is taken)
+            asm volatile("" :: "v"(before) : "memory");
+            if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+                const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float mean = (float)(total / ((double)N * (double)D));
+                mse[0] = mean; mse[1] = mean;
+                const float weighted = beta * mean;
+                mse[2] = mean + weighted; mse[3] = 0.0f;
+                __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

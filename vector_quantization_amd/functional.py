@@ -132,3 +132,37 @@ def fused_decode_loss(x: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, 
     """Returns (z_ste, m_cb, m_cm, m_cb + beta*m_cm): the straight-through output, the codebook / commitment MSE values and
     their VQGAN combination."""
     return _FusedDecodeLoss.apply(x, weight, idx, beta)
+
+
+class _FusedMapDecodeLoss(Function):
+    """``_FusedDecodeLoss`` for a quantizer call on the NCHW feature map (tokenization.quantize): the straight-through
+    output is written directly as the map [B, D, H, W], the loss values are those of the token form.  ``x_rows`` are the
+    token-major rows the map encode produced (``ops.encode_map``); gradients flow to ``x_map`` and the codebook."""
+
+    @staticmethod
+    def forward(ctx, x_map: torch.Tensor, x_rows: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, beta: float = 0.0):
+        ctx.set_materialize_grads(False)
+        ctx.beta = float(beta)
+        b, d, h, w = x_map.shape
+        ctx.map_shape, ctx.map_dtype = (b, d, h, w), x_map.dtype
+        z_map, mse = ops.gather_ste_map(x_rows, weight, idx, b, h, w, beta=beta)
+        ctx.save_for_backward(x_rows, weight, idx)
+        return z_map, mse[0], mse[1], mse[2]
+
+    @staticmethod
+    def backward(ctx, g_map, g_cb, g_cm, g_comb):
+        x_rows, weight, idx = ctx.saved_tensors
+        b, d, h, w = ctx.map_shape
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        g_tok = None
+        if g_map is not None:                                    # 'b c h w -> (b h w) c' of the incoming gradient
+            g_tok = ops.transpose_last2(g_map.float().contiguous().reshape(b, d, h * w)).reshape(b * h * w, d)
+        gx, gw = ops.vq_backward(x_rows, weight, idx, g_tok, g_cb, g_cm, need_x, need_w, g_comb=g_comb, beta=ctx.beta)
+        if gx is not None:
+            gx = ops.transpose_last2(gx.reshape(b, h * w, d)).reshape(b, d, h, w).to(ctx.map_dtype)
+        return gx, None, gw, None, None
+
+
+def fused_map_decode_loss(x_map: torch.Tensor, x_rows: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, beta: float = 0.0):
+    """Returns (z_map [B, D, H, W], m_cb, m_cm, m_cb + beta*m_cm)."""
+    return _FusedMapDecodeLoss.apply(x_map, x_rows, weight, idx, beta)

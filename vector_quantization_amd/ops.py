@@ -183,6 +183,61 @@ def encode(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.T
 
 
 @_on_tensor_device
+def encode_map(x_map: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None, zero_hist: bool = False):
+    """``encode`` for latents given as the NCHW-contiguous feature map [B, D, H, W]: 'b c h w -> (b h w) c' is folded into
+    the call's first launch.  Returns (idx int64 [B*H*W], prepared codebook, xrows [B*H*W, D], xq) — xrows = the
+    token-major copy of the latents in x's dtype, xq = the normalised fp32 rows (cosine; None for L2)."""
+    _require_cuda(x_map, e)
+    if x_map.dim() != 4 or not x_map.is_contiguous() or x_map.dtype not in (torch.float32, torch.bfloat16) or x_map.data_ptr() % 16:
+        raise ValueError('encode_map expects a contiguous fp32 / bf16 [B, D, H, W] map')
+    e = _codebook(e)
+    B, D, H, W = x_map.shape
+    K = e.shape[0]
+    if D != e.shape[1]:
+        raise ValueError(f'latent dim {D} != codebook dim {e.shape[1]}')
+    m = METRICS[metric]
+    L = _lib.lib()
+    N = B * H * W
+    dt = _lib.DTYPE_F32 if x_map.dtype == torch.float32 else _lib.DTYPE_BF16
+    image = _bytes(L.vqhip_codebook_bytes(K, D), e.device)
+    idx = torch.empty(N, dtype=torch.int64, device=x_map.device)
+    cos = m in (METRIC_COS, METRIC_COS_BF16)
+    xrows = torch.empty(N, D, dtype=x_map.dtype, device=x_map.device)
+    xq = torch.empty(N, D, dtype=torch.float32, device=x_map.device) if cos else None
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), x_map.device)
+    if hist is not None:
+        assert hist.dtype == torch.int32 and hist.numel() == K and hist.is_contiguous()
+    check(L.vqhip_encode_map(_ptr(x_map), dt, _ptr(e), B, H * W, K, D, m, _ptr(image), image.numel(), _ptr(idx), _ptr(hist),
+                             _ptr(xrows), _ptr(xq), _ptr(ws), ws.numel(), 1 if (zero_hist and hist is not None) else 0, _stream()),
+          'vqhip_encode_map')
+    return idx, PreparedCodebook(image, e, K, D, m), xrows, xq
+
+
+@_on_tensor_device
+def gather_ste_map(x_rows: Optional[torch.Tensor], e: torch.Tensor, idx: torch.Tensor, B: int, H: int, W: int, beta: float = 0.0):
+    """(out_map fp32 [B, D, H, W] NCHW-contiguous, mse fp32[4] or None): the straight-through output x + (e[idx] - x) — or,
+    with ``x_rows`` None, the decoded rows e[idx] — written directly as the feature map ('(b h w) c -> b c h w' folded in)."""
+    _require_cuda(e, idx)
+    e = _codebook(e)
+    D = e.shape[1]
+    idx = idx.reshape(-1).contiguous()
+    N = B * H * W
+    assert idx.dtype == torch.int64 and idx.numel() == N and N > 0
+    out = torch.empty(B, D, H, W, dtype=torch.float32, device=e.device)
+    mse = None
+    dt = _lib.DTYPE_F32
+    scratch = None
+    if x_rows is not None:
+        x_rows, dt = _latents(x_rows)
+        assert tuple(x_rows.shape) == (N, D)
+        mse = torch.empty(4, dtype=torch.float32, device=e.device)
+        scratch = _mse_scratch(e.device)
+    check(_lib.lib().vqhip_gather_ste_map(_ptr(x_rows), dt, _ptr(e), _ptr(idx), B, H * W, D, _ptr(out), _ptr(mse), float(beta),
+                                          _ptr(scratch), _stream()), 'vqhip_gather_ste_map')
+    return out, mse
+
+
+@_on_tensor_device
 def argmin_exact(x: torch.Tensor, e: torch.Tensor, metric='L2', hist: Optional[torch.Tensor] = None,
                  return_min: bool = False):
     """Same contract as ``argmin`` evaluated entirely with fp32 MFMA (x, e normalised by the caller for cosine)."""

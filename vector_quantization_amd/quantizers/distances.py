@@ -195,6 +195,18 @@ class BaseDistance(nn.Module, ABC):
             stash['metric'] = ops.metric_name(cb.metric)
         return quant
 
+    def encode_map(self, x_map: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
+                   stash: Optional[dict] = None, zero_hist: bool = False):
+        """``encode`` on the NCHW feature map [B, D, H, W] (ops.encode_map): returns (quant [B*H*W], x_rows [B*H*W, D]) —
+        x_rows = the token-major latents the rest of the step works on (L2: a copy in the map's dtype)."""
+        quant, cb, xrows, xq = ops.encode_map(x_map.detach(), e.detach(), self.metric, hist=hist, zero_hist=zero_hist)
+        if stash is not None:
+            stash['xq'] = xq if xq is not None else xrows
+            stash['eq'] = cb.exact_rows() if xq is not None else e.detach()
+            stash['prepared'] = cb
+            stash['metric'] = ops.metric_name(cb.metric)
+        return quant, xrows
+
     def argmin(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
                prepared: Optional[ops.PreparedCodebook] = None, stash: Optional[dict] = None) -> torch.Tensor:
         """torch.argmin(self(x, e), -1) without materialising the matrix.  ``stash['xq']`` receives the latents as the

@@ -186,6 +186,69 @@ class VectorQuantizer(BaseQuantizer):
         return z_ste, loss, memo
 
 
+    # ---- the same three entry points on the NCHW feature map (models/base.py:116-146) --------------------
+    def map_fusable(self, x: torch.Tensor) -> bool:
+        """True when ``forward_map`` / ``encode_map`` take the route without transposes: an NCHW-contiguous fp32 / bf16
+        device map, a D with a proposal image, no callback that rewrites the latents before the encode (NormalizeCallback:
+        the normalised rows are a new token-major tensor anyway), and a decode/loss tail that can be fused."""
+        from .callbacks import BaseCallback
+        if not (x.dim() == 4 and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+            return False
+        if x.shape[1] != self.embedding_dim or not ops.coarse_supported(x.shape[1]) or x.data_ptr() % 16 or self._cache_codebook:
+            return False
+        if type(self)._encode is not VectorQuantizer._encode or not hasattr(self._distance, 'encode_map'):
+            return False
+        return all(type(cb).before_encode is BaseCallback.before_encode for cb in self._callbacks.callbacks)
+
+    def encode_map(self, x_map: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:
+        """``encode`` for latents given as the feature map [B, D, H, W]: (x_rows [B*H*W, D], quant [B*H*W], memo).  The
+        'b c h w -> (b h w) c' of models/base.py:124,140 happens inside the encode's first kernel; ``x_rows`` — the token
+        matrix the callbacks and the rest of the step see — is its by-product (detached)."""
+        enc = get_memo(memo, 'encode')
+        w = self._embedding.weight.detach()
+        hist = None
+        if self.training and len(self._callbacks.callbacks) > 0:
+            hist = torch.empty(self.codebook_size, dtype=torch.int32, device=x_map.device)
+        stash = {}
+        quant, x_rows = self._distance.encode_map(x_map, w, hist=hist, stash=stash, zero_hist=True)
+        enc['distance'] = LazyDistance(self._distance, x_rows, w, xq=stash.get('xq'), eq=stash.get('eq'), metric=stash.get('metric'))
+        if hist is not None:
+            enc['hist'] = hist
+        memo['encode'] = enc
+        return x_rows, self._callbacks.after_encode(x_rows, quant, memo), memo
+
+    def forward_map(self, x_map: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:
+        """``forward`` on the feature map: (z_map [B, D, H, W] NCHW-contiguous, loss, memo) — BaseModel.quantize
+        (models/base.py:116-128) without either rearrangement kernel.  Gradients flow to ``x_map`` and the codebook."""
+        assert self.map_fusable(x_map) and self._fusable()
+        x_rows, quant, memo = self.encode_map(x_map, memo)
+        memo.update(x=x_rows, quant=quant)
+        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
+        z_map, m_cb, m_cm, m_vqgan = VF.fused_map_decode_loss(x_map, x_rows, self._embedding.weight, quant, betas[0] if betas else 0.0)
+        memo['decode'] = get_memo(memo, 'decode')
+        losses = {}
+        for name, loss in self._losses.items():
+            if isinstance(loss, VQGANLoss):
+                losses[name] = m_vqgan if loss.beta == betas[0] else torch.add(m_cb, m_cm, alpha=loss.beta)
+            elif isinstance(loss, CodebookLoss):
+                losses[name] = m_cb
+            else:
+                losses[name] = m_cm
+        loss_memo = get_memo(memo, 'loss')
+        loss_memo.update(losses)
+        memo['loss'] = loss_memo
+        values = list(losses.values())
+        loss = values[0] if len(values) == 1 else sum(values, x_map.new_zeros([], dtype=torch.float32))
+        return z_map, loss, memo
+
+    def decode_map(self, quant: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, Memo]:
+        """``decode`` of an image-shaped index tensor [B, H, W] straight into the map [B, D, H, W] (decode_from_quant,
+        image_reconstruction/models.py:97-106); no gradient (the reference decodes tokens under no_grad there)."""
+        b, h, w = quant.shape
+        z_map, _ = ops.gather_ste_map(None, self._embedding.weight.detach(), quant.reshape(-1), b, h, w)
+        return z_map, memo
+
+
 @VQITQuantizerRegistry.register_()
 class VQGANQuantizer(VectorQuantizer):
 

@@ -76,6 +76,14 @@ def to_map(z: torch.Tensor, b: int, h: int, w: int, token_major: bool = False) -
     return _ToMap.apply(z, b, h, w)
 
 
+def _map_route(quantizer, x: torch.Tensor, decode: bool) -> bool:
+    """An NCHW-contiguous map can be handed to the quantizer as it is (no transpose kernels either side) when the quantizer
+    has the map entry points and nothing in its configuration needs the token matrix earlier (``map_fusable``)."""
+    if not hasattr(quantizer, 'map_fusable') or not quantizer.map_fusable(x):
+        return False
+    return quantizer._fusable() if decode else True
+
+
 def quantize(quantizer, x: torch.Tensor, memo: dict):
     """BaseModel.quantize (models/base.py:116-128): returns (z [B,C,H,W], q_loss, memo)."""
     from .quantizers.memo import get_memo
@@ -83,6 +91,10 @@ def quantize(quantizer, x: torch.Tensor, memo: dict):
     quantizer_memo = get_memo(memo, 'quantizer')
     quantizer_memo['x_shape'] = x.shape
     token_major = is_token_major(x)
+    if not token_major and _map_route(quantizer, x, decode=True):
+        # NCHW map: both rearrangements of models/base.py:124-127 are folded into the quantizer's own kernels
+        z, q_loss, memo['quantizer'] = quantizer.forward_map(x, quantizer_memo)
+        return z, q_loss, memo
     z, q_loss, memo['quantizer'] = quantizer(to_tokens(x), quantizer_memo)
     return to_map(z, b, h, w, token_major), q_loss, memo
 
@@ -93,7 +105,10 @@ def encode_to_quant(quantizer, x: torch.Tensor, memo: dict):
     b, _, h, w = x.shape
     quantizer_memo = get_memo(memo, 'quantizer')
     quantizer_memo['x_shape'] = x.shape
-    xt, quant, quantizer_memo = quantizer.encode(to_tokens(x), quantizer_memo)
+    if not is_token_major(x) and _map_route(quantizer, x, decode=False):
+        xt, quant, quantizer_memo = quantizer.encode_map(x, quantizer_memo)
+    else:
+        xt, quant, quantizer_memo = quantizer.encode(to_tokens(x), quantizer_memo)
     quantizer_memo.update(x=xt, quant=quant)
     memo['quantizer'] = quantizer_memo
     return quant.reshape(b, h, w), memo
@@ -104,6 +119,9 @@ def decode_from_quant(quantizer, quant: torch.Tensor, memo: dict, token_major: b
     z [B,C,H,W] (``token_major=True``: as a zero-copy channels-last view of the gathered rows)."""
     from .quantizers.memo import get_memo
     b, h, w = quant.shape
+    if (not token_major and hasattr(quantizer, 'decode_map') and quant.is_cuda and not torch.is_grad_enabled()
+            and not quantizer._callbacks.overrides_decode_or_loss()):
+        return quantizer.decode_map(quant, get_memo(memo, 'quantizer'))[0], memo     # rows gathered straight into the NCHW map
     z, memo['quantizer'] = quantizer.decode(quant.reshape(-1), get_memo(memo, 'quantizer'))
     return to_map(z, b, h, w, token_major), memo
 
