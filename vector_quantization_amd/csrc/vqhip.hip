@@ -340,6 +340,19 @@ static int run_segsum(const void *src, int x_dtype, const float *e, const int64_
     return VQHIP_OK;
 }
 
+// |v|^2 / F.normalize for rows of at most 32 elements: 64 / L rows per wave (row_small_kernel)
+template <bool NORMALIZE>
+static int launch_row_small(const void *v, int dtype, int64_t R, int D, float eps, float *out, hipStream_t s) {
+    const int L = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    const int grid = waves_grid((R + 64 / L - 1) / (64 / L), 4);
+#define VQ_ROW_SMALL(DT, LL) row_small_kernel<DT, LL, NORMALIZE><<<grid, 256, 0, s>>>(v, R, D, eps, out)
+    if (dtype == VQHIP_DTYPE_F32) { if (L == 8) VQ_ROW_SMALL(0, 8); else if (L == 16) VQ_ROW_SMALL(0, 16); else VQ_ROW_SMALL(0, 32); }
+    else { if (L == 8) VQ_ROW_SMALL(1, 8); else if (L == 16) VQ_ROW_SMALL(1, 16); else VQ_ROW_SMALL(1, 32); }
+#undef VQ_ROW_SMALL
+    VQ_CHECK_LAUNCH("row_small_kernel");
+    return VQHIP_OK;
+}
+
 extern "C" {
 
 int vqhip_version(void) { return VQHIP_VERSION; }
@@ -364,6 +377,7 @@ int vqhip_row_sqnorm(const void *v, int dtype, int64_t R, int D, float *out, voi
     if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: bad argument");
     if (R == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (D <= 32 && (dtype == VQHIP_DTYPE_F32 || dtype == VQHIP_DTYPE_BF16)) return launch_row_small<false>(v, dtype, R, D, 0.0f, out, s);
     if (dtype == VQHIP_DTYPE_F32) row_sqnorm_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
     else if (dtype == VQHIP_DTYPE_BF16) row_sqnorm_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, out);
     else return fail(VQHIP_EINVAL, "vqhip_row_sqnorm: dtype");
@@ -375,6 +389,7 @@ int vqhip_normalize_rows(const void *v, int dtype, int64_t R, int D, float eps, 
     if (!v || !out || D <= 0 || R < 0) return fail(VQHIP_EINVAL, "vqhip_normalize_rows: bad argument");
     if (R == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (D <= 32 && (dtype == VQHIP_DTYPE_F32 || dtype == VQHIP_DTYPE_BF16)) return launch_row_small<true>(v, dtype, R, D, eps, out, s);
     if (dtype == VQHIP_DTYPE_F32) normalize_rows_kernel<0><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
     else if (dtype == VQHIP_DTYPE_BF16) normalize_rows_kernel<1><<<waves_grid(R, 4), 256, 0, s>>>(v, R, D, eps, out);
     else return fail(VQHIP_EINVAL, "vqhip_normalize_rows: dtype");

@@ -256,6 +256,29 @@ __global__ void normalize_rows_kernel(const void *v, int64_t R, int D, float eps
     for (int d = lane; d < D; d += 64) out[r * D + d] = load_elem<DT>(v, r * D + d) / den;
 }
 
+// D <= 32 (the LlamaGen tokenizer normalises 8-dim latents, VQ-KD 32-dim ones): a whole wave per row leaves 7/8 of the lanes
+// idle and launches one wave per token (81 us for 524 288 x 8 where the data is 25 MB).  L lanes per row, 64 / L rows per
+// wave; the halving tree runs inside the L-lane group — the very additions of the full-wave tree, whose upper levels only add
+// the zeros of the idle lanes — so the results are bit-identical to the kernels above.
+template <int DT, int L, bool NORMALIZE>
+__global__ void row_small_kernel(const void *v, int64_t R, int D, float eps, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * (64 / L) + lane / L;
+    const int d = lane % L;
+    const bool live = r < R && d < D;
+    const float a = live ? load_elem<DT>(v, r * D + d) : 0.0f;
+    float p = fmaf(a, a, 0.0f);
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    if constexpr (NORMALIZE) {
+        const float nrm = sqrtf(p);
+        const float den = (nrm < eps) ? eps : nrm;
+        if (live) out[r * D + d] = a / den;
+    } else {
+        if (r < R && d == 0) out[r] = p;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // codebook preparation
 // ------------------------------------------------------------------------------------------------
