@@ -1510,9 +1510,19 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
                 }
                 uint32_t hits = 0;      // bit 8t + e
 #pragma unroll
-                for (int t = 0; t < TT; ++t)
+                for (int t = 0; t < TT; ++t) {
+                    // the lane's 8 scores of this (token tile, code tile): one maximum and one compare first — a queued row
+                    // has a handful of scores above its threshold in the whole codebook, so nearly every tile ends here
+                    // (med3(a, b, +inf) = max(a, b), visible to the compiler: MFMA-result hazards are its to pad)
+                    float m = __builtin_amdgcn_fmed3f(acc[0][t][0], acc[0][t][1], INFINITY);
+                    m = __builtin_amdgcn_fmed3f(m, acc[0][t][2], INFINITY); m = __builtin_amdgcn_fmed3f(m, acc[0][t][3], INFINITY);
+                    m = __builtin_amdgcn_fmed3f(m, acc[1][t][0], INFINITY); m = __builtin_amdgcn_fmed3f(m, acc[1][t][1], INFINITY);
+                    m = __builtin_amdgcn_fmed3f(m, acc[1][t][2], INFINITY); m = __builtin_amdgcn_fmed3f(m, acc[1][t][3], INFINITY);
+                    if (__any(m >= mythr[t] || m != m)) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+                        for (int e = 0; e < 8; ++e) hits |= (acc[e >> 2][t][e & 3] >= mythr[t]) ? (1u << (8 * t + e)) : 0u;
+                    }
+                }
                 while (hits) {
                     const int b = __ffs((int)hits) - 1;
                     hits &= hits - 1;
