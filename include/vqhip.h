@@ -325,9 +325,9 @@ int vqhip_profile_enable(int on);
 /* Knobs for A/B measurements (results never change): key 2 = number of codebook slices (1,2,4,8,16; 0 = automatic);
  * key 3 = workgroup cap of the gather kernel (0 = automatic); key 4 = its streaming mode (1 on, 2 off, 0 = automatic:
  * on when the outputs exceed 192 MiB); key 5 = filtered epilogue of the D <= 128 proposal kernels (default 1); key 6 = decision
- * stage inside the proposal kernel (0 never, 1 always, 2 = where one slice covers the codebook: default); key 7 = stream-K form at D <= 32 (0); key 8 = no aux reads for cosine / dot
- * codebooks at D <= 32 (1); key 9 = group records with replay identification at D <= 32 (1); key 10 = balanced tiles per
- * workgroup (1).  Keys 0 and 1 are retired no-ops. */
+ * stage inside the proposal kernel (0 never, 1 always, 2 = where one slice covers the codebook: default); key 8 = no aux reads
+ * for cosine / dot codebooks at D <= 32 (1); key 9 = group records with replay identification at D <= 32 (1); key 10 = balanced
+ * tiles per workgroup (1).  Any other key: VQHIP_EINVAL. */
 int vqhip_set_tuning(int key, int value);
 int vqhip_profile_collect(double *ms_sum, int64_t *launches);
 

@@ -105,18 +105,17 @@ static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool STREAMK = false, bool NOAUX = false,
-          bool GROUPS = false>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false, bool GROUPS = false>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
-                             const VqDecideOut &dec, int streamk_grid, int pad_stage, int tpb, hipStream_t s) {
+                             const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, STREAMK, NOAUX, GROUPS>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, NOAUX, GROUPS>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     const int64_t ntiles = (N + 15) / 16;
     const int64_t ntb = (ntiles + tpb - 1) / tpb;
-    const int grid = STREAMK ? streamk_grid : (int)(ntb * nslices);
+    const int grid = (int)(ntb * nslices);
     const long slot = prof_begin(s);
     kern<<<grid, WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec, pad_stage, tpb);
     prof_end(slot, s);
@@ -135,37 +134,6 @@ static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages
     VQ_CHECK_LAUNCH("rescan_kernel");
     return VQHIP_OK;
 }
-
-// filtered (small-D) proposal kernels: long code streams make the skip test effective, so one slice is allowed
-// Stream-K split of the (token block x stage) space over `grid` workgroups (coarse_kernel, streamk form): the largest
-// number of workgroups that touch one token block = record slots the decision stage must read.
-static int streamk_pieces(int64_t ntb, int64_t nstages, int64_t grid) {
-    const int64_t U = ntb * nstages;
-    int64_t worst = 1, g = 0;
-    for (int64_t tb = 0; tb < ntb; ++tb) {
-        while (g + 1 < grid && ((g + 1) * U) / grid <= tb * nstages) ++g;            // first workgroup of the block
-        int64_t gl = g;
-        while (gl + 1 < grid && ((gl + 1) * U) / grid <= tb * nstages + nstages - 1) ++gl;   // last one
-        worst = (gl - g + 1) > worst ? (gl - g + 1) : worst;
-    }
-    return (int)worst;
-}
-// grid for the stream-K form: two workgroups per CU (measured at D = 32, K = 8192: 1.14 ns/token with one workgroup per
-// CU, 0.87 with two, profiles/r02_balance_d32.txt), fewer when a token block would be cut into more than 16 pieces
-static int streamk_grid(int64_t ntb, int64_t nstages, int *pieces_out) {
-    int64_t grid = 512;
-    const int64_t U = ntb * nstages;
-    if (grid > U) grid = U;
-    int pieces = streamk_pieces(ntb, nstages, grid);
-    while (pieces > VQ_MAX_SLICES && grid > 1) { grid = grid * 3 / 4; pieces = streamk_pieces(ntb, nstages, grid); }
-    *pieces_out = pieces;
-    return (int)grid;
-}
-// key 7: 1 = stream-K form on the D <= 32 kernels.  Built to cure the 392-workgroups-on-256-CUs tail of BASELINE
-// configs[2]; measured slower there (-4.6 %) and at small N (-14 %), +2.5 % only at N = 65 536
-// (profiles/r02_ab_streamk.txt): every segment pays a prologue, a ring refill and — the larger part — a cold skip
-// threshold, and a block cut in three needs three records per token.  Off; results are identical either way.
-static std::atomic<int> g_tune_streamk{0};
 
 #ifndef VQ_NBUF_D32
 #define VQ_NBUF_D32 4          // LDS ring depth of the D <= 32 proposal kernels (2 and 3 measured: profiles/r02_smallD_ring.txt)
@@ -242,31 +210,19 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         VqDecideOut dsel = dec;                                                                     \
         if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;                            \
         *fused_decide_out = dsel.idx != nullptr ? 1 : 0;                                            \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, 0, pad_stage, tpb, s); \
-    }
-    // stream-K form (D <= 32): equal shares of the (token block x stage) space, two workgroups per CU
-#define VQ_CFG_SK(NS, TT, W, ...)                                                                   \
-    {                                                                                               \
-        int64_t ntb = (N + (W) * (TT) * 16 - 1) / ((W) * (TT) * 16);                                \
-        int pieces = 1;                                                                             \
-        const int grid = streamk_grid(ntb, L.nstages, &pieces);                                     \
-        *nslices_out = pieces;                                                                      \
-        VqDecideOut nodec = dec; nodec.idx = nullptr;                                               \
-        *fused_decide_out = 0;                                                                      \
-        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, pieces, rec, Np, cbst, xh2, rho2, L.Dp, metric, nodec, grid, pad_stage, (W) * (TT), s); \
+        return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s); \
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
         case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }
                 // (N >= 262 144: at least 1024 workgroups of 64 tokens per wave — balance no longer matters and that form is the faster one)
-                if (g_tune_streamk.load() && small32) VQ_CFG_SK(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32, true, true)
                 // group records from VQ_GROUPS_MIN_N tokens on: below, the identification replay at the end of a
                 // workgroup (a few L2 round trips) costs more than the stream saves
                 if (N >= VQ_GROUPS_MIN_N && g_tune_groups.load()) {
-                    if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, true, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, true, true) }
-                    if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, false, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, false, true)
+                    if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, true, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, true, true) }
+                    if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, true)
                 }
-                if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, false, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, false, true) }
+                if (noaux) { if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true, true) }
                 if (small32) VQ_CFG(2, VQ_D32_SMALL_TT, VQ_D32_SMALL_W, VQ_TPS_D32, VQ_NBUF_D32, true) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32, true)
         case 4: if (!g_tune_filter.load()) { if (small) VQ_CFG(4, 2, 8, 4, 4) else VQ_CFG(4, 4, 8, 4, 4) }
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
@@ -289,7 +245,6 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         default: break;
     }
 #undef VQ_CFG
-#undef VQ_CFG_SK
     return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
 }
 
@@ -1155,11 +1110,9 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 4) g_tune_gather_nt = (value == 1 || value == 2) ? value : 0;
     else if (key == 5) g_tune_filter = value != 0;
     else if (key == 6) g_tune_fused_decide = (value >= 0 && value <= 2) ? value : 0;
-    else if (key == 7) g_tune_streamk = value != 0;
     else if (key == 8) g_tune_noaux = value != 0;
     else if (key == 9) g_tune_groups = value != 0;
     else if (key == 10) g_tune_balance = value != 0;
-    else if (key == 0 || key == 1) return VQHIP_OK;      // retired knobs (epilogue pipelining, wave priority): no-ops
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;
 }

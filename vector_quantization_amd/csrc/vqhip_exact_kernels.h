@@ -1,0 +1,343 @@
+// libvqhip device kernels, unit 5 of 8: the all-fp32 MFMA pass over whole batches (argmin_exact, col_argmin fallback, distance).
+// Included by vqhip_kernels.h.
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// exact fp32 MFMA pass (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain)
+// ------------------------------------------------------------------------------------------------
+// MODE 0: row argmin via 64-bit atomicMin keys[row]; MODE 1: column argmin keys[code]; MODE 2: store d[N,K]
+// Work item = (tile of 32 rows, chunk of 4*CT*32 codes); persistent grid-stride loop over items.
+template <int DT, int MODE, int CT>
+__global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                    const float *__restrict__ en_in,
+                                                    const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
+                                                    int metric, const int *__restrict__ row_list,
+                                                    const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
+                                                    float *__restrict__ dout, int *__restrict__ ticket = nullptr,
+                                                    int64_t *__restrict__ fin_idx = nullptr,
+                                                    int32_t *__restrict__ fin_hist = nullptr) {
+    // CT = code tiles (32 codes) per wave: 4 for whole-batch passes, 1 when only a few flagged rows need the
+    // whole codebook (more, smaller work items)
+    // ticket != nullptr (row-list form): the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows
+    // itself, so the last-resort path is ONE launch; with an empty list every workgroup returns at once.
+    constexpr int DB = 256;                     // dims per register block
+    constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    const int64_t ntiles = (nrows + 31) / 32;
+    const int64_t nchunks = (K + CHUNK - 1) / CHUNK;
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < ntiles * nchunks; item += gridDim.x) {
+        const int64_t tile = item / nchunks, chunk = item % nchunks;
+        const int64_t slot = tile * 32 + j;
+        const bool rvalid = slot < nrows;
+        const int64_t row = rvalid ? (row_list ? (int64_t)row_list[slot] : slot) : 0;
+        const int64_t kbase = chunk * CHUNK + (int64_t)wave * CT * 32;
+
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        // oracle-order |x|^2: precomputed for whole-batch passes, computed per lane on the (rare) last-resort path
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {      // 4 consecutive dims per load
+                int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (rvalid && d < D) {
+                    if (DT == 0) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)((const float *)x + row * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            v0 = load_elem<DT>(x, row * D + d);
+                            if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                            if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                            if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                        }
+                    } else if (d + 3 < D && (D % 4) == 0) {
+                        uint2 t = *(const uint2 *)((const uint16_t *)x + row * D + d);
+                        v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                        v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
+                    } else {
+                        v0 = load_elem<DT>(x, row * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int64_t k = kbase + c * 32 + j;         // this lane's A row (code)
+                const bool kvalid = k < K;
+                const float *erow = e + (kvalid ? k : 0) * D;
+#pragma unroll
+                for (int s4 = 0; s4 < DB / 4; ++s4) {
+                    int d = db + 4 * s4;
+                    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                    if (d < D) {
+                        if (d + 3 < D && (D % 4) == 0) {
+                            float4 t = *(const float4 *)(erow + d);
+                            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
+                        } else {
+                            a0 = erow[d];
+                            if (d + 1 < D) a1 = erow[d + 1];
+                            if (d + 2 < D) a2 = erow[d + 2];
+                            if (d + 3 < D) a3 = erow[d + 3];
+                        }
+                        if (!kvalid) { a0 = a1 = a2 = a3 = 0.0f; }
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1 : a0, xfr[2 * s4], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a3 : a2, xfr[2 * s4 + 1], acc[c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // epilogue: C[code row][token col j]
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (VQ_IS_L2(metric)) {
+                    const float enk = (k < K) ? en_in[k] : 0.0f;
+                    float t = VQ_SWAPPED(metric) ? (acc[c][q] + enk) + xn : (acc[c][q] + xn) + enk;
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = cos_distance(acc[c][q], metric);
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    // column argmin: reduce over the 32 token lanes of this half, one atomic per code
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+    if (MODE == 0 && ticket != nullptr && nrows > 0) {
+        // arrival counter (MI355X guide, Guideline 16): the key atomics execute at the memory side; every wave drains
+        // its own, the workgroup meets, one lane publishes; whoever draws the last ticket reads the keys with loads that
+        // bypass its L1 (agent-scope relaxed atomic loads)
+        __shared__ int is_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (is_last) {
+            for (int64_t i = threadIdx.x; i < nrows; i += blockDim.x) {
+                const int64_t r = (int64_t)row_list[i];
+                const u64 key = __hip_atomic_load(&keys[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
+                fin_idx[r] = (int64_t)k;
+                if (fin_hist) atomicAdd(&fin_hist[k], 1);
+            }
+        }
+    }
+}
+
+// Whole-batch fp32 pass (argmin_exact, col_argmin, distance): a workgroup = 4 waves x 32 rows against a chunk of CT code
+// tiles.  Code tiles are staged through LDS once per workgroup (coalesced float4 loads, register prefetch of the next
+// tile, 16-byte XOR swizzle -> conflict-free ds_read_b128) and shared by the 4 waves; accumulators of all CT tiles stay
+// live so that the row fragments are loaded once per 256-dim block.  Same k-ordered fma chains as exact_kernel.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                          const float *__restrict__ en_in, const float *__restrict__ xn_in,
+                                                          int64_t N, int64_t K, int D, int metric, u64 *__restrict__ keys,
+                                                          float *__restrict__ dout) {
+    constexpr int CT = 8;                        // code tiles (32 codes) per work item
+    constexpr int DB = 128;                      // dims per register / LDS block
+    constexpr int NPRE = 32 * (DB / 4) / 256;    // 16-byte chunks of a tile per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float4 *tile = (float4 *)lds;                // [2][32 rows][DB/4 chunks], chunk index XOR (row & 15)
+    constexpr int CPR = DB / 4;                  // chunks per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t nrb = (N + 127) / 128;
+    const int64_t nchunks = (K + CT * 32 - 1) / (CT * 32);
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+
+    for (int64_t item = blockIdx.x; item < nrb * nchunks; item += gridDim.x) {
+        const int64_t rb = item / nchunks, chunk = item % nchunks;
+        const int64_t row = rb * 128 + wave * 32 + j;
+        const bool rvalid = row < N;
+        const int64_t rrow = rvalid ? row : N - 1;
+        const int64_t kbase = chunk * CT * 32;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
+
+        for (int db = 0; db < D; db += DB) {
+            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
+            float xfr[DB / 2];
+#pragma unroll
+            for (int s4 = 0; s4 < DB / 4; ++s4) {
+                const int d = db + 4 * s4;
+                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (d < D) {
+                    if (d + 3 < D && (D % 4) == 0) {
+                        if (DT == 0) {
+                            float4 t = *(const float4 *)((const float *)x + rrow * D + d);
+                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                        } else {
+                            uint2 t = *(const uint2 *)((const uint16_t *)x + rrow * D + d);
+                            v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
+                            v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
+                        }
+                    } else {
+                        v0 = load_elem<DT>(x, rrow * D + d);
+                        if (d + 1 < D) v1 = load_elem<DT>(x, rrow * D + d + 1);
+                        if (d + 2 < D) v2 = load_elem<DT>(x, rrow * D + d + 2);
+                        if (d + 3 < D) v3 = load_elem<DT>(x, rrow * D + d + 3);
+                    }
+                }
+                xfr[2 * s4] = sx * (h ? v1 : v0);
+                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+            }
+            // staging: thread t owns the 16-byte chunks t, t+256, ... of the 32 x DB tile
+            float4 pre[NPRE];
+            auto fetch = [&](int ct) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    const int64_t k = kbase + ct * 32 + r;
+                    const int d = db + 4 * ch;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < K && d < D) {
+                        if (d + 3 < D && (D % 4) == 0) v = *(const float4 *)(e + k * D + d);
+                        else {
+                            v.x = e[k * D + d];
+                            if (d + 1 < D) v.y = e[k * D + d + 1];
+                            if (d + 2 < D) v.z = e[k * D + d + 2];
+                            if (d + 3 < D) v.w = e[k * D + d + 3];
+                        }
+                    }
+                    pre[i] = v;
+                }
+            };
+            auto stash = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int c = threadIdx.x + 256 * i;
+                    const int r = c / CPR, ch = c % CPR;
+                    tile[(buf * 32 + r) * CPR + (ch ^ (r & 15))] = pre[i];
+                }
+            };
+            __syncthreads();            // previous block / item is done with both buffers
+            fetch(0);
+            stash(0);
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct + 1 < CT) fetch(ct + 1);
+                const float4 *trow = tile + ((ct & 1) * 32 + j) * (DB / 4);
+#pragma unroll
+                for (int q = 0; q < DB / 4; ++q) {
+                    if (db + 4 * q < D) {
+                        const float4 v = trow[q ^ (j & 15)];
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.y : v.x, xfr[2 * q], acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
+                    }
+                }
+                if (ct + 1 < CT) stash((ct + 1) & 1);
+                __syncthreads();
+            }
+        }
+
+        const float xn = (VQ_IS_L2(metric) && rvalid) ? xn_in[row] : 0.0f;
+        u64 best = ~0ull;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                float d;
+                if (VQ_IS_L2(metric)) {
+                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = cos_distance(acc[c][q], metric);
+                }
+                if (MODE == 0) {
+                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o = __shfl_xor(key, off, 64);
+                        key = o < key ? o : key;
+                    }
+                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
+                } else {
+                    if (rvalid && k < K) dout[row * K + k] = d;
+                }
+            }
+        }
+        if (MODE == 0) {
+            u64 o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+        }
+    }
+}
+
+// decode keys -> idx (+hist, +dmin).  rows = flagged list (device count) or all N
+__global__ void finalize_kernel(const u64 *keys, const int *row_list, const int *nrows_dev, int64_t N, int64_t *idx,
+                                float *dmin, int32_t *hist) {
+    const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row = row_list ? (int64_t)row_list[i] : i;
+        u64 key = keys[row];
+        uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
+        idx[row] = (int64_t)k;
+        if (hist) atomicAdd(&hist[k], 1);
+        if (dmin) {
+            u64 hi = key >> 32;
+            float d;
+            if (hi == 0) d = __uint_as_float(0x7FC00000u);
+            else {
+                uint32_t b = (uint32_t)(hi - 1ull);
+                b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b;
+                d = __uint_as_float(b);
+            }
+            dmin[row] = d;
+        }
+    }
+}
+
+__global__ void fill_u64_kernel(u64 *p, int64_t n, u64 v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}

@@ -1,0 +1,442 @@
+// libvqhip device kernels, unit 3 of 8: the fp16-MFMA proposal pass (coarse_kernel) with its record merge and, optionally,
+// the decision stage.  Included by vqhip_kernels.h.
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// fp16 MFMA proposal pass
+// ------------------------------------------------------------------------------------------------
+struct Top2 { float v1, v2, v3; uint32_t c1, c2; };
+__device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int metric, float X2, float R2, float *bf16_part = nullptr);
+
+// where the decision stage writes (one struct: the proposal kernel carries it as a single argument)
+struct VqDecideOut {
+    int64_t *idx; int32_t *hist;
+    int *rescan_list, *multi_list, *exact_list, *counters;
+    u64 *keys; float *thr_out; int *rescan_cnt;
+    int *arrive;            // one arrival counter per token block of the proposal kernel (zeroed by x_prep_kernel)
+    const int *n_dev;       // nullable DEVICE row count: only rows [0, min(N, *n_dev)) are live (vqhip_col_argmin_rows:
+                            // the launch is sized for a capacity, the actual number of listed codes stays on the device)
+};
+template <bool AGENT>
+__device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
+                                            const float *rec, const float *xh2, const float *rho2, int64_t Np,
+                                            const VqDecideOut &o, int *wcount, int *wbase);
+
+__device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
+    if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }
+    else if (v > t.v2) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = v; t.c2 = c; }
+    else t.v3 = fmaxf(t.v3, v);
+}
+
+__device__ __forceinline__ void top_merge_lane(Top2 &t, int xor_mask) {   // fold the partner lane's record into t
+    Top2 o;
+    o.v1 = __shfl_xor(t.v1, xor_mask, 64); o.v2 = __shfl_xor(t.v2, xor_mask, 64); o.v3 = __shfl_xor(t.v3, xor_mask, 64);
+    o.c1 = __shfl_xor(t.c1, xor_mask, 64); o.c2 = __shfl_xor(t.c2, xor_mask, 64);
+    if (o.c1 != 0xFFFFFFFFu) top_insert(t, o.v1, o.c1);
+    if (o.c2 != 0xFFFFFFFFu) top_insert(t, o.v2, o.c2);
+    t.v3 = fmaxf(t.v3, o.v3);
+}
+
+// code row inside a 32-code tile for accumulator element e = 4*c + reg of lane l (v_mfma_f32_16x16x32: row = 4(l>>4)+reg)
+__device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3); }
+
+// One workgroup = WAVES waves x TT token tiles of 16 tokens held in registers as MFMA B fragments for the whole kernel;
+// it streams one slice of the codebook image through an LDS ring of NBUF stages (global_load_lds; four stages filled two
+// ahead up to D = 256, a double buffer above) and
+// keeps, per lane and token, the best score with its tile / register and the runner-up value.
+// Scores are a_k = se*(xh . eh_k) - se*|e_k|^2/2 (the accumulator is initialised with the aux value).
+// MFMA shape 16x16x32 (the chip holds a higher clock on it than on 32x32x16: +8..11 % measured on this kernel).
+// The epilogue of tile t-1 (3 VALU per element) is spread over the MFMAs of tile t (two accumulator sets ping-pong).
+//
+// FILTER (small D, where 3 VALU per score against D/8 MFMA cycles per score make the kernel VALU-issue-bound): the 8
+// elements a lane holds per (token tile, code tile) first go through a 4-instruction maximum (v_max3) and ONE compare
+// against the lane's threshold; the per-element update runs only if some lane of the wave reaches its threshold
+// (wave-uniform branch).  The threshold of a token is (best score any of its four lanes has seen) - (the row's margin
+// m, the very number the decision kernel uses), refreshed once per stage.  A skipped score s satisfies
+// s < best_so_far - m <= final best - m = the decision threshold, so it is strictly outside the candidate set the
+// margin defines and needs neither identification nor a bound in the record; every score within the margin of the
+// running best still goes through the exact per-element update.  Rows without a usable margin never skip.
+//
+// NOAUX (cosine / dot product: no |e|^2 term, the aux chunk is all zeros except for the padding codes of the very last
+// stage): the accumulators start from the inline constant 0 and the two 16-byte aux reads per code tile — half of the
+// LDS read traffic at D = 32 — are issued only in `pad_stage` (-1: the codebook fills its last stage).
+//
+// GROUPS (with FILTER; D <= 32, where the per-element update of the tiles that fail the skip test was the larger half of
+// the VALU work): see "group record" in the loop and "group records -> code records" after it.
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false,
+          bool GROUPS = false>
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4) void coarse_kernel(
+    const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
+    float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
+    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
+    static_assert(!GROUPS || FILTER, "group records are a form of the filtered epilogue");
+    constexpr bool GBRANCH = TT >= VQ_GROUP_BRANCH_MIN_TT;
+    constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
+    constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
+    constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);   // chunks per stage (2 per k-step and tile, + aux)
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int NE = 8;                                // accumulator elements per lane, token tile and code tile
+#ifndef VQ_SCALAR_WAVE
+#define VQ_SCALAR_WAVE 1
+#endif
+    // the wave index as a SCALAR: the compiler cannot tell that threadIdx.x >> 6 is wave-uniform, and everything indexed by it
+    // (the LDS-DMA request loop above all) otherwise runs as a divergent loop.  Measured (profiles/r02_scalar_wave.txt):
+    // +1.2 % at D = 256 (3.129 -> 3.093 ms at 524 288 tokens), +0.5-1 % at D >= 128, but -1.5..2.5 % at D = 32
+    // (the kernel is at its SGPR limit there): D <= 32 keeps the vector form
+    const int lane = threadIdx.x & 63;
+    const int wave = (VQ_SCALAR_WAVE && NSTEP > 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+    const int64_t ntt = (N + 31) / 32 * 2;               // 16-token tiles in the fp16 token image (of the launch's capacity)
+    if (dec.n_dev != nullptr) {              // device-side row count: token blocks past it have nothing to do
+        const int64_t nd = *dec.n_dev;
+        N = nd < N ? nd : N;
+        if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
+    }
+    // Work assignment: workgroup = (token block tb, codebook slice sl of nslices).
+    // tpb: 16-token tiles per workgroup, <= WAVES*TT (the host picks it so that the workgroups fill whole rounds of the
+    // chip: launch_coarse).  Waves past it only help filling the ring; tiles past it belong to the next workgroup.
+    // (A stream-K split of the (token block x stage) space into equal shares per CU was built for the D <= 32 kernels and
+    //  measured slower, -4.6 % at configs[2], -14 % at small N: profiles/r02_ab_streamk.txt; removed.)
+    const bool wave_active = wave * TT < tpb;
+    const int sl = blockIdx.x % nslices;
+    const int64_t tb = blockIdx.x / nslices;
+    const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
+  {
+
+    // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
+    half8 xf[TT][NS32];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        int64_t tt = tb * tpb + wave * TT + t;
+        tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
+        const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
+#pragma unroll
+        for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+    }
+
+    float b1[TT], b2[TT], th[TT], mg[TT];
+    uint32_t t1[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { b1[t] = -INFINITY; b2[t] = -INFINITY; th[t] = -INFINITY; mg[t] = INFINITY; t1[t] = 0; }
+    static_assert(!FILTER || PIPE, "the filtered epilogue is written for the ping-pong form");
+    float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;     // destinations of the asm maxima: live across the whole loop (see vmax3_into)
+    if constexpr (FILTER) {
+        const VqCbStats stv = cb_stats_view(cbst);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
+            tokn = tokn < N ? tokn : N - 1;
+            const float m = row_margin(&stv, Dp, metric, xh2[tokn], rho2[tokn]);
+            mg[t] = (m > 0.0f) ? m : INFINITY;                 // no usable bound: threshold -inf, nothing is skipped
+        }
+    }
+
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+
+    // NBUF == 4: ring of four stages filled two ahead, and the second half of the waves (the SIMD partners of the
+    // first half) runs one stage behind.  Measured at D = 256 against the double-buffered form with stages twice the
+    // size: ring and look-ahead -6 %, the lag another -2 % (lagging the odd waves instead: -1 % less; three ahead
+    // without lag: +9 % slower) — MI355X guide, 'Two waves per SIMD', item 9
+    constexpr int AHEAD = NBUF >= 3 ? 2 : 1;                 // NBUF == 3 (large D): two ahead, no lag
+    const int lag = (NBUF >= 4 && wave >= WAVES / 2) ? 1 : 0;
+    if (st0 < st1) issue_stage(st0, 0);
+    if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+
+    f32x4 accA[2][TT], accB[2][TT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)   // "previous tile" of the very first tile: never wins (group records: never even registers)
+                accB[c][t][q] = GROUPS ? -INFINITY : -3.0e38f;
+
+    for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
+        if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+        const int64_t st = it - lag;
+        if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
+        const int buf = (int)((st - st0) % NBUF);
+        const char *base = lds + buf * STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+      // the tiles of one stage; WITH_AUX false: accumulators start from the constant 0 (no aux read)
+      auto run_stage = [&](auto with_aux_tag) __attribute__((always_inline)) {
+        constexpr bool WITH_AUX = decltype(with_aux_tag)::value;
+#pragma unroll
+        for (int ti = 0; ti < TPS; ++ti) {
+            f32x4 (&cur)[2][TT] = (PIPE && (ti & 1)) ? accB : accA;
+            f32x4 (&prv)[2][TT] = (PIPE && (ti & 1)) ? accA : accB;
+            // accumulator init = -se*|e|^2/2 of this lane's code rows 16c + 4(l>>4) + {0..3}
+            if constexpr (WITH_AUX) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) cur[c][t] = a4;
+                }
+            }
+            uint32_t old[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) old[t] = __float_as_uint(b1[t]);
+            // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets);
+            // chunk ch = 2*s32 + c feeds the TT MFMAs of code half c at k-step s32
+            constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);   // deeper where a chunk feeds fewer MFMAs
+            half8 af[PF + 1];
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+            for (int ch = 0; ch < NSTEP; ++ch) {
+                if (ch + PF < NSTEP)
+                    af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    if constexpr (!WITH_AUX) {
+                        if (ch < 2) {                      // first k-step of this code half: C = inline constant 0
+                            cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                            continue;
+                        }
+                    }
+                    cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                }
+                if constexpr (FILTER) {
+                    // token tile t of the previous code tile: maximum of its 8 elements, one compare, wave-uniform skip
+                    const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;
+#pragma unroll
+                    for (int i = 0; i < (TT + NSTEP - 1) / NSTEP; ++i) {
+                        constexpr int EVERY = (NSTEP / TT) > 0 ? NSTEP / TT : 1;       // TT < NSTEP: one token tile every EVERY chunks
+                        const int t = (TT >= NSTEP) ? ch * (TT / NSTEP) + i : ((ch % EVERY == 0) ? ch / EVERY : -1);
+                        if (t >= 0 && t < TT) {
+                            // (ordered behind all TT MFMAs of this chunk: >= TT MFMAs after the previous tile's last one)
+                            float after[TT];
+#pragma unroll
+                            for (int u = 0; u < TT; ++u) after[u] = cur[ch & 1][u][0];
+                            tile_max8<TT>(sc0, sc1, sc2, prv[0][t], prv[1][t], after);
+                            if constexpr (GROUPS) {
+                                // group record: the lane keeps the best GROUP maximum (its 8 codes of one code tile),
+                                // the tile it came from and the best maximum of any other group; which of the 8 codes
+                                // it was is found after the stream by replaying that one tile (below)
+                                if (!GBRANCH || __any(!(sc0 < th[t]))) {
+                                    const float nb = vmax(b1[t], sc0);
+                                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], sc0);
+                                    t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? tgp : t1[t];
+                                    b1[t] = nb;
+                                }
+                            } else if (__any(!(sc0 < th[t]))) {
+                                const uint32_t was = __float_as_uint(b1[t]);
+#pragma unroll
+                                for (int e = 0; e < NE; ++e) {
+                                    float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                                    b1[t] = vmax(b1[t], v);
+                                }
+                                t1[t] = (__float_as_uint(b1[t]) != was) ? tgp : t1[t];
+                            }
+                        }
+                    }
+                }
+                // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
+                constexpr int TOTAL = NE * TT;
+#pragma unroll
+                for (int i = 0; PIPE && !FILTER && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                    constexpr int EVERY = (NSTEP / TOTAL) > 0 ? NSTEP / TOTAL : 1;   // TOTAL < NSTEP: one element every EVERY chunks
+                    const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % EVERY == 0) ? ch / EVERY : -1);
+                    if (id >= 0 && id < TOTAL) {
+                        const int t = id / NE, e = id % NE;
+                        float v = __uint_as_float((__float_as_uint(prv[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+                    }
+                }
+            }
+            if constexpr (!PIPE) {   // large D: one tile per stage, epilogue in place (the SIMD's other wave covers it)
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float v = __uint_as_float((__float_as_uint(cur[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+                    }
+            }
+            if constexpr (!FILTER) {
+                const uint32_t tgp = (uint32_t)(st * TPS + ti) - (PIPE ? 1u : 0u);  // tile the retired elements belong to
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
+            }
+        }
+      };   // run_stage
+        if constexpr (NOAUX) {
+            if (st == (int64_t)pad_stage) run_stage(std::true_type{}); else run_stage(std::false_type{});
+        } else {
+            run_stage(std::true_type{});
+        }
+        if constexpr (FILTER && (!GROUPS || GBRANCH)) {   // refresh the skip thresholds: best score among the token's four lanes, less the margin
+#pragma unroll
+            for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
+        }
+        // next stage landed (vmcnt(0)) and everybody is done reading this one.  (A barrier that keeps the pieces of the
+        // stage requested in this iteration in flight — s_waitcnt vmcnt(pieces) instead of 0 — was measured: 1-3 %
+        // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
+        __syncthreads();
+    }
+    // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
+    if (PIPE && st1 > st0) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t old = __float_as_uint(b1[t]);
+            if constexpr (GROUPS) {
+                float g = accB[0][t][0];
+#pragma unroll
+                for (int e = 1; e < NE; ++e) g = __builtin_amdgcn_fmed3f(g, accB[e >> 2][t][e & 3], INFINITY);   // max, NaN-transparent like v_max
+                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], g);
+                b1[t] = vmax(b1[t], g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    float v = __uint_as_float((__float_as_uint(accB[e >> 2][t][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                    b1[t] = vmax(b1[t], v);
+                }
+            }
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
+    }
+
+    // ---- group records -> code records.  A lane whose best group can matter (its maximum is within the row's margin of
+    // the best any of the token's four lanes holds) replays that one code tile — same fragments, same MFMA sequence per
+    // accumulator, hence the very scores of the stream — and runs the per-element update (index bits, runner-up) on its 8
+    // elements.  Everything else the lane has seen stays a value bound: raised to the largest value the index-bit form
+    // of the same score can take (|low 4 mantissa bits| of slack, on the safe side for either sign).
+    bool ident[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) ident[t] = true;
+    if constexpr (GROUPS) {
+        auto bound_up = [](float v) {
+            const uint32_t b = __float_as_uint(v);
+            return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
+        };
+        constexpr int RB = NSTEP <= 2 ? VQ_REPLAY_BATCH : (NSTEP <= 4 ? 2 : 1);   // tiles replayed per round trip (registers)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float top = quad_rows_max(b1[t]);
+            // (rows past N are image padding: never written, not replayed; the tile range check turns anything unexpected
+            // — a score stream of NaNs, say — into "unidentified", which the decision stage answers with a second pass)
+            const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
+            const bool need = (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) && tokn < N && wave * TT + t < tpb &&
+                              t1[t] >= (uint32_t)(st0 * TPS) && t1[t] < (uint32_t)(st1 * TPS);
+            float e1 = -INFINITY, e2 = -INFINITY;
+            u64 todo = __ballot(need);
+            while (todo) {
+                uint32_t T[RB];
+                u64 rest = todo;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int l = rest ? (__ffsll((unsigned long long)rest) - 1) : (__ffsll((unsigned long long)todo) - 1);
+                    T[i] = (uint32_t)__builtin_amdgcn_readlane((int)t1[t], l);
+                    rest &= rest - 1;
+                }
+                half8 a[RB][NSTEP];
+                f32x4 acc[RB][2];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int64_t rst = T[i] / TPS;
+                    const int rti = (int)(T[i] % TPS);
+                    const char *sb = frag + rst * (int64_t)STAGE_BYTES;
+#pragma unroll
+                    for (int ch = 0; ch < NSTEP; ++ch)
+                        a[i][ch] = *(const half8 *)(sb + (rti * NSTEP + ch) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (NOAUX && rst != (int64_t)pad_stage) acc[i][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        else acc[i][c] = *(const f32x4 *)(sb + TPS * NSTEP * VQ_CHUNK_BYTES + (rti * 32 + 16 * c + 4 * (lane >> 4)) * 4);
+                    }
+                }
+                u64 done = 0;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                    for (int ch = 0; ch < NSTEP; ++ch)
+                        acc[i][ch & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][ch], xf[t][ch >> 1], acc[i][ch & 1], 0, 0, 0);
+                    float w1 = -INFINITY, w2 = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        float v = __uint_as_float((__float_as_uint(acc[i][e >> 2][e & 3]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        w2 = __builtin_amdgcn_fmed3f(w1, w2, v);
+                        w1 = vmax(w1, v);
+                    }
+                    const bool mine = need && t1[t] == T[i];
+                    e1 = mine ? w1 : e1; e2 = mine ? w2 : e2;
+                    done |= __ballot(mine);
+                }
+                todo &= ~done;
+            }
+            const float other = bound_up(b2[t]);
+            if (need) { b1[t] = e1; b2[t] = fmaxf(other, e2); }
+            else { b2[t] = fmaxf(other, bound_up(b1[t])); }
+            ident[t] = need;
+        }
+    }
+
+    // ---- merge the four lanes that share a token; lanes 0..15 write one record per (token, slice) ----
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        Top2 r; r.v1 = r.v2 = r.v3 = -INFINITY; r.c1 = r.c2 = 0xFFFFFFFFu;
+        {
+            uint32_t bits = __float_as_uint(b1[t]);
+            uint32_t code = t1[t] * 32u + (uint32_t)tile_row16((int)(bits & 7u), lane);
+            if (ident[t] && b1[t] > -INFINITY) top_insert(r, b1[t], code);
+            r.v3 = fmaxf(r.v3, b2[t]);
+        }
+        top_merge_lane(r, 16);
+        top_merge_lane(r, 32);
+        const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
+        if (lane < 16 && tokn < N && wave * TT + t < tpb) {
+            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
+            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
+            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+        }
+    }
+
+    // ---- decision stage, by the workgroup that completes a token block (dec.idx == nullptr: left to refine_decide_kernel)
+    // Arrival counter per token block (MI355X guide, Guideline 16): every wave drains its record stores, the workgroup
+    // meets, one lane releases at agent scope and takes a ticket; the workgroup that draws the last ticket of the block
+    // (nslices of them) acquires and merges the records of all slices — one launch less on the critical path.
+    if (dec.idx != nullptr) {
+        int *flags = (int *)lds;                         // the stage ring is free now (first barrier below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int last = 1;
+            if (nslices > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = (atomicAdd(&dec.arrive[tb], 1) == nslices - 1) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            flags[0] = last;
+        }
+        __syncthreads();
+        const bool last = flags[0] != 0;
+        __syncthreads();                                 // everybody has read the flag before the LDS words are reused
+        if (last) {
+            int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
+            int64_t n = tb * (int64_t)(tpb * 16) + threadIdx.x;      // tpb*16 <= BM <= WAVES*64 threads: one token per thread
+            const bool oob = (int)threadIdx.x >= tpb * 16 || n >= N;
+            if (n >= N) n = N - 1;
+            decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
+        }
+    }
+  }
+}
