@@ -474,8 +474,15 @@ def main():
         if world > 1 and not args.no_cvq:
             # the communicating workload of the path, so that a scaling run is interpretable
             extra['cvq'] = {}
+            # HIP-graph replay of a step that CONTAINS an RCCL collective has never been executed for this repo (one-GPU
+            # builder boxes): a capture that goes wrong can hang a process group, which would cost the whole scaling run.
+            # The eager step — which no longer waits for the host anywhere — is timed by default; VQ_BENCH_CVQ_GRAPHS=1 adds
+            # the graphed one.
+            cvq_graphs = os.environ.get('VQ_BENCH_CVQ_GRAPHS') == '1'
             for toks in (12 * TOK_PER_IMAGE, 256 * TOK_PER_IMAGE):
-                rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), settle=120)
+                rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), graphs=cvq_graphs, settle=120)
+                if not cvq_graphs:
+                    rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph capture of an RCCL collective is untested here)' 
                 extra['cvq'][str(toks)] = rec
         tokens_per_step_global = N * world
         scaling = 'weak'
@@ -486,7 +493,8 @@ def main():
     elif wl == 'cvq':
         images = args.images or 12
         N, K, D = images * TOK_PER_IMAGE, K_CODES, DIM
-        rec, prof = run_cvq(B, N, args.steps, args.warmup, args.min_seconds)
+        rec, prof = run_cvq(B, N, args.steps, args.warmup, args.min_seconds,
+                            graphs=(world == 1 or os.environ.get('VQ_BENCH_CVQ_GRAPHS') == '1'))
         blocks = [rec['ms_per_step'] * args.steps / 1e3]
         extra['cvq'] = rec
         loss, used_codes = rec['loss'], rec['used_codes']

@@ -327,7 +327,7 @@ int vqhip_profile_enable(int on);
  * on when the outputs exceed 192 MiB); key 5 = filtered epilogue of the D <= 128 proposal kernels (default 1); key 6 = decision
  * stage inside the proposal kernel (0 never, 1 always, 2 = where one slice covers the codebook: default); key 8 = no aux reads
  * for cosine / dot codebooks at D <= 32 (1); key 9 = group records with replay identification at D <= 32 (1); key 10 = balanced
- * tiles per workgroup (1).  Any other key: VQHIP_EINVAL. */
+ * tiles per workgroup (1); key 11 = the 32x32x16 proposal kernel at D <= 16 (1).  Any other key: VQHIP_EINVAL. */
 int vqhip_set_tuning(int key, int value);
 int vqhip_profile_collect(double *ms_sum, int64_t *launches);
 

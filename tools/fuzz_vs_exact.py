@@ -23,7 +23,7 @@ while time.time() < t_end:
     N = [ri(1, 512), ri(512, 70000), 65536, ri(70000, 300000)][ri(0, 4)]
     if N * K * D > 3e12: N = max(1, int(3e12 / (K * D)))
     metric = 'L2' if ri(0, 3) else ('Cosine' if ri(0, 3) else 'CosineBF16')     # CosineBF16: the bf16-autocast semantics (opt-in)
-    kind = ri(0, 6)
+    kind = ri(0, 7)
     scale = 10.0 ** ri(-4, 5)
     w = torch.randn(K, D, device='cuda', generator=g)
     x = torch.randn(N, D, device='cuda', generator=g)
@@ -37,6 +37,9 @@ while time.time() < t_end:
         x = x * torch.exp(2 * torch.randn(N, 1, device='cuda', generator=g)); w = w * torch.exp(torch.randn(K, 1, device='cuda', generator=g))
     elif kind == 5:  # integer grid (exact ties)
         x = torch.randint(-3, 4, (N, D), device='cuda', generator=g).float(); w = torch.randint(-3, 4, (K, D), device='cuda', generator=g).float()
+    elif kind == 6:  # unit-norm codebook (NormalizeCallback): L2 takes the constant-norm form (no bias term in the proposal scores)
+        w = torch.nn.functional.normalize(w)
+        if ri(0, 2): x = torch.nn.functional.normalize(x)
     x, w = x * scale, w * scale
     if os.environ.get('VQ_FUZZ_VERBOSE'): print(f'trial {trials + 1}: N={N} K={K} D={D} {metric} kind={kind} scale={scale}', flush=True)
     xd = x.bfloat16() if ri(0, 3) == 0 else x

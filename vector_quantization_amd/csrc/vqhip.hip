@@ -100,6 +100,7 @@ static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B meas
 // launch saves), so the stand-alone launch stays the default; results are identical either way.
 // (2 = only where ONE slice covers the codebook: the workgroup then decides its own tokens, no ticket and no fence involved)
 static std::atomic<int> g_tune_fused_decide{2};
+static std::atomic<int> g_tune_w32{1};      // key 11: 0 = D <= 16 keeps the 16x16x32 proposal kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
@@ -120,6 +121,24 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     kern<<<grid, WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec, pad_stage, tpb);
     prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse_kernel");
+    return VQHIP_OK;
+}
+
+// D <= 16: the proposal pass on v_mfma_f32_32x32x16_f16 (vqhip_proposal32_kernels.h), same images and arguments
+template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX>
+static int launch_coarse32_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
+                               int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
+                               const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
+    constexpr int LDS = NBUF * (TPS * 2 + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
+    auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX>;
+    static LdsCache lds_set;
+    if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
+    const int64_t ntiles = (N + 15) / 16;
+    const int64_t ntb = (ntiles + tpb - 1) / tpb;
+    const long slot = prof_begin(s);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec, pad_stage, tpb);
+    prof_end(slot, s);
+    VQ_CHECK_LAUNCH("coarse32_kernel");
     return VQHIP_OK;
 }
 
@@ -214,7 +233,30 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
-        case 2: if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }
+        case 2: if (L.D <= 16 && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load()) {
+                    // one 32x32x16 instruction covers the whole inner dimension: a quarter of the MFMA issue, group update per
+                    // 16 scores.  Wide token tiles of 32 tokens: 1 (below 262 144 tokens) or 2 per wave.
+#ifdef VQ_W32_TT
+                    const int tt = VQ_W32_TT;
+#else
+                    const int tt = small32 ? 1 : 2;
+#endif
+                    const int full = 8 * tt * 2;                                    // 16-token tiles per workgroup
+                    const int64_t ntb0 = (N + full * 16 - 1) / (full * 16);
+                    const int ns = pick_slices(ntb0, L.nstages, VQ_MIN_SLICES_FILTER);
+                    *nslices_out = ns;
+                    int tpb = (ns == 1) ? balanced_tiles_per_block(N, full) : full;
+                    tpb = (tpb + 1) & ~1;                                           // whole wide tiles
+                    const int fmode = g_tune_fused_decide.load();
+                    VqDecideOut dsel = dec;
+                    if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;
+                    *fused_decide_out = dsel.idx != nullptr ? 1 : 0;
+#define VQ_CFG32(TTW, NOAUXV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s)
+                    if (tt == 1) { if (noaux) VQ_CFG32(1, true); else VQ_CFG32(1, false); }
+                    else { if (noaux) VQ_CFG32(2, true); else VQ_CFG32(2, false); }
+#undef VQ_CFG32
+                }
+                if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }
                 // (N >= 262 144: at least 1024 workgroups of 64 tokens per wave — balance no longer matters and that form is the faster one)
                 // group records from VQ_GROUPS_MIN_N tokens on: below, the identification replay at the end of a
                 // workgroup (a few L2 round trips) costs more than the stream saves
@@ -1113,6 +1155,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 8) g_tune_noaux = value != 0;
     else if (key == 9) g_tune_groups = value != 0;
     else if (key == 10) g_tune_balance = value != 0;
+    else if (key == 11) g_tune_w32 = value != 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;
 }

@@ -211,6 +211,7 @@ __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
 #include "vqhip_prepare_kernels.h"
 #include "vqhip_proposal_kernels.h"
 #include "vqhip_refine_kernels.h"
+#include "vqhip_proposal32_kernels.h"
 #include "vqhip_exact_kernels.h"
 #include "vqhip_update_kernels.h"
 #include "vqhip_sort_kernels.h"

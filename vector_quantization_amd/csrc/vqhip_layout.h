@@ -54,7 +54,7 @@ VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
     L.nblk1 = (K + 15) / 16;                 // cb_stats_kernel: 16 codes per block
     L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
     // [256, 256 + 16*128): VQ_CB_SLOTS maxima slots of cb_image_kernel, one 128-byte line each (see cb_stats_view)
-    L.off_part1 = 256 + VQ_CB_SLOTS * 128;   // float4 {max|e|, max e2, max en, bad} per stats block
+    L.off_part1 = 256 + VQ_CB_SLOTS * 128;   // float4 {max|e|, max e2, L2: -(min |e|^2) / else 0, bad} per stats block
     L.off_part2 = L.off_part1 + L.nblk1 * 16;  // (unused since round 2: the image kernel raises the header maxima itself)
     L.off_en = (L.off_part2 + L.nblk2 * 16 + 255) / 256 * 256;
     L.off_eexact = (L.off_en + L.Kp * 4 + 255) / 256 * 256;
@@ -73,6 +73,10 @@ struct VqCbStats {
     uint32_t nonfinite;     // !=0: some entry is NaN/Inf (or overflows the fp16 image)
     int32_t metric;
     uint32_t finalized;     // the image kernel has run (r2max/eh2max/nonfinite are raised by it with filtered atomics)
+    uint32_t en_spread_bits;  // L2, constant-norm codebook (below): max_k |e_k|^2 - min_k |e_k|^2, else 0
+    uint32_t l2_const_norm;   // L2 and the norms agree to 2^-16 relative (a NormalizeCallback codebook): the proposal scores
+                              // carry NO -|e_k|^2/2 term (aux values of real codes are 0) and the row margin carries the
+                              // spread instead — the aux reads were a third of the D <= 16 kernel's time (vqhip_proposal32_kernels.h)
 };
 
 struct VqWsLayout {

@@ -90,7 +90,7 @@ __device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64
     for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
         for (int c = 0; c < 4; ++c) p[c] = p[c] + __shfl_xor(p[c], off, 64);
-    float m_e2 = 0.0f, m_en = 0.0f;
+    float m_e2 = 0.0f, m_en = VQ_IS_L2(metric) ? -INFINITY : 0.0f;   // L2: m_en = -(smallest |e_k|^2) (max-reduced like the rest)
     if (VQ_IS_COS(metric)) {
         amax = 0.0f;
 #pragma unroll
@@ -117,7 +117,7 @@ __device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64
             if (lane == 0) en[k0 + c] = VQ_IS_L2(metric) ? p[c] : 0.0f;     // DOT: operands are used as given, no bias
             bad |= !isfinite(p[c]);
             m_e2 = fmaxf(m_e2, p[c]);
-            if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, p[c]);
+            if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, -p[c]);
         }
     }
     amax = wave_max(amax);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     VqCbStats g_st;
     {
         const f32x4 *part = (const f32x4 *)(cb + L.off_part1);
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        float a0 = 0.0f, a1 = 0.0f, a2 = VQ_IS_L2(metric) ? -INFINITY : 0.0f, a3 = 0.0f;
         for (int64_t i = threadIdx.x; i < L.nblk1; i += 256) {
             f32x4 v = part[i];
             a0 = fmaxf(a0, v[0]); a1 = fmaxf(a1, v[1]); a2 = fmaxf(a2, v[2]); a3 = fmaxf(a3, v[3]);
@@ -158,11 +158,20 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
         a0 = wave_max(a0); a1 = wave_max(a1); a2 = wave_max(a2); a3 = wave_max(a3);
         a0 = block_max4(a0, red4); a1 = block_max4(a1, red4); a2 = block_max4(a2, red4); a3 = block_max4(a3, red4);
         g_st.maxabs_bits = __float_as_uint(a0); g_st.e2max_bits = __float_as_uint(a1);
-        g_st.enmax_bits = (VQ_IS_L2(metric)) ? __float_as_uint(a2) : 0u;
+        // L2: the largest |e_k|^2 is a1 (the same sums), the smallest is -a2.  Constant-norm codebook (NormalizeCallback:
+        // norms equal to a few ulp): the -|e_k|^2/2 term of the proposal score is the same for every code up to se*spread/2 —
+        // it is dropped from the scores (aux = 0 below, no aux reads in coarse32_kernel) and the spread goes into the margin
+        const bool l2 = VQ_IS_L2(metric);
+        const float spread = l2 ? a1 + a2 : 0.0f;
+        const bool const_norm = l2 && a3 == 0.0f && a1 > 0.0f && spread >= 0.0f && spread <= a1 * 1.52587890625e-05f;
+        g_st.enmax_bits = l2 ? __float_as_uint(a1) : 0u;
+        g_st.en_spread_bits = const_norm ? __float_as_uint(spread) : 0u;
+        g_st.l2_const_norm = const_norm ? 1u : 0u;
         g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
             st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 1u;
+            st->en_spread_bits = g_st.en_spread_bits; st->l2_const_norm = g_st.l2_const_norm;
             st->r2max_bits = 0u; st->eh2max_bits = 0u;       // (the image's own maxima live in the slots: cb_stats_view)
         }
     }
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     // aux chunk slice of this tile: -se*|e_k|^2/2 for its 32 codes (padded codes: a large FINITE negative score;
     // -inf with the register index or-ed into its mantissa would be a signalling NaN and poison v_max_f32)
     if (g == 0) {
-        float v = (k < K) ? (-0.5f * en[k]) * se : -3.0e38f;
+        float v = (k < K) ? (g_st.l2_const_norm ? 0.0f : (-0.5f * en[k]) * se) : -3.0e38f;
         *(float *)(stage_base + (int64_t)L.tps * L.nstep * VQ_CHUNK_BYTES + (ti * 32 + r) * 4) = v;
     }
     red[0][g][r] = r2; red[1][g][r] = h2;

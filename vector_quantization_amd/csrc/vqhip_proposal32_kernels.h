@@ -1,0 +1,304 @@
+// libvqhip device kernels, unit 3b: the proposal pass for D <= 16 on v_mfma_f32_32x32x16_f16.  Included by vqhip_kernels.h.
+//
+// Why a second form.  At D <= 32 the proposal pass is bound by the vector instructions that look at the scores and by MFMA
+// ISSUE, not by the matrix pipe (profiles/r03_d32_epilogue_shares.txt).  With D <= 16 one 32x32x16 instruction
+// covers the whole inner dimension and 32 codes x 32 tokens = 1024 scores, where the 16x16x32 form needs four instructions
+// (half of whose k-slots multiply padding): a quarter of the MFMA issue (8 cycles of the SIMD's vector port each), and a lane
+// holds 16 scores of ONE token per instruction, so the group record (coarse_kernel, GROUPS) is updated per 16 scores instead
+// of per 8 while the group stays ONE code tile — the identification replay does not grow (what sank the pair groups).
+//
+// Same images, same pipeline.  Nothing outside this kernel changes: the operands are read from the EXISTING fragment-major
+// images (a 16-row x 32-dim chunk holds, for lane l', row (l' & 15), dims 8 (l' >> 4) .. +8; dims 16..31 are padding at
+// D <= 16) with a per-lane address — lane l of the 32x32x16 operand wants row (l & 31) and dims 8 (l >> 5) .. +8, i.e. the
+// 16-byte piece (l >> 5) * 16 + (l & 15) of chunk (l >> 4) & 1 — so codebook image, token image, LDS-DMA ring, records,
+// decision stage, second pass and re-rank are the ones of the 16x16x32 form.  Scores: se * (xh . eh_k) - se |e_k|^2 / 2 with the
+// accumulator initialised from the aux values, accumulated over 16 products instead of 32 (16 of them zeros) — within the
+// same error bound B (row_margin is computed for the padded dimension 32); the replay uses this kernel's own instruction,
+// hence the very scores of the stream; the second pass (16x16x32) re-derives scores under the same bound, which is all the
+// margin argument needs of it.
+#pragma once
+
+// maximum of the 16 accumulator elements of one (token tile, code tile) in eight instructions, ordered behind the fake inputs
+// after[] (results of the MFMAs of the CURRENT tile: >= TT 32-cycle MFMAs after the producers; see tile_max8)
+template <int TT>
+__device__ __forceinline__ void tile_max16(float &dst, float &sc1, float &sc2, const f32x16 &p, const float (&after)[TT]) {
+    const float a0 = after[0], a1 = after[TT > 1 ? 1 : 0];
+    asm("v_max3_f32 %0, %3, %4, %5\n\t"
+        "v_max3_f32 %1, %6, %7, %8\n\t"
+        "v_max3_f32 %2, %9, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %14, %15\n\t"
+        "v_max3_f32 %2, %2, %16, %17\n\t"
+        "v_max3_f32 %0, %0, %1, %2\n\t"
+        "v_max_f32 %0, %0, %18"
+        : "+v"(dst), "+v"(sc1), "+v"(sc2)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]),
+          "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]), "v"(a0), "v"(a1));
+}
+// max over the two lanes l, l ^ 32 that share a token in the 32x32 MFMA output
+__device__ __forceinline__ float pair_rows_max(float v) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// One workgroup = WAVES waves x TT wide token tiles of 32 tokens (B fragments in registers for the whole kernel); the codebook
+// image streams through the LDS ring exactly as in coarse_kernel (NBUF stages of TPS tiles, filled two ahead, the second half
+// of the waves one stage behind).  tpb: 16-token tiles per workgroup (even).  Group records + replay identification as in
+// coarse_kernel<..., GROUPS>; straight-line update (no skip test: TT <= 2).
+template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX>
+__global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
+    const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
+    float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
+    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(TPS % 2 == 0 && NBUF >= 4, "ring of four stages, accumulators ping-pong by tile parity");
+    constexpr int NSTEP = 2;                              // the images are those of the padded dimension 32
+    constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);
+    constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
+    constexpr int NE = 16;                                // accumulator elements per lane, token tile and code tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5;                           // dims 8 half .. +8 of the operands; output rows + 4 half
+    const int col = lane & 31;                            // token of the wide tile (B, output column) / code of the tile (A)
+    const int sub = (lane >> 4) & 1;                      // which 16-row chunk holds this lane's row
+    const int piece = (half * 16 + (lane & 15)) * 16;     // byte offset of this lane's 16-byte piece inside that chunk
+    const int64_t ntt = (N + 31) / 32 * 2;                // 16-token tiles in the fp16 token image (of the launch's capacity)
+    if (dec.n_dev != nullptr) {                           // device-side row count: token blocks past it have nothing to do
+        const int64_t nd = *dec.n_dev;
+        N = nd < N ? nd : N;
+        if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
+    }
+    const bool wave_active = wave * TT * 2 < tpb;
+    const int sl = blockIdx.x % nslices;
+    const int64_t tb = blockIdx.x / nslices;
+    const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
+
+    // ---- prologue: the wide token tiles' B fragments, gathered from the 16-token chunks of the token image ----
+    half8 xf[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        int64_t t16 = tb * tpb + (wave * TT + t) * 2 + sub;
+        t16 = t16 < ntt ? t16 : ntt - 1;                  // out-of-range tiles read a valid tile and are never written
+        xf[t] = *(const half8 *)(ximg + t16 * (int64_t)VQ_CHUNK_BYTES + piece);
+    }
+    float b1[TT], b2[TT], mg[TT];
+    uint32_t t1[TT];
+    float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;             // destinations of the asm maxima: live across the whole loop
+    bool const_norm;                                      // L2 on a constant-norm codebook: aux values of real codes are 0
+    {
+        const VqCbStats stv = cb_stats_view(cbst);
+        const_norm = __builtin_amdgcn_readfirstlane((int)stv.l2_const_norm) != 0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            b1[t] = -INFINITY; b2[t] = -INFINITY; t1[t] = 0;
+            int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
+            tokn = tokn < N ? tokn : N - 1;
+            const float m = row_margin(&stv, Dp, metric, xh2[tokn], rho2[tokn]);
+            mg[t] = (m > 0.0f) ? m : INFINITY;            // no usable bound: nothing is identified, the decision stage re-scans
+        }
+    }
+
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+    constexpr int AHEAD = 2;
+    const int lag = (wave >= WAVES / 2) ? 1 : 0;
+    if (st0 < st1) issue_stage(st0, 0);
+    if (st0 + 1 < st1) issue_stage(st0 + 1, 1);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+
+    f32x16 accA[TT], accB[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int q = 0; q < NE; ++q) accB[t][q] = -INFINITY;   // "previous tile" of the very first tile: never registers
+
+    for (int64_t it = st0; it < st1 + 1; ++it) {
+        if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+        const int64_t st = it - lag;
+        if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
+        const int buf = (int)((st - st0) % NBUF);
+        const char *base = lds + buf * STAGE_BYTES;
+        const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
+        auto run_stage = [&](auto with_aux_tag) __attribute__((always_inline)) {
+            constexpr bool WITH_AUX = decltype(with_aux_tag)::value;
+#pragma unroll
+            for (int ti = 0; ti < TPS; ++ti) {
+                f32x16 (&cur)[TT] = (ti & 1) ? accB : accA;
+                f32x16 (&prv)[TT] = (ti & 1) ? accA : accB;
+                const half8 af = *(const half8 *)(base + (ti * NSTEP + sub) * VQ_CHUNK_BYTES + piece);
+                f32x16 init;
+                if constexpr (WITH_AUX) {                 // -se |e|^2 / 2 of this lane's code rows (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a4 = *(const f32x4 *)(aux + (ti * 32 + 8 * g + 4 * half) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) init[4 * g + q] = a4[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) init[q] = 0.0f;
+                }
+                const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;   // the tile whose scores are retired below
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[t], init, 0, 0, 0);
+                    // token tile t of the PREVIOUS code tile: its maximum, then the group record (the lane keeps the best
+                    // group maximum — its 16 codes of one code tile — the tile it came from and the best maximum of any
+                    // other group; which of the 16 codes it was is found after the stream by replaying that one tile)
+                    float after[TT];
+#pragma unroll
+                    for (int u = 0; u < TT; ++u) after[u] = cur[u <= t ? u : t][0];
+                    tile_max16<TT>(sc0, sc1, sc2, prv[t], after);
+                    const float nb = vmax(b1[t], sc0);
+                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], sc0);
+                    t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? tgp : t1[t];
+                    b1[t] = nb;
+                }
+            }
+        };
+        if constexpr (NOAUX) {
+            if (st == (int64_t)pad_stage) run_stage(std::true_type{}); else run_stage(std::false_type{});
+        } else {       // the aux reads (four 16-byte LDS reads per lane and tile) are skipped where every value is zero anyway
+            if (const_norm && st != (int64_t)pad_stage) run_stage(std::false_type{}); else run_stage(std::true_type{});
+        }
+        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+    }
+    // drain: the last tile (odd parity: it sits in accB)
+    if (st1 > st0) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t old = __float_as_uint(b1[t]);
+            float g = accB[t][0];
+#pragma unroll
+            for (int e = 1; e < NE; ++e) g = __builtin_amdgcn_fmed3f(g, accB[t][e], INFINITY);   // max, NaN-transparent like v_max
+            b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], g);
+            b1[t] = vmax(b1[t], g);
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
+    }
+
+    // ---- group records -> code records: a lane whose best group can matter replays that one code tile (same fragments, same
+    // instruction, same initial value: the very scores of the stream) and runs the per-element update on its 16 elements;
+    // everything else the lane has seen stays a value bound (coarse_kernel, same section)
+    bool ident[TT];
+    {
+        auto bound_up = [](float v) {
+            const uint32_t b = __float_as_uint(v);
+            return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
+        };
+        constexpr int RB = 4;                             // tiles replayed per round trip (4 + 16 registers each)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float top = pair_rows_max(b1[t]);
+            const int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
+            const bool need = (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) && tokn < N &&
+                              (wave * TT + t) * 2 < tpb && t1[t] >= (uint32_t)(st0 * TPS) && t1[t] < (uint32_t)(st1 * TPS);
+            float e1 = -INFINITY, e2 = -INFINITY;
+            u64 todo = __ballot(need);
+            while (todo) {
+                uint32_t T[RB];
+                u64 rest = todo;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int l = rest ? (__ffsll((unsigned long long)rest) - 1) : (__ffsll((unsigned long long)todo) - 1);
+                    T[i] = (uint32_t)__builtin_amdgcn_readlane((int)t1[t], l);
+                    rest &= rest - 1;
+                }
+                half8 a[RB];
+                f32x16 acc[RB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int64_t rst = T[i] / TPS;
+                    const int rti = (int)(T[i] % TPS);
+                    const char *sb = frag + rst * (int64_t)STAGE_BYTES;
+                    a[i] = *(const half8 *)(sb + (rti * NSTEP + sub) * VQ_CHUNK_BYTES + piece);
+                    if ((NOAUX || const_norm) && rst != (int64_t)pad_stage) {
+#pragma unroll
+                        for (int q = 0; q < NE; ++q) acc[i][q] = 0.0f;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 a4 = *(const f32x4 *)(sb + TPS * NSTEP * VQ_CHUNK_BYTES + (rti * 32 + 8 * g + 4 * half) * 4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[i][4 * g + q] = a4[q];
+                        }
+                    }
+                }
+                u64 done = 0;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xf[t], acc[i], 0, 0, 0);
+                    float w1 = -INFINITY, w2 = -INFINITY;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {                 // element id = accumulator register (4 bits)
+                        float v = __uint_as_float((__float_as_uint(acc[i][e]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        w2 = __builtin_amdgcn_fmed3f(w1, w2, v);
+                        w1 = vmax(w1, v);
+                    }
+                    const bool mine = need && t1[t] == T[i];
+                    e1 = mine ? w1 : e1; e2 = mine ? w2 : e2;
+                    done |= __ballot(mine);
+                }
+                todo &= ~done;
+            }
+            const float other = bound_up(b2[t]);
+            if (need) { b1[t] = e1; b2[t] = fmaxf(other, e2); }
+            else { b2[t] = fmaxf(other, bound_up(b1[t])); }
+            ident[t] = need;
+        }
+    }
+
+    // ---- merge the two lanes that share a token; lanes 0..31 write one record per (token, slice) ----
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        Top2 r; r.v1 = r.v2 = r.v3 = -INFINITY; r.c1 = r.c2 = 0xFFFFFFFFu;
+        {
+            const uint32_t bits = __float_as_uint(b1[t]);
+            const uint32_t code = t1[t] * 32u + (uint32_t)mfma_row((int)(bits & 15u), half);
+            if (ident[t] && b1[t] > -INFINITY) top_insert(r, b1[t], code);
+            r.v3 = fmaxf(r.v3, b2[t]);
+        }
+        top_merge_lane(r, 32);
+        const int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
+        if (lane < 32 && tokn < N && (wave * TT + t) * 2 < tpb) {
+            float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
+            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
+            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+        }
+    }
+
+    // ---- decision stage, by the workgroup that completes a token block (coarse_kernel, same section) ----
+    if (dec.idx != nullptr) {
+        int *flags = (int *)lds;                         // the stage ring is free now (first barrier below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int last = 1;
+            if (nslices > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = (atomicAdd(&dec.arrive[tb], 1) == nslices - 1) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            flags[0] = last;
+        }
+        __syncthreads();
+        const bool last = flags[0] != 0;
+        __syncthreads();                                 // everybody has read the flag before the LDS words are reused
+        if (last) {
+            int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
+            int64_t n = tb * (int64_t)(tpb * 16) + threadIdx.x;      // tpb*16 <= WAVES*64 threads: one token per thread
+            const bool oob = (int)threadIdx.x >= tpb * 16 || n >= N;
+            if (n >= N) n = N - 1;
+            decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
+        }
+    }
+}

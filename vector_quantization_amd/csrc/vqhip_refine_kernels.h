@@ -70,6 +70,9 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
         float S = 2.0f * (1.01f * Df * VQ_U * 2.0f * Xn * Emax + 2.1f * VQ_U * mag) + 4.0f * VQ_U * mag;
         float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax + 0.5f * ENmax);
         m = 2.0f * B + 0.5f * S;
+        // constant-norm codebook: the scores carry no -|e_k|^2/2 term; two codes' terms differ by at most spread/2 (twice that
+        // is added: generous, and the spread of a normalised codebook is ~2^-22 of the norm)
+        if (st->l2_const_norm != 0) m += __uint_as_float(st->en_spread_bits);
     } else {
         float B = rho * Emax + Xh * Rmax + (4.0f * Df + 32.0f) * VQ_U * (Xh * Ehmax);
         m = 2.0f * B + 2.0f * (Df + 4.0f) * VQ_U * Xn * Emax + 8.0f * VQ_U;
