@@ -7,7 +7,7 @@ import torch
 from vector_quantization_amd import _lib, ops
 L = _lib.lib()
 g = torch.Generator(device='cuda').manual_seed(3407)
-shapes = [(524288, 16384, 8, 'L2'), (524288, 16384, 8, 'Cosine'), (65536, 16384, 8, 'L2'), (65536, 16384, 8, 'Cosine'), (100352, 8192, 16, 'Cosine'), (100352, 8192, 16, 'L2'), (20000, 4096, 16, 'L2')]
+shapes = [(100352, 8192, 32, 'Cosine'), (100352, 8192, 32, 'L2'), (65536, 8192, 32, 'Cosine'), (524288, 16384, 32, 'L2'), (524288, 16384, 8, 'L2'), (524288, 16384, 8, 'Cosine'), (65536, 16384, 8, 'L2'), (65536, 16384, 8, 'Cosine'), (100352, 8192, 16, 'Cosine'), (100352, 8192, 16, 'L2'), (20000, 4096, 16, 'L2')]
 def timeit(fn, reps=20, warm=4):
     for _ in range(warm): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

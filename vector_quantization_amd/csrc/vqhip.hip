@@ -125,12 +125,12 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
 }
 
 // D <= 16: the proposal pass on v_mfma_f32_32x32x16_f16 (vqhip_proposal32_kernels.h), same images and arguments
-template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX>
+template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS>
 static int launch_coarse32_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                                int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
                                const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * 2 + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
-    auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX>;
+    auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX, KS>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     const int64_t ntiles = (N + 15) / 16;
@@ -154,6 +154,9 @@ static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages
     return VQHIP_OK;
 }
 
+#ifndef VQ_W32_MAX_D
+#define VQ_W32_MAX_D 32        // the 32x32x16 proposal kernel up to this D (16: one instruction per tile; 32: two)
+#endif
 #ifndef VQ_NBUF_D32
 #define VQ_NBUF_D32 4          // LDS ring depth of the D <= 32 proposal kernels (2 and 3 measured: profiles/r02_smallD_ring.txt)
 #endif
@@ -233,7 +236,10 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     }
     switch (nstep) {
         // D <= 128: VALU-issue-bound with the plain epilogue -> filtered epilogue (see coarse_kernel)
-        case 2: if (L.D <= 16 && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load()) {
+        // D <= 16 always; 16 < D <= 32 (two instructions per tile) only without aux reads — measured (tools/ab_w32.py,
+        // profiles/r03_w32_ab.txt): D = 32 cosine +2.5..5 %, D = 32 L2 -4..-14 % (the form is LDS-bound once the four 16-byte aux
+        // reads per lane and tile come on top of 2 KiB of fragments)
+        case 2: if ((L.D <= 16 || (L.D <= VQ_W32_MAX_D && noaux)) && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load()) {
                     // one 32x32x16 instruction covers the whole inner dimension: a quarter of the MFMA issue, group update per
                     // 16 scores.  Wide token tiles of 32 tokens: 1 (below 262 144 tokens) or 2 per wave.
 #ifdef VQ_W32_TT
@@ -251,9 +257,14 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
                     VqDecideOut dsel = dec;
                     if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;
                     *fused_decide_out = dsel.idx != nullptr ? 1 : 0;
-#define VQ_CFG32(TTW, NOAUXV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s)
-                    if (tt == 1) { if (noaux) VQ_CFG32(1, true); else VQ_CFG32(1, false); }
-                    else { if (noaux) VQ_CFG32(2, true); else VQ_CFG32(2, false); }
+#define VQ_CFG32(TTW, NOAUXV, KSV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV, KSV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s)
+                    if (L.D <= 16) {
+                        if (tt == 1) { if (noaux) VQ_CFG32(1, true, 1); else VQ_CFG32(1, false, 1); }
+                        else { if (noaux) VQ_CFG32(2, true, 1); else VQ_CFG32(2, false, 1); }
+                    } else {
+                        if (tt == 1) { if (noaux) VQ_CFG32(1, true, 2); else VQ_CFG32(1, false, 2); }
+                        else { if (noaux) VQ_CFG32(2, true, 2); else VQ_CFG32(2, false, 2); }
+                    }
 #undef VQ_CFG32
                 }
                 if (!g_tune_filter.load()) { if (small32) VQ_CFG(2, 2, 8, VQ_TPS_D32, VQ_NBUF_D32) else VQ_CFG(2, 4, 8, VQ_TPS_D32, VQ_NBUF_D32) }

@@ -45,7 +45,9 @@ __device__ __forceinline__ float pair_rows_max(float v) {
 // image streams through the LDS ring exactly as in coarse_kernel (NBUF stages of TPS tiles, filled two ahead, the second half
 // of the waves one stage behind).  tpb: 16-token tiles per workgroup (even).  Group records + replay identification as in
 // coarse_kernel<..., GROUPS>; straight-line update (no skip test: TT <= 2).
-template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX>
+// KS: k-steps of 16 dims — 1 for D <= 16, 2 for D <= 32 (two instructions accumulate; the chains of the TT token tiles are
+// interleaved so that no instruction waits for the one it accumulates onto).
+template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS = 1>
 __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
@@ -73,12 +75,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
 
     // ---- prologue: the wide token tiles' B fragments, gathered from the 16-token chunks of the token image ----
-    half8 xf[TT];
+    half8 xf[TT][KS];                                     // (k-step s: the pieces 32 further on, i.e. 512 bytes)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         int64_t t16 = tb * tpb + (wave * TT + t) * 2 + sub;
         t16 = t16 < ntt ? t16 : ntt - 1;                  // out-of-range tiles read a valid tile and are never written
-        xf[t] = *(const half8 *)(ximg + t16 * (int64_t)VQ_CHUNK_BYTES + piece);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[t][s] = *(const half8 *)(ximg + t16 * (int64_t)VQ_CHUNK_BYTES + piece + s * 512);
     }
     float b1[TT], b2[TT], mg[TT];
     uint32_t t1[TT];
@@ -130,7 +133,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
             for (int ti = 0; ti < TPS; ++ti) {
                 f32x16 (&cur)[TT] = (ti & 1) ? accB : accA;
                 f32x16 (&prv)[TT] = (ti & 1) ? accA : accB;
-                const half8 af = *(const half8 *)(base + (ti * NSTEP + sub) * VQ_CHUNK_BYTES + piece);
+                half8 af[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) af[s] = *(const half8 *)(base + (ti * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
                 f32x16 init;
                 if constexpr (WITH_AUX) {                 // -se |e|^2 / 2 of this lane's code rows (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -145,8 +150,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
                 }
                 const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;   // the tile whose scores are retired below
 #pragma unroll
+                for (int s = 0; s + 1 < KS; ++s)          // all but the last k-step, token tiles interleaved
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+                        cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], xf[t][s], s == 0 ? init : cur[t], 0, 0, 0);
+#pragma unroll
                 for (int t = 0; t < TT; ++t) {
-                    cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, xf[t], init, 0, 0, 0);
+                    cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[KS - 1], xf[t][KS - 1], KS == 1 ? init : cur[t], 0, 0, 0);
                     // token tile t of the PREVIOUS code tile: its maximum, then the group record (the lane keeps the best
                     // group maximum — its 16 codes of one code tile — the tile it came from and the best maximum of any
                     // other group; which of the 16 codes it was is found after the stream by replaying that one tile)
@@ -209,14 +219,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
                     T[i] = (uint32_t)__builtin_amdgcn_readlane((int)t1[t], l);
                     rest &= rest - 1;
                 }
-                half8 a[RB];
+                half8 a[RB][KS];
                 f32x16 acc[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int64_t rst = T[i] / TPS;
                     const int rti = (int)(T[i] % TPS);
                     const char *sb = frag + rst * (int64_t)STAGE_BYTES;
-                    a[i] = *(const half8 *)(sb + (rti * NSTEP + sub) * VQ_CHUNK_BYTES + piece);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) a[i][s] = *(const half8 *)(sb + (rti * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
                     if ((NOAUX || const_norm) && rst != (int64_t)pad_stage) {
 #pragma unroll
                         for (int q = 0; q < NE; ++q) acc[i][q] = 0.0f;
@@ -232,7 +243,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
                 u64 done = 0;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xf[t], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][s], xf[t][s], acc[i], 0, 0, 0);
                     float w1 = -INFINITY, w2 = -INFINITY;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) {                 // element id = accumulator register (4 bits)

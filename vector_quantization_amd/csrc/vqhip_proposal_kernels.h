@@ -101,7 +101,11 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     const int sl = blockIdx.x % nslices;
     const int64_t tb = blockIdx.x / nslices;
     const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
-  {
+  // A loop that runs once.  It is what is left of the stream-K segment loop, and it stays because of what hipcc makes of the
+  // kernel with it: without it the D = 1024 instantiation comes out with another schedule (165 instead of 193 VGPRs, the A
+  // fragments fetched less far ahead) and runs 21 % slower (1.075 -> 1.301 ms at 65 536 x 8192, same-device A/B), every other
+  // instantiation within 1 %.
+  for (bool once = true; once; once = false) {
 
     // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
     half8 xf[TT][NS32];
