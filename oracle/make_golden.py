@@ -538,6 +538,93 @@ def connector_case():
                                         'vq/tasks/image_tokenization/models/base.py:116-146'])))
 
 
+def runner_cases():
+    """f1/f2: the runner-level callers, executed from the reference's own files (ref_import.load_runners): the token file
+    TokenizeCallback writes, the two .npy files of the LlamaGen TokenizeCallback, the values CodebookUsageMetric /
+    CodebookPPLMetric return over three iterations, and Tokenizer._run_iter on a model whose encode_to_quant is the
+    reference BaseModel's.  The files are stored byte for byte (uint8 arrays)."""
+    import pathlib
+    import types
+    import torch.distributed as dist
+    ref, rr = ref_import.load(), ref_import.load_runners()
+    B, C, H, W, K = 3, 32, 4, 4, 64
+    gen = synth.rng(71)
+    quant = gen.integers(0, K, size=B * H * W, dtype=np.int64)
+    category = np.array([1, 207, 999], dtype=np.int64)
+    ids = ['n01440764_10026', 'n02099601_7', 'n15075141_999']
+    quant10 = gen.integers(0, K, size=10 * H * W, dtype=np.int64)
+    label = np.array([388], dtype=np.int64)
+    metric_quants = [gen.integers(0, K // 2 + 8 * i, size=40 + 16 * i, dtype=np.int64) for i in range(3)]
+    rec = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        runner = types.SimpleNamespace(work_dir=pathlib.Path(tmp), iter_=3, dataset=types.SimpleNamespace(image_size=256))
+        cb = rr.TokenizeCallback()
+        cb.bind(runner)
+        cb.after_run_iter(dict(id_=ids, category=torch.from_numpy(category)),
+                          dict(quantizer=dict(quant=torch.from_numpy(quant), x_shape=torch.Size((B, C, H, W)))))
+        rec['tokens_pth'] = np.frombuffer((pathlib.Path(tmp) / 'tokens' / '3_0.pth').read_bytes(), dtype=np.uint8)
+        cb2 = rr.LlamaGenTokenizeCallback()
+        cb2.bind(runner)
+        batch = dict(original_image=torch.zeros(1, 10, 3, 8, 8, dtype=torch.uint8), image=torch.zeros(1, 10, 3, 8, 8),
+                     category=torch.from_numpy(label))
+        cb2.before_run_iter(batch, {})
+        assert batch['image'].shape == (10, 3, 8, 8)
+        cb2.after_run_iter(batch, dict(quantizer=dict(quant=torch.from_numpy(quant10))))
+        base = pathlib.Path(tmp) / 'llamagen_tokens'
+        rec['llamagen_codes_npy'] = np.frombuffer((base / 'imagenet256_codes' / '2.npy').read_bytes(), dtype=np.uint8)
+        rec['llamagen_labels_npy'] = np.frombuffer((base / 'imagenet256_labels' / '2.npy').read_bytes(), dtype=np.uint8)
+        # metrics: summary() all-reduces, which needs a process group — one rank, gloo
+        own_group = not dist.is_initialized()
+        if own_group:
+            dist.init_process_group('gloo', store=dist.FileStore(os.path.join(tmp, 'store'), 1), rank=0, world_size=1)
+        try:
+            runner.strategy = types.SimpleNamespace(module=types.SimpleNamespace(quantizer=types.SimpleNamespace(codebook_size=K)))
+            usage = rr.CodebookUsageMetric(quant='["quantizer"]["quant"]')        # configs/vqgan/runner.py:121-128
+            ppl = rr.CodebookPPLMetric(quant='["quantizer"]["quant"]')
+            assert usage.summary({}) == 0. and ppl.summary({}) == 0.              # before any iteration (metrics.py:50-51)
+            for m in (usage, ppl):
+                m.bind(runner)
+                for mq in metric_quants:
+                    m.forward({}, dict(quantizer=dict(quant=torch.from_numpy(mq))))
+            rec['usage'] = np.float64(usage.summary({}))
+            rec['ppl'] = np.float64(ppl.summary({}))
+            rec['counts'] = usage._counts.numpy().astype(np.int64)
+        finally:
+            if own_group:
+                dist.destroy_process_group()
+    # Tokenizer._run_iter (tokenizer.py:44-55) on a holder whose encode_to_quant is BaseModel's (models/base.py:130-146)
+    Kq, Dq = 128, 16
+    wcb = gen.standard_normal((Kq, Dq), dtype=np.float32)
+    image = gen.standard_normal((2, Dq, 4, 4), dtype=np.float32)
+    q = ref_quantizer(Kq, Dq, 'L2', 'vqgan', (), wcb)
+
+    class Holder:
+        _quantizer = q
+
+        def encode(self, image, memo):
+            return image, memo
+
+        def encode_to_quant(self, image, memo):
+            return ref.BaseModel.encode_to_quant(self, image, memo)
+
+    tok = object.__new__(rr.Tokenizer)
+    tok.strategy = types.SimpleNamespace(module=Holder())
+    with torch.no_grad():
+        memo = rr.Tokenizer._run_iter(tok, dict(original_image=torch.from_numpy(image), image=torch.from_numpy(image)), {})
+    assert sorted(memo) == ['image', 'original_image', 'quantizer'] and tuple(memo['quantizer']['x_shape']) == (2, Dq, 4, 4)
+    np.savez_compressed(
+        os.path.join(OUT, 'runner_files.npz'), **rec, quant=quant, category=category, quant10=quant10, label=label,
+        metric_quants_0=metric_quants[0], metric_quants_1=metric_quants[1], metric_quants_2=metric_quants[2],
+        tok_image=image, tok_w=wcb, tok_quant=memo['quantizer']['quant'].numpy().astype(np.int64),
+        spec=json.dumps(dict(B=B, C=C, H=H, W=W, K=K, seed=71, ids=ids, iter=3, rank=0, image_size=256, source='reference-import',
+                             torch=torch.__version__,
+                             reference=['vq/tasks/image_tokenization/runners/callbacks.py:23-53',
+                                        'vq/tasks/image_tokenization/runners/metrics.py:25-73',
+                                        'vq/tasks/image_tokenization/runners/tokenizer.py:44-55',
+                                        'vq/tasks/image_tokenization/models/base.py:130-146',
+                                        'tools/tokenize_llamagen.py:65-103'])))
+
+
 def main(only=(), out_dir=None, quiet=False):
     global OUT
     if not ref_import.available():
@@ -569,6 +656,8 @@ def main(only=(), out_dir=None, quiet=False):
         entropy_case()
     if not only or 'connector' in only:
         connector_case()
+    if not only or 'runners' in only:
+        runner_cases()
     print_('fixtures written to', OUT, '— every value produced by the reference files:')
     for n, f in ref_import.load().files.items():
         print_('   ', f)

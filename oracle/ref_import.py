@@ -272,6 +272,33 @@ def _install_todd() -> types.ModuleType:
 
         debug = warning = info
 
+    # ---- runner-side holders (structure only): what a callback / metric is bound to, and todd's string accessor ----
+    class _RunnerHolder(Generic[T]):
+        def __init__(self, *args, **kwargs) -> None:
+            super().__init__()
+
+        def bind(self, runner) -> None:
+            self._runner = runner
+
+        @property
+        def runner(self):
+            return self._runner
+
+    class BaseCallback(_RunnerHolder[T]):
+        def before_run_iter(self, batch, memo) -> None:
+            pass
+
+        def after_run_iter(self, batch, memo) -> None:
+            pass
+
+    class BaseMetric(_RunnerHolder[T]):
+        pass
+
+    def get_(obj, attr: str):
+        """todd.patches.py_.get_: the configs pass accessor strings such as '["quantizer"]["quant"]'
+        (configs/vqgan/runner.py:123)."""
+        return eval('__o' + attr, {'__o': obj})     # noqa: S307 — build-container test infrastructure, fixed strings
+
     known = {
         'todd': dict(Config=Config, Registry=Registry, RegistryMeta=RegistryMeta, Store=Store, logger=_Logger()),
         'todd.bases': {},
@@ -286,6 +313,9 @@ def _install_todd() -> types.ModuleType:
         'todd.patches.torch': dict(ModuleDict=ModuleDict, ModuleList=ModuleList, Sequential=Sequential,
                                    get_world_size=get_world_size, get_rank=get_rank, all_gather=all_gather),
         'todd.runners': dict(Memo=dict),
+        'todd.runners.callbacks': dict(BaseCallback=BaseCallback),
+        'todd.runners.metrics': dict(BaseMetric=BaseMetric),
+        'todd.patches.py_': dict(get_=get_),
         'todd.runners.utils': dict(PriorityQueue=PriorityQueue),
         'todd.utils': dict(EMA=_ToddArithmetic.EMA, ema=_ToddArithmetic.ema, HolderMixin=HolderMixin, is_sync=is_sync,
                            StoreMeta=StoreMeta, EnvRegistry=_registry('EnvRegistry')),
@@ -340,6 +370,8 @@ _PACKAGES = {
     'vq.tasks': [('star', 'registries')],                                        # vq/tasks/__init__.py
     'vq.tasks.image_tokenization': [('star', 'registries')],                     # .../image_tokenization/__init__.py:2
     'vq.tasks.image_tokenization.models': [('pkg', 'quantizers'), ('star', 'registries')],   # models/__init__.py:1,3
+    'vq.tasks.image_tokenization.runners': [('star', 'callbacks'), ('star', 'metrics'),      # runners/__init__.py:1-4
+                                            ('star', 'registries'), ('star', 'tokenizer')],
     'vq.tasks.image_tokenization.models.connectors': [                           # connectors/__init__.py:1-3
         ('star', 'base'), ('star', 'composed'), ('star', 'conv')],
     'vq.tasks.image_tokenization.models.quantizers': [                           # quantizers/__init__.py:1-4
@@ -449,6 +481,38 @@ def load() -> types.SimpleNamespace:
 
     ns.build_quantizer = build_quantizer
     return ns
+
+
+@functools.lru_cache(1)
+def load_runners() -> types.SimpleNamespace:
+    """The caller side of the path, also from the reference's own files: ``Tokenizer``,
+    ``TokenizeCallback``, ``CodebookUsageMetric``, ``CodebookPPLMetric`` (vq/tasks/image_tokenization/runners/*.py) and the
+    LlamaGen ``TokenizeCallback`` of tools/tokenize_llamagen.py.  ``vq.runners`` (BaseValidator, the runner registries'
+    other parent) stays inert: the classes are driven by hand in oracle/make_golden.py, exactly the methods that touch
+    tokens and files."""
+    ref = load()
+    models = sys.modules['vq.tasks.image_tokenization.models']
+    models.BaseModel = ref.BaseModel                                              # models/__init__.py:2 (from .base import *)
+    runners = importlib.import_module('vq.tasks.image_tokenization.runners')
+    it = sys.modules['vq.tasks.image_tokenization']
+    it.runners = runners                                                          # image_tokenization/__init__.py:1
+    for stub in ('torchvision', 'torchvision.transforms'):                        # imported by the tool, used by its dataset hook only
+        if stub not in sys.modules:
+            m = _InertModule(stub)
+            m.__path__ = []
+            sys.modules[stub] = m
+    path = os.path.join(REFERENCE_ROOT, 'tools', 'tokenize_llamagen.py')
+    spec = importlib.util.spec_from_file_location('ref_tools_tokenize_llamagen', path)
+    tool = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = tool
+    spec.loader.exec_module(tool)
+    return types.SimpleNamespace(Tokenizer=runners.Tokenizer, TokenizeCallback=runners.TokenizeCallback, Tokens=runners.Tokens,
+                                 CodebookUsageMetric=runners.CodebookUsageMetric, CodebookPPLMetric=runners.CodebookPPLMetric,
+                                 VQITCallbackRegistry=runners.VQITCallbackRegistry, VQITMetricRegistry=runners.VQITMetricRegistry,
+                                 LlamaGenTokenizeCallback=tool.TokenizeCallback, LlamaGenTokenizer=tool.Tokenizer,
+                                 files=['vq/tasks/image_tokenization/runners/callbacks.py',
+                                        'vq/tasks/image_tokenization/runners/metrics.py',
+                                        'vq/tasks/image_tokenization/runners/tokenizer.py', 'tools/tokenize_llamagen.py'])
 
 
 if __name__ == '__main__':

@@ -39,6 +39,18 @@ def test_reference_files_are_the_ones_executed():
                 assert sys.modules[obj.__module__].__file__.startswith(ref_import.REFERENCE_ROOT), name
 
 
+def test_runner_level_classes_are_the_reference_files_too():
+    """tests/golden/runner_files.npz comes from the reference's Tokenizer / TokenizeCallback / metrics / LlamaGen tool."""
+    import sys
+    rr = ref_import.load_runners()
+    for f in rr.files:
+        assert os.path.isfile(os.path.join(ref_import.REFERENCE_ROOT, f)), f
+    for cls in (rr.Tokenizer, rr.TokenizeCallback, rr.CodebookUsageMetric, rr.CodebookPPLMetric, rr.LlamaGenTokenizeCallback):
+        assert sys.modules[cls.__module__].__file__.startswith(ref_import.REFERENCE_ROOT), cls
+    assert rr.VQITCallbackRegistry._resolve('TokenizeCallback') is rr.LlamaGenTokenizeCallback      # the tool registers with force=True
+    assert rr.VQITMetricRegistry._resolve('CodebookPPLMetric') is rr.CodebookPPLMetric
+
+
 def test_standin_supplies_no_arithmetic_but_the_documented_three():
     """No torch/numpy arithmetic call in the stand-in outside _ToddArithmetic (ema, EMA, MSELoss(norm))."""
     src = open(ref_import.__file__).read()
@@ -76,7 +88,7 @@ def test_every_fixture_cites_reference_lines():
         spec = json.loads(str(np.load(p)['spec']))
         assert spec['source'] == 'reference-import'
         for cite in spec['reference']:
-            m = re.match(r'(vq/[\w/]+\.py):[\d,\-]+$', cite)
+            m = re.match(r'((?:vq|tools)/[\w/]+\.py):[\d,\-]+$', cite)
             assert m and os.path.isfile(os.path.join(ref_import.REFERENCE_ROOT, m.group(1))), cite
 
 

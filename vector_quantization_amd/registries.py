@@ -1,5 +1,6 @@
 """Registry hierarchy of the quantizer path, same names as the reference
-(vq/registries.py:18-35, vq/tasks/image_tokenization/models/registries.py,
+(vq/registries.py:18-35, vq/tasks/image_tokenization/registries.py:11-16, .../runners/registries.py:11-16,
+vq/tasks/image_tokenization/models/registries.py,
 .../quantizers/registries.py:9-14, vq/algorithms/vq/distances.py:19-20, vq/algorithms/cvqvae/registries.py:8)."""
 from .config import Registry
 
@@ -41,4 +42,24 @@ class VQITQuantizerLossRegistry(VQITQuantizerRegistry):
 
 
 class AnchorRegistry(Registry):
+    pass
+
+
+class RunnerRegistry(Registry):
+    """Stands in for todd.registries.RunnerRegistry."""
+
+
+class VQRunnerRegistry(VQRegistry, RunnerRegistry):
+    pass
+
+
+class VQITRunnerRegistry(VQRunnerRegistry):
+    pass
+
+
+class VQITCallbackRegistry(VQITRunnerRegistry):
+    pass
+
+
+class VQITMetricRegistry(VQITRunnerRegistry):
     pass
