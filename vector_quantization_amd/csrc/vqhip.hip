@@ -324,10 +324,11 @@ static int run_exact_rows(const void *x, int x_dtype, const float *e, const floa
     // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items); the workgroup
     // that finishes last turns the keys into indices (ticket: zeroed by x_prep_kernel with the other counters)
     const int grid = 256;
+    if (D % 4) return fail(VQHIP_EINVAL, "exact_kernel: D % 4 != 0 (the proposal route has D % 8 == 0)");
     if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr, ticket, idx, hist);
+        exact_kernel<0><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist);
     else
-        exact_kernel<1, 0, 1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, nullptr, ticket, idx, hist);
+        exact_kernel<1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist);
     VQ_CHECK_LAUNCH("exact_kernel");
     return VQHIP_OK;
 }
@@ -1195,3 +1196,4 @@ int vqhip_profile_collect(double *ms_sum, int64_t *launches) {
 }
 
 }  // extern "C"
+

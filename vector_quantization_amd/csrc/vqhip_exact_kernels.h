@@ -4,99 +4,89 @@
 // ------------------------------------------------------------------------------------------------
 // exact fp32 MFMA pass (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain)
 // ------------------------------------------------------------------------------------------------
-// MODE 0: row argmin via 64-bit atomicMin keys[row]; MODE 1: column argmin keys[code]; MODE 2: store d[N,K]
-// Work item = (tile of 32 rows, chunk of 4*CT*32 codes); persistent grid-stride loop over items.
-template <int DT, int MODE, int CT>
+// Last-resort path of vqhip_argmin: a few LISTED rows against the whole codebook, row argmin via 64-bit atomicMin keys[row].
+// Work item = (tile of 32 listed rows, chunk of 128 codes: one 32-code tile per wave); persistent grid-stride loop over items.
+// A lane owns one latent row (as B operand: row j, k-parity h) and one code row (A operand) and walks them in batches of 32
+// dims — 8 pieces of 16 bytes each — through a ring of RING batches requested ahead; the chain of D/2 dependent
+// v_mfma_f32_32x32x2_f32 is the oracle's k-ordered fma chain.  The dims loop is a RUN-TIME loop on purpose: the first form
+// unrolled all 64 pieces of a 256-dim block (11 600 instructions, 93 KB of code executed once per wave) and a handful of
+// listed rows cost 29-36 us whatever was taken out of the data path — MFMAs, atomics, the ticket, the order of the loads
+// (profiles/r03_exact_rows.txt): the waves were waiting for their own instruction stream.
+// ticket: the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows itself, so the path is ONE launch;
+// with an empty list every workgroup returns at once.
+template <int DT>
 __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
                                                     const float *__restrict__ en_in,
                                                     const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
                                                     int metric, const int *__restrict__ row_list,
                                                     const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
-                                                    float *__restrict__ dout, int *__restrict__ ticket = nullptr,
-                                                    int64_t *__restrict__ fin_idx = nullptr,
-                                                    int32_t *__restrict__ fin_hist = nullptr) {
-    // CT = code tiles (32 codes) per wave: 4 for whole-batch passes, 1 when only a few flagged rows need the
-    // whole codebook (more, smaller work items)
-    // ticket != nullptr (row-list form): the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows
-    // itself, so the last-resort path is ONE launch; with an empty list every workgroup returns at once.
-    constexpr int DB = 256;                     // dims per register block
-    constexpr int CHUNK = 4 * CT * 32;          // codes per work item (4 waves)
+                                                    int *__restrict__ ticket, int64_t *__restrict__ fin_idx,
+                                                    int32_t *__restrict__ fin_hist) {
+    constexpr int CHUNK = 4 * 32;               // codes per work item (4 waves)
+    constexpr int RING = 4;                     // batches in flight
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int64_t nrows = row_list ? (int64_t)(*nrows_dev) : N;
     const int64_t ntiles = (nrows + 31) / 32;
     const int64_t nchunks = (K + CHUNK - 1) / CHUNK;
     const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+    // D % 4 == 0 (the proposal route this path belongs to has D % 8 == 0).  An element-wise tail form in the same kernel made
+    // hipcc hoist its ~250 loop-invariant `d + q < D` conditions in front of everything: thousands of scalar instructions and
+    // lane spills per wave, 7 us before the first request went out.
+    const int nb = (D + 31) / 32;
 
     for (int64_t item = blockIdx.x; item < ntiles * nchunks; item += gridDim.x) {
         const int64_t tile = item / nchunks, chunk = item % nchunks;
         const int64_t slot = tile * 32 + j;
         const bool rvalid = slot < nrows;
         const int64_t row = rvalid ? (row_list ? (int64_t)row_list[slot] : slot) : 0;
-        const int64_t kbase = chunk * CHUNK + (int64_t)wave * CT * 32;
-
-        f32x16 acc[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[c][q] = 0.0f;
-
-        // oracle-order |x|^2: precomputed for whole-batch passes, computed per lane on the (rare) last-resort path
+        const int64_t k = chunk * CHUNK + (int64_t)wave * 32 + j;     // this lane's A row (code)
+        const bool kvalid = k < K;
+        const float *erow = e + (kvalid ? k : 0) * D;
+        // oracle-order |x|^2: precomputed by the token-side kernel, computed per lane otherwise
         const float xn = (VQ_IS_L2(metric) && rvalid) ? (xn_in ? xn_in[row] : sqnorm_thread<DT>(x, row * D, D)) : 0.0f;
-        for (int db = 0; db < D; db += DB) {
-            // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
-            float xfr[DB / 2];
+
+        // piece = 4 consecutive dims of a row, as fp32, at a clamped address: no branch between the requests
+        auto x_piece = [&](int d) -> float4 {
+            const int64_t off = row * D + (d < D ? d : 0);
+            if (DT == 0) return *(const float4 *)((const float *)x + off);
+            const uint2 t = *(const uint2 *)((const uint16_t *)x + off);
+            return float4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xFFFF0000u),
+                          __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xFFFF0000u)};
+        };
+        auto e_piece = [&](int d) -> float4 { return *(const float4 *)(erow + (d < D ? d : 0)); };
+        float4 xr[RING][8], er[RING][8];
 #pragma unroll
-            for (int s4 = 0; s4 < DB / 4; ++s4) {      // 4 consecutive dims per load
-                int d = db + 4 * s4;
-                float v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                if (rvalid && d < D) {
-                    if (DT == 0) {
-                        if (d + 3 < D && (D % 4) == 0) {
-                            float4 t = *(const float4 *)((const float *)x + row * D + d);
-                            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
-                        } else {
-                            v0 = load_elem<DT>(x, row * D + d);
-                            if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
-                            if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
-                            if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
-                        }
-                    } else if (d + 3 < D && (D % 4) == 0) {
-                        uint2 t = *(const uint2 *)((const uint16_t *)x + row * D + d);
-                        v0 = __uint_as_float(t.x << 16); v1 = __uint_as_float(t.x & 0xFFFF0000u);
-                        v2 = __uint_as_float(t.y << 16); v3 = __uint_as_float(t.y & 0xFFFF0000u);
-                    } else {
-                        v0 = load_elem<DT>(x, row * D + d);
-                        if (d + 1 < D) v1 = load_elem<DT>(x, row * D + d + 1);
-                        if (d + 2 < D) v2 = load_elem<DT>(x, row * D + d + 2);
-                        if (d + 3 < D) v3 = load_elem<DT>(x, row * D + d + 3);
-                    }
-                }
-                xfr[2 * s4] = sx * (h ? v1 : v0);
-                xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
+        for (int u = 0; u < RING; ++u) {
+            if (u < nb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { xr[u][i] = x_piece(32 * u + 4 * i); er[u][i] = e_piece(32 * u + 4 * i); }
             }
+        }
+        f32x16 acc;
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int64_t k = kbase + c * 32 + j;         // this lane's A row (code)
-                const bool kvalid = k < K;
-                const float *erow = e + (kvalid ? k : 0) * D;
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        for (int b0 = 0; b0 < nb; b0 += RING) {
 #pragma unroll
-                for (int s4 = 0; s4 < DB / 4; ++s4) {
-                    int d = db + 4 * s4;
-                    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-                    if (d < D) {
-                        if (d + 3 < D && (D % 4) == 0) {
-                            float4 t = *(const float4 *)(erow + d);
-                            a0 = t.x; a1 = t.y; a2 = t.z; a3 = t.w;
-                        } else {
-                            a0 = erow[d];
-                            if (d + 1 < D) a1 = erow[d + 1];
-                            if (d + 2 < D) a2 = erow[d + 2];
-                            if (d + 3 < D) a3 = erow[d + 3];
-                        }
-                        if (!kvalid) { a0 = a1 = a2 = a3 = 0.0f; }
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1 : a0, xfr[2 * s4], acc[c], 0, 0, 0);
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a3 : a2, xfr[2 * s4 + 1], acc[c], 0, 0, 0);
+            for (int u = 0; u < RING; ++u) {
+                const int b = b0 + u;
+                if (b < nb) {
+                    __builtin_amdgcn_sched_barrier(0);   // requests stay where they are written (hipcc sinks them to their uses)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int d = 32 * b + 4 * i;
+                        // a whole piece past D is all zeros: +0 (or -0) added to an accumulator that is never -0 changes nothing
+                        const bool okx = rvalid && d < D, oke = kvalid && d < D;
+                        const float4 xv = xr[u][i], ev = er[u][i];
+                        const float b0v = sx * (okx ? (h ? xv.y : xv.x) : 0.0f), b1v = sx * (okx ? (h ? xv.w : xv.z) : 0.0f);
+                        const float a0v = oke ? (h ? ev.y : ev.x) : 0.0f, a1v = oke ? (h ? ev.w : ev.z) : 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0v, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1v, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b + RING < nb) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { xr[u][i] = x_piece(32 * (b + RING) + 4 * i); er[u][i] = e_piece(32 * (b + RING) + 4 * i); }
                     }
                 }
             }
@@ -104,43 +94,26 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
 
         // epilogue: C[code row][token col j]
         u64 best = ~0ull;
+        const int64_t kbase = chunk * CHUNK + (int64_t)wave * 32;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t k = kbase + c * 32 + mfma_row(q, h);
-                float d;
-                if (VQ_IS_L2(metric)) {
-                    const float enk = (k < K) ? en_in[k] : 0.0f;
-                    float t = VQ_SWAPPED(metric) ? (acc[c][q] + enk) + xn : (acc[c][q] + xn) + enk;
-                    t = (t < 0.0f) ? 0.0f : t;
-                    d = sqrtf(t);
-                } else {
-                    d = cos_distance(acc[c][q], metric);
-                }
-                if (MODE == 0) {
-                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
-                } else if (MODE == 1) {
-                    // column argmin: reduce over the 32 token lanes of this half, one atomic per code
-                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {
-                        u64 o = __shfl_xor(key, off, 64);
-                        key = o < key ? o : key;
-                    }
-                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
-                } else {
-                    if (rvalid && k < K) dout[row * K + k] = d;
-                }
+        for (int q = 0; q < 16; ++q) {
+            const int64_t kq = kbase + mfma_row(q, h);
+            float d;
+            if (VQ_IS_L2(metric)) {
+                const float enk = (kq < K) ? en_in[kq] : 0.0f;
+                float t = VQ_SWAPPED(metric) ? (acc[q] + enk) + xn : (acc[q] + xn) + enk;
+                t = (t < 0.0f) ? 0.0f : t;
+                d = sqrtf(t);
+            } else {
+                d = cos_distance(acc[q], metric);
             }
+            if (kq < K) { u64 key = dist_key(d, (uint32_t)kq); best = key < best ? key : best; }
         }
-        if (MODE == 0) {
-            u64 o = __shfl_xor(best, 32, 64);
-            best = o < best ? o : best;
-            if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
-        }
+        u64 o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
     }
-    if (MODE == 0 && ticket != nullptr && nrows > 0) {
+    if (ticket != nullptr && nrows > 0) {
         // arrival counter (MI355X guide, Guideline 16): the key atomics execute at the memory side; every wave drains
         // its own, the workgroup meets, one lane publishes; whoever draws the last ticket reads the keys with loads that
         // bypass its L1 (agent-scope relaxed atomic loads)
@@ -157,9 +130,9 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
             for (int64_t i = threadIdx.x; i < nrows; i += blockDim.x) {
                 const int64_t r = (int64_t)row_list[i];
                 const u64 key = __hip_atomic_load(&keys[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t k = (uint32_t)(key & 0xFFFFFFFFull);
-                fin_idx[r] = (int64_t)k;
-                if (fin_hist) atomicAdd(&fin_hist[k], 1);
+                const uint32_t kk = (uint32_t)(key & 0xFFFFFFFFull);
+                fin_idx[r] = (int64_t)kk;
+                if (fin_hist) atomicAdd(&fin_hist[kk], 1);
             }
         }
     }
