@@ -134,6 +134,30 @@ def test_nonfinite_inputs(ops):
     np.testing.assert_array_equal(ops.argmin(xq, cb).cpu().numpy(), z['quant_cos'].astype(np.int64))
 
 
+def test_sqrt_buckets_tie_to_the_lowest_index(ops):
+    """Distinct radicands whose square roots round to the same float tie (torch.cdist takes the root before argmin compares),
+    and the winner is the LOWEST index even if its radicand is the larger one.  The all-fp32 route compares radicands first
+    (vqhip_exact_kernels.h): this is the case it must hand to its exact loop.  Rows of zeros make the radicand |e_k|^2:
+    code `hi` = (1.25, 0, ...) has 1.5625, code `lo` = (1.25, 2^-11.5, 0, ...) the next float above it; both roots are 1.25."""
+    K, D, lo, hi = 300, 8, 17, 211
+    rng = np.random.default_rng(5)
+    w = (3.0 + rng.random((K, D))).astype(np.float32)                        # every other code is far away
+    w[lo] = 0; w[hi] = 0
+    w[hi, 0] = 1.25
+    w[lo, 0] = 1.25; w[lo, 1] = np.float32(2.0 ** -11.5)
+    x = np.zeros((5, D), np.float32)
+    d = co.l2_dist(x[:1], w)[0]
+    en = (w[[lo, hi]].astype(np.float64) ** 2).sum(1)
+    assert en[0] > en[1] and d[lo] == d[hi] == np.float32(1.25)              # larger radicand, same float distance
+    ref = co.l2_argmin(x, w)
+    assert (ref == lo).all()
+    np.testing.assert_array_equal(ops.argmin_exact(dev(x), dev(w), 'L2').cpu().numpy(), ref)
+    np.testing.assert_array_equal(ops.argmin(dev(x), ops.prepare_codebook(dev(w), 'L2')).cpu().numpy(), ref)
+    # and with the roles of the indices swapped the smaller radicand is also the lower index
+    w[[lo, hi]] = w[[hi, lo]]
+    np.testing.assert_array_equal(ops.argmin_exact(dev(x), dev(w), 'L2').cpu().numpy(), co.l2_argmin(x, w))
+
+
 @pytest.mark.parametrize('metric', ['L2', 'Cosine'])
 def test_distance_matrix_and_col_argmin(ops, metric):
     x, w = synth.make_inputs('normal', 77, 200, 333, 32)

@@ -22,7 +22,7 @@ res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 res['_shape'] = sys.argv[2]
 json.dump(res, open(out + '/pmc_stalls.json', 'w'), indent=1)
 for k, d in res.items():
-    if 'coarse' in k:
+    if 'coarse' in k or 'exact_tiled' in k:
         print(k)
         for c in sorted(d): print(f'   {c:32s} {d[c]:16.1f}')
 PY

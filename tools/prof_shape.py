@@ -14,6 +14,9 @@ x = torch.randn(N, D, device='cuda', generator=g)
 if metric == 'Cosine':
     x = ops.normalize_rows(x)
 for _ in range(reps):
+    if os.environ.get('VQ_PROF_EXACT'):            # the all-fp32 route instead
+        idx = ops.argmin_exact(x, w, metric)
+        continue
     cb = ops.prepare_codebook(w, metric)
     idx = ops.argmin(x, cb)
 torch.cuda.synchronize()

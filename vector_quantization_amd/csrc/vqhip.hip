@@ -304,16 +304,18 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
 template <int MODE>
 static int run_exact_tiled(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K,
                            int D, int metric, u64 *keys, float *dout, hipStream_t s) {
-    constexpr int LDS = 2 * 32 * 128 * 4;
-    auto k0 = exact_tiled_kernel<0, MODE>;
-    auto k1 = exact_tiled_kernel<1, MODE>;
-    static LdsCache set0, set1;
-    if (int rc = ensure_dyn_lds((const void *)k0, LDS, set0)) return rc;
-    if (int rc = ensure_dyn_lds((const void *)k1, LDS, set1)) return rc;
+    constexpr int LDS = 2 * 32 * 128 * 4 + 8 * 32 * 4;      // two staged tiles + the |e|^2 of an item's 256 codes
+    static LdsCache sets[4];
+    const void *kerns[4] = {(const void *)exact_tiled_kernel<0, MODE, false>, (const void *)exact_tiled_kernel<1, MODE, false>,
+                            (const void *)exact_tiled_kernel<0, MODE, true>, (const void *)exact_tiled_kernel<1, MODE, true>};
+    const int bf = x_dtype == VQHIP_DTYPE_F32 ? 0 : 1, v4 = (D % 4 == 0) ? 2 : 0;
+    if (int rc = ensure_dyn_lds(kerns[v4 + bf], LDS, sets[v4 + bf])) return rc;
     int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
     int grid = (int)(items < 1024 ? items : 1024);
-    if (x_dtype == VQHIP_DTYPE_F32) k0<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
-    else k1<<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+#define VQ_TILED(DT, V4) exact_tiled_kernel<DT, MODE, V4><<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout)
+    if (v4) { if (bf) VQ_TILED(1, true); else VQ_TILED(0, true); }
+    else { if (bf) VQ_TILED(1, false); else VQ_TILED(0, false); }
+#undef VQ_TILED
     VQ_CHECK_LAUNCH("exact_tiled_kernel");
     return VQHIP_OK;
 }
@@ -1196,4 +1198,5 @@ int vqhip_profile_collect(double *ms_sum, int64_t *launches) {
 }
 
 }  // extern "C"
+
 

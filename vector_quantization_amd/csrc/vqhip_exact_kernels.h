@@ -4,6 +4,12 @@
 // ------------------------------------------------------------------------------------------------
 // exact fp32 MFMA pass (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain)
 // ------------------------------------------------------------------------------------------------
+// Row argmin, L2: a lane meets its codes in increasing index order, so a later code can only replace the lane's best with a
+// STRICTLY smaller distance; sqrt is correctly rounded, hence monotone: radicand t >= tb (the smallest radicand the lane has
+// keyed) implies sqrt(t) >= sqrt(tb) and the code cannot win — its sqrt and key (the larger half of the epilogue's
+// instructions) are skipped.  NaN radicands never compare >= and always go through (NaN sorts first in dist_key).
+__device__ __forceinline__ bool l2_skip(float t, float tb) { return t >= tb; }
+
 // Last-resort path of vqhip_argmin: a few LISTED rows against the whole codebook, row argmin via 64-bit atomicMin keys[row].
 // Work item = (tile of 32 listed rows, chunk of 128 codes: one 32-code tile per wave); persistent grid-stride loop over items.
 // A lane owns one latent row (as B operand: row j, k-parity h) and one code row (A operand) and walks them in batches of 32
@@ -94,6 +100,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
 
         // epilogue: C[code row][token col j]
         u64 best = ~0ull;
+        float tb = INFINITY;                     // smallest radicand this lane has turned into a key (see l2_skip)
         const int64_t kbase = chunk * CHUNK + (int64_t)wave * 32;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -103,7 +110,9 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                 const float enk = (kq < K) ? en_in[kq] : 0.0f;
                 float t = VQ_SWAPPED(metric) ? (acc[q] + enk) + xn : (acc[q] + xn) + enk;
                 t = (t < 0.0f) ? 0.0f : t;
+                if (l2_skip(t, tb)) continue;
                 d = sqrtf(t);
+                if (kq < K) tb = fminf(tb, t);
             } else {
                 d = cos_distance(acc[q], metric);
             }
@@ -142,7 +151,11 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
 // tiles.  Code tiles are staged through LDS once per workgroup (coalesced float4 loads, register prefetch of the next
 // tile, 16-byte XOR swizzle -> conflict-free ds_read_b128) and shared by the 4 waves; accumulators of all CT tiles stay
 // live so that the row fragments are loaded once per 256-dim block.  Same k-ordered fma chains as exact_kernel.
-template <int DT, int MODE>
+// VEC4 (D % 4 == 0): operands move as whole 16-byte pieces at clamped addresses with zeros selected in past D / K, and the only
+// branches are one per group of 8 pieces (32 dims) — straight-line groups of 16 MFMAs.  The element-wise tail form (any D) is
+// a separate instantiation: in one kernel its per-piece conditions put every MFMA pair into a basic block of its own and
+// hipcc hoisted some 250 loop-invariant comparisons in front of the item loop (25 000 instructions, 1 150 v_readlane).
+template <int DT, int MODE, bool VEC4>
 __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict__ x, const float *__restrict__ e,
                                                           const float *__restrict__ en_in, const float *__restrict__ xn_in,
                                                           int64_t N, int64_t K, int D, int metric, u64 *__restrict__ keys,
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
     constexpr int NPRE = 32 * (DB / 4) / 256;    // 16-byte chunks of a tile per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float4 *tile = (float4 *)lds;                // [2][32 rows][DB/4 chunks], chunk index XOR (row & 15)
+    float4 *en_lds = tile + 2 * 32 * (DB / 4);   // |e_k|^2 of the item's CT * 32 codes (L2), parked at the start of the item
     constexpr int CPR = DB / 4;                  // chunks per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -165,6 +179,16 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
         const bool rvalid = row < N;
         const int64_t rrow = rvalid ? row : N - 1;
         const int64_t kbase = chunk * CT * 32;
+        // |e_k|^2 of the item's codes: one 16-byte piece per thread, requested here, parked in LDS behind the first barrier
+        // below (the previous item's epilogue may still be reading) and read by the epilogue behind the barriers of the tile
+        // loop — by then the round trip is long over (requested in the epilogue itself, a tile ahead, the norms cost 8 exposed
+        // round trips per item).  en_in holds (K + 63) / 64 * 64 floats (vq_ws_layout).
+        const bool en_owner = VQ_IS_L2(metric) && (int)threadIdx.x < CT * 8;
+        float4 en_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (en_owner) {
+            const int64_t k0 = kbase + 4 * (int)threadIdx.x, kpad = (K + 63) / 64 * 64;
+            en_pre = *(const float4 *)(en_in + (k0 < kpad ? k0 : 0));
+        }
         f32x16 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
@@ -174,6 +198,51 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
         for (int db = 0; db < D; db += DB) {
             // B fragments: lane (row j, k-parity h) holds sx * x[row][db + 2s + h], s = 0..DB/2-1
             float xfr[DB / 2];
+            if constexpr (VEC4) {
+                // every piece of the block requested before the first one is used (a group that waited for its own 8 loads
+                // before the next group's went out cost 17 000 cycles per block, profiles/r03_exact_rows.txt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {       // two passes of 16 pieces (64 registers of requests in flight)
+                    float4 xp[DB / 8];
+#pragma unroll
+                    for (int g = 0; g < DB / 64; ++g) {
+                        if (db + 32 * (2 * half + g) < D) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int s4 = 8 * (2 * half + g) + i, d = db + 4 * s4;
+                                const int64_t off = rrow * D + (d < D ? d : 0);
+                                if (DT == 0) {
+                                    xp[8 * g + i] = *(const float4 *)((const float *)x + off);
+                                } else {
+                                    const uint2 t = *(const uint2 *)((const uint16_t *)x + off);
+                                    xp[8 * g + i] = float4{__uint_as_float(t.x), __uint_as_float(t.y), 0.0f, 0.0f};
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < DB / 64; ++g) {
+                        if (db + 32 * (2 * half + g) < D) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int s4 = 8 * (2 * half + g) + i, d = db + 4 * s4;
+                                const float4 p = xp[8 * g + i];
+                                float v0, v1, v2, v3;
+                                if (DT == 0) {
+                                    v0 = p.x; v1 = p.y; v2 = p.z; v3 = p.w;
+                                } else {
+                                    const uint32_t t0 = __float_as_uint(p.x), t1 = __float_as_uint(p.y);
+                                    v0 = __uint_as_float(t0 << 16); v1 = __uint_as_float(t0 & 0xFFFF0000u);
+                                    v2 = __uint_as_float(t1 << 16); v3 = __uint_as_float(t1 & 0xFFFF0000u);
+                                }
+                                xfr[2 * s4] = sx * (d < D ? (h ? v1 : v0) : 0.0f);
+                                xfr[2 * s4 + 1] = sx * (d < D ? (h ? v3 : v2) : 0.0f);
+                            }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int s4 = 0; s4 < DB / 4; ++s4) {
                 const int d = db + 4 * s4;
@@ -198,6 +267,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                 xfr[2 * s4] = sx * (h ? v1 : v0);
                 xfr[2 * s4 + 1] = sx * (h ? v3 : v2);
             }
+            }
             // staging: thread t owns the 16-byte chunks t, t+256, ... of the 32 x DB tile
             float4 pre[NPRE];
             auto fetch = [&](int ct) {
@@ -208,7 +278,10 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                     const int64_t k = kbase + ct * 32 + r;
                     const int d = db + 4 * ch;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < K && d < D) {
+                    if constexpr (VEC4) {
+                        const float4 t = *(const float4 *)(e + (k < K ? k : 0) * D + (d < D ? d : 0));
+                        if (k < K && d < D) v = t;
+                    } else if (k < K && d < D) {
                         if (d + 3 < D && (D % 4) == 0) v = *(const float4 *)(e + k * D + d);
                         else {
                             v.x = e[k * D + d];
@@ -229,6 +302,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                 }
             };
             __syncthreads();            // previous block / item is done with both buffers
+            if (db == 0 && en_owner) en_lds[threadIdx.x] = en_pre;
             fetch(0);
             stash(0);
             __syncthreads();
@@ -236,6 +310,21 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
             for (int ct = 0; ct < CT; ++ct) {
                 if (ct + 1 < CT) fetch(ct + 1);
                 const float4 *trow = tile + ((ct & 1) * 32 + j) * (DB / 4);
+                if constexpr (VEC4) {
+                    // zero pieces past D (both operands) add +-0 to accumulators that are never -0: the chain is unchanged
+#pragma unroll
+                    for (int g = 0; g < DB / 32; ++g) {
+                        if (db + 32 * g < D) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int q = 8 * g + i;
+                                const float4 v = trow[q ^ (j & 15)];
+                                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.y : v.x, xfr[2 * q], acc[ct], 0, 0, 0);
+                                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < DB / 4; ++q) {
                     if (db + 4 * q < D) {
@@ -244,6 +333,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                         acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
                     }
                 }
+                }
                 if (ct + 1 < CT) stash((ct + 1) & 1);
                 __syncthreads();
             }
@@ -251,14 +341,80 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
 
         const float xn = (VQ_IS_L2(metric) && rvalid) ? xn_in[row] : 0.0f;
         u64 best = ~0ull;
+        // this lane's code of accumulator element (c, q) is kb + (32 c + mfma_row(q, 0)): a constant offset from a per-item
+        // value that the compiler must not see through — it otherwise hoists the 128 sums `4 h + offset` out of the item loop
+        // and keeps (spills) them: 115 registers stored at kernel entry, one scratch load per element
+        int64_t kb = kbase + 4 * h;
+        asm volatile("" : "+v"(kb));
+        // |e_k|^2 of the lane's 16 codes of a tile: four runs of four codes, four 16-byte LDS reads (en_lds above)
+        float enr[2][16];
+        auto request_en = [&](int c, float (&dst)[16]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = en_lds[c * 8 + 2 * g + h];
+                dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+            }
+        };
+        if (VQ_IS_L2(metric)) request_en(0, enr[0]);
+        if (MODE == 0 && VQ_IS_L2(metric)) {
+            // Row argmin, L2, in the radicands: sqrt is correctly rounded, hence monotone, so the winner is the lowest-index
+            // code among those whose sqrt rounds to sqrt(t_min) — all of them have t <= t_min (1 + 2^-21) (the bucket of a
+            // float d ends below d^2 (1 + 2^-24)^2 and t_min >= d^2 (1 - 2^-24)^2).  One pass keeps the lane's smallest
+            // radicand with its (lowest) index and the second smallest value (6 VALU per code); a runner-up above the
+            // threshold (the rule) means ONE sqrt and key per lane, anything else (near-ties, equal radicands, NaN: they
+            // land in the runner-up) sends the wave through the exact per-code loop.  (Per-code sqrt + key + 64-bit minimum
+            // were 28 % of the kernel: with 64 lanes a per-lane "cannot win" test still runs the expensive block at most
+            // steps, profiles/r03_exact_rows.txt.)
+            float tmin = INFINITY, t2 = INFINITY;
+            uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int64_t k = kb + (c * 32 + mfma_row(q, 0));
+                    float t = (acc[c][q] + xn) + ((k < K) ? enr[c & 1][q] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    t = (k < K) ? t : INFINITY;                       // codes that do not exist: never first, never a near-tie
+                    const bool upd = t < tmin;
+                    t2 = fminf(t2, (k < K) ? fmaxf(t, tmin) : INFINITY);   // NaN: fmaxf returns tmin -> flagged below
+                    kmin = upd ? (uint32_t)k : kmin;
+                    tmin = upd ? t : tmin;
+                }
+            }
+            const bool unique = t2 > tmin * (1.0f + 0x1p-21f);       // (inf > inf is false: a lane of equal / all-NaN radicands is not unique)
+            // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
+            if (__any(kmin != 0xFFFFFFFFu ? !unique : kb < K)) {
+                float xn2 = xn;
+                asm volatile("" : "+v"(xn2));     // the radicands are computed AGAIN here: sharing them with the pass above would keep 128 values alive
+                request_en(0, enr[0]);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int64_t k = kb + (c * 32 + mfma_row(q, 0));
+                        float t = (acc[c][q] + xn2) + ((k < K) ? enr[c & 1][q] : 0.0f);
+                        t = (t < 0.0f) ? 0.0f : t;
+                        if (k < K) { const u64 key = dist_key(sqrtf(t), (uint32_t)k); best = key < best ? key : best; }
+                    }
+                }
+            } else if (kmin != 0xFFFFFFFFu) {
+                best = dist_key(sqrtf(tmin), kmin);
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
+            if (VQ_IS_L2(metric) && c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int64_t k = kbase + c * 32 + mfma_row(q, h);
+                const int64_t k = kb + (c * 32 + mfma_row(q, 0));
                 float d;
                 if (VQ_IS_L2(metric)) {
-                    float t = (acc[c][q] + xn) + ((k < K) ? en_in[k] : 0.0f);
+                    float t = (acc[c][q] + xn) + ((k < K) ? enr[c & 1][q] : 0.0f);
                     t = (t < 0.0f) ? 0.0f : t;
                     d = sqrtf(t);
                 } else {
