@@ -391,11 +391,12 @@ def test_empty_and_ragged(ops):
         np.testing.assert_array_equal(ops.argmin(dev(x), cb).cpu().numpy(), co.l2_argmin(x, w.cpu().numpy()))
 
 
-@pytest.mark.parametrize('D', [8, 12, 16, 24, 64, 128, 512, 520, 640, 768, 776, 1024, 1032])
+@pytest.mark.parametrize('D', [6, 8, 12, 16, 24, 30, 64, 128, 254, 512, 520, 640, 768, 776, 1024, 1030, 1032])
 @pytest.mark.parametrize('metric', ['L2', 'Cosine'])
 def test_all_supported_dims(ops, D, metric):
     """Every padded-D instantiation of the proposal kernel (k-steps of 16: 2..32 pipelined, 48 and 64 with one tile per
-    stage) and the fp32-only route (D % 8 != 0 or D > 1024)."""
+    stage) and the fp32-only route (D % 8 != 0 or D > 1024) in both of its forms (D % 4 == 0: whole 16-byte pieces; any D:
+    element-wise tails); the all-fp32 route itself on every D as well."""
     N, K = 700, 1500
     x, w = synth.make_inputs('normal', 100 + D, N, K, D)
     if metric == 'Cosine':
@@ -406,6 +407,8 @@ def test_all_supported_dims(ops, D, metric):
         xq = dev(x)
     cb = ops.prepare_codebook(dev(w), metric)
     np.testing.assert_array_equal(ops.argmin(xq, cb).cpu().numpy(), ref)
+    wq = ops.normalize_rows(dev(w)) if metric == 'Cosine' else dev(w)
+    np.testing.assert_array_equal(ops.argmin_exact(xq, wq, metric).cpu().numpy(), ref)
 
 
 def test_large_batch_many_slices_and_single_slice(ops):

@@ -7,7 +7,10 @@ import torch
 from vector_quantization_amd import ops
 
 def timeit(fn, reps=20, warm=3):
-    for _ in range(warm): fn()
+    # (a first untimed pass of the same length: the first time a process has this many launches in flight the HIP runtime
+    #  grows its pools and the HOST spends ~2 ms per call for a few dozen calls — seen as a 4x slower quantize() on whichever
+    #  configuration came first, tools history in profiles/r03_shapes.txt)
+    for _ in range(max(warm, reps)): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps

@@ -14,7 +14,7 @@ q = build_quantizer(dict(type='VQGANQuantizer', embedding=dict(type='torch_nn_mo
                          distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
 q.init_weights(Config(type='vqgan')); q = q.cuda().eval()
 def timeit(fn, reps=30, warm=5):
-    for _ in range(warm): fn()
+    for _ in range(max(warm, reps)): fn()     # same queue depth once untimed: see tools/bench_shapes.py
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
