@@ -100,6 +100,10 @@ static std::atomic<int> g_tune_slices{0};   // proposal-kernel knob for A/B meas
 // launch saves), so the stand-alone launch stays the default; results are identical either way.
 // (2 = only where ONE slice covers the codebook: the workgroup then decides its own tokens, no ticket and no fence involved)
 static std::atomic<int> g_tune_fused_decide{2};
+// mode 2: the proposal kernel runs the decision stage itself where one slice covers the codebook, and for small batches
+// whatever the slice count (a launch less on a chain of ~5 us launches: 12 images -2.6 %, 32 images -0.5 %, tools/ab_small_batch.py;
+// at 256 images and more the last-arriving workgroup's merge is the longer tail)
+#define VQ_FUSED_DECIDE_MAX_N 16384
 static std::atomic<int> g_tune_w32{1};      // key 11: 0 = D <= 16 keeps the 16x16x32 proposal kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
@@ -230,7 +234,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         const int tpb = (ns == 1) ? balanced_tiles_per_block(N, (W) * (TT)) : (W) * (TT);           \
         const int fmode = g_tune_fused_decide.load();                                               \
         VqDecideOut dsel = dec;                                                                     \
-        if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;                            \
+        if (!(fmode == 1 || (fmode == 2 && (ns == 1 || N <= VQ_FUSED_DECIDE_MAX_N)))) dsel.idx = nullptr;                            \
         *fused_decide_out = dsel.idx != nullptr ? 1 : 0;                                            \
         return launch_coarse_cfg<NS, TT, W, __VA_ARGS__>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s); \
     }
@@ -255,7 +259,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
                     tpb = (tpb + 1) & ~1;                                           // whole wide tiles
                     const int fmode = g_tune_fused_decide.load();
                     VqDecideOut dsel = dec;
-                    if (!(fmode == 1 || (fmode == 2 && ns == 1))) dsel.idx = nullptr;
+                    if (!(fmode == 1 || (fmode == 2 && (ns == 1 || N <= VQ_FUSED_DECIDE_MAX_N)))) dsel.idx = nullptr;
                     *fused_decide_out = dsel.idx != nullptr ? 1 : 0;
 #define VQ_CFG32(TTW, NOAUXV, KSV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV, KSV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s)
                     if (L.D <= 16) {

@@ -511,7 +511,14 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
                                                   int *__restrict__ counters, int *__restrict__ arrive, int narrive,
                                                   float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero,
                                                   int64_t hw = 0, void *__restrict__ xrows = nullptr) {
-    if ((int)blockIdx.x < nblk_stats) cb_stats_body(blockIdx.x, e, K, D, metric, cb, L);
-    else x_prep_body<DT, XNORM, NCHW>((int64_t)blockIdx.x - nblk_stats, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
-                                      VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)gridDim.x - nblk_stats, hw, xrows);
+    // the smaller of the two groups of workgroups goes FIRST in the grid: dispatched behind the larger one it starts when that
+    // one drains and its own latency (a chain of round trips either way) is added to the kernel — at 3072 tokens against 1024
+    // statistics workgroups the token side started ~8 us into a 16 us kernel
+    const int xgrid = (int)gridDim.x - nblk_stats;
+    const bool x_first = xgrid < nblk_stats;
+    const int b = (int)blockIdx.x;
+    const bool is_x = x_first ? b < xgrid : b >= nblk_stats;
+    if (!is_x) cb_stats_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
+    else x_prep_body<DT, XNORM, NCHW>((int64_t)(x_first ? b : b - nblk_stats), x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
+                                      VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows);
 }
