@@ -28,15 +28,20 @@ from torch import nn
 
 
 class _Step(nn.Module):
-    """forward(x) -> (z, loss, quant): the quantizer call with a fresh memo, tensors only (what graph capture wants)."""
+    """forward(x) -> (z, loss): the quantizer call with a fresh memo, tensors only (what graph capture wants).  The tokens
+    are not a differentiable output: handed back through ``make_graphed_callables`` they would make autograd materialise a
+    zero "gradient" for them at every backward (one more fill kernel per step); they are kept as ``last_quant`` instead — the
+    captured step's own output tensor (graph pool memory, kept alive by this reference), rewritten by every replay."""
 
     def __init__(self, quantizer: nn.Module) -> None:
         super().__init__()
         self.quantizer = quantizer
+        self.last_quant: Optional[torch.Tensor] = None
 
     def forward(self, x: torch.Tensor):
         z, loss, memo = self.quantizer(x, {})
-        return z, loss, memo['quant']
+        self.last_quant = memo['quant']
+        return z, loss
 
 
 class GraphedQuantizer(nn.Module):
@@ -68,7 +73,7 @@ class GraphedQuantizer(nn.Module):
         self._train = quantizer.training
         self._shape, self._dtype = tuple(sample_x.shape), sample_x.dtype
         saved = {k: v.detach().clone() for k, v in quantizer.state_dict().items()}
-        step = _Step(quantizer)
+        step = self._step = _Step(quantizer)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         from . import ops
         with ops.owned_mse_scratch(self._mse_scratch):
@@ -85,7 +90,8 @@ class GraphedQuantizer(nn.Module):
                 torch.cuda.current_stream().wait_stream(side)
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph), torch.no_grad():
-                    self._out = step(self._x)
+                    z, loss = step(self._x)
+                    self._out = (z, loss, step.last_quant)
         with torch.no_grad():                                    # undo the side effects of warm-up and capture
             for k, v in quantizer.state_dict().items():
                 v.copy_(saved[k])
@@ -94,7 +100,8 @@ class GraphedQuantizer(nn.Module):
         if tuple(x.shape) != self._shape or x.dtype != self._dtype:
             raise ValueError(f'graph captured for {self._shape} {self._dtype}, got {tuple(x.shape)} {x.dtype}')
         if self._train:
-            return self._call(x)
+            z, loss = self._call(x)
+            return z, loss, self._step.last_quant
         self._x.copy_(x)
         self._graph.replay()
         return self._out
