@@ -293,12 +293,23 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
 #ifndef VQ_CFG_D768
 #define VQ_CFG_D768 VQ_CFG(48, 2, 8, 1)
 #endif
-#ifndef VQ_CFG_D1024
-#define VQ_CFG_D1024 VQ_CFG(64, 1, 8, 1)
-#endif
         case 32: VQ_CFG_D512
         case 48: VQ_CFG_D768
-        case 64: VQ_CFG_D1024
+        case 64: {
+            // D = 1024, two forms: eight waves x 16 tokens (two waves per SIMD; one 1 KiB LDS read per MFMA), or four waves x 48
+            // tokens (one wave per SIMD with the whole register file: coarse_kernel, PIPE_H; a third of the LDS bytes per flop).
+            // Per unit of work the second is 1.06-1.29x faster (1.013 against 1.095 ms at 65 536 x 8192, 2.71 against 3.22 at
+            // 196 608), but its 192-token workgroups fill the chip in other multiples than the 128-token ones: 16 384 and
+            // 32 768 tokens are faster on the first form, 24 576 and 49 152 on the second (profiles/r03_large_d_experiments.txt).
+            // Whole rounds of 256 workgroups times the work of one, the second form's divided by 1.18, decide.
+            // (At D = 768 the one-wave form with 64 tokens per wave is 1-6 % BEHIND the eight-wave form: not taken.)
+            auto cost = [&](int tokens, double eff) {
+                const int64_t ntb = (N + tokens - 1) / tokens;
+                const int ns = pick_slices(ntb, L.nstages, 2);
+                return (double)((ntb * ns + 255) / 256) * tokens * ((double)L.nstages / ns) / eff;
+            };
+            if (cost(192, 1.18) < cost(128, 1.0)) VQ_CFG(64, 3, 4, 1) else VQ_CFG(64, 1, 8, 1)
+        }
         default: break;
     }
 #undef VQ_CFG

@@ -117,6 +117,9 @@ __device__ __forceinline__ float vmax(float a, float b) {
 #ifndef VQ_REPLAY_BATCH
 #define VQ_REPLAY_BATCH 4      // (8 without aux reads: spills inside the replay loop, 123 instead of 92 us at configs[2])
 #endif
+#ifndef VQ_PIPEH_PF
+#define VQ_PIPEH_PF 3
+#endif
 #ifndef VQ_GROUP_BRANCH_MIN_TT
 #define VQ_GROUP_BRANCH_MIN_TT 4
 #endif

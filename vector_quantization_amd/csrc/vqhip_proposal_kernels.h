@@ -73,6 +73,11 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     static_assert(!GROUPS || FILTER, "group records are a form of the filtered epilogue");
     constexpr bool GBRANCH = TT >= VQ_GROUP_BRANCH_MIN_TT;
     constexpr bool PIPE = (TPS % 2) == 0;                // epilogue of tile t-1 in the MFMA shadow of tile t (ping-pong by parity)
+    // One wave per SIMD (WAVES <= 4: D = 1024 ships with 48 tokens per wave where the two-wave form holds 16 — a third of the
+    // LDS bytes per flop), one tile per stage: the two code halves of a tile run one after the other and each half's epilogue
+    // sits in the MFMA shadow of the next half — the ping-pong of PIPE without a second accumulator set.
+    constexpr bool PIPE_H = (TPS == 1) && (WAVES <= 4);
+    static_assert(!(PIPE_H && (NOAUX || FILTER)), "half-tile ping-pong: plain large-D form only");
     constexpr int NS32 = NSTEP / 2;                      // k-steps of 32 dims
     constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);   // chunks per stage (2 per k-step and tile, + aux)
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
@@ -116,6 +121,21 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
         const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
 #pragma unroll
         for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+    }
+    if constexpr (PIPE_H) {
+        // One wave per SIMD owns 512 registers, 256 of them accumulation registers — which the MFMA reads as operands just as
+        // well.  Left alone, hipcc runs out of the first 256, parks fragments in the second as SPILLS and copies each back
+        // (v_accvgpr_mov) in front of the MFMA that uses it: 4 copies per chunk, and the lone wave became bound by its own
+        // instruction stream (profiles/r03_large_d_experiments.txt).  Told where the fragments live — the upper half of the
+        // token tiles in accumulation registers, the lower half in vector registers — it emits the loop without a copy and
+        // without a spill (500 registers at D = 768 with 64 tokens per wave, 496 at D = 1024 with 48).
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int s = 0; s < NS32; ++s) {
+                if (t >= TT / 2) asm volatile("" : "+a"(xf[t][s]));
+                else asm volatile("" : "+v"(xf[t][s]));
+            }
     }
 
     float b1[TT], b2[TT], th[TT], mg[TT];
@@ -162,6 +182,10 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
 #pragma unroll
             for (int q = 0; q < 4; ++q)   // "previous tile" of the very first tile: never wins (group records: never even registers)
                 accB[c][t][q] = GROUPS ? -INFINITY : -3.0e38f;
+    if constexpr (PIPE_H) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) accA[1][t] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    }
 
     for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
@@ -173,6 +197,42 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
       // the tiles of one stage; WITH_AUX false: accumulators start from the constant 0 (no aux read)
       auto run_stage = [&](auto with_aux_tag) __attribute__((always_inline)) {
         constexpr bool WITH_AUX = decltype(with_aux_tag)::value;
+        if constexpr (PIPE_H) {
+            constexpr int PFH = VQ_PIPEH_PF;                  // A fragments this many chunks (TT MFMAs each) ahead
+            constexpr int TOTALH = 4 * TT;                    // accumulator elements per lane and code half
+            const uint32_t tile = (uint32_t)st;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 a4 = *(const f32x4 *)(aux + (16 * c + 4 * (lane >> 4)) * 4);
+                uint32_t old[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) { accA[c][t] = a4; old[t] = __float_as_uint(b1[t]); }
+                half8 af[PFH + 1];
+#pragma unroll
+                for (int i = 0; i < PFH; ++i) af[i] = *(const half8 *)(base + (2 * i + c) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                for (int s = 0; s < NS32; ++s) {
+                    if (s + PFH < NS32)
+                        af[(s + PFH) % (PFH + 1)] = *(const half8 *)(base + (2 * (s + PFH) + c) * VQ_CHUNK_BYTES + lane * 16);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t)
+                        accA[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s % (PFH + 1)], xf[t][s], accA[c][t], 0, 0, 0);
+#pragma unroll
+                    for (int id = s * TOTALH / NS32; id < (s + 1) * TOTALH / NS32; ++id) {
+                        const int t = id / 4, q = id % 4, e = 4 * (1 - c) + q;
+                        float v = __uint_as_float((__float_as_uint(accA[1 - c][t][q]) & 0xFFFFFFF0u) | (uint32_t)e);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                        b1[t] = vmax(b1[t], v);
+                    }
+                    // the statements of a chunk stay together: under this register pressure hipcc otherwise folds the fragment
+                    // ring into one buffer (ds_read -> s_waitcnt -> MFMAs) and hoists the epilogue out of the MFMA shadow
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const uint32_t tgp = tile - (c == 0 ? 1u : 0u);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
+            }
+        } else
 #pragma unroll
         for (int ti = 0; ti < TPS; ++ti) {
             f32x4 (&cur)[2][TT] = (PIPE && (ti & 1)) ? accB : accA;
@@ -260,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
                     }
                 }
             }
-            if constexpr (!PIPE) {   // large D: one tile per stage, epilogue in place (the SIMD's other wave covers it)
+            if constexpr (!PIPE && !PIPE_H) {   // large D: one tile per stage, epilogue in place (the SIMD's other wave covers it)
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
 #pragma unroll
@@ -291,6 +351,19 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
         // stage requested in this iteration in flight — s_waitcnt vmcnt(pieces) instead of 0 — was measured: 1-3 %
         // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
         __syncthreads();
+    }
+    if (PIPE_H && st1 > st0) {   // drain: second half of the last tile
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const uint32_t old = __float_as_uint(b1[t]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = __uint_as_float((__float_as_uint(accA[1][t][q]) & 0xFFFFFFF0u) | (uint32_t)(4 + q));
+                b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], v);
+                b1[t] = vmax(b1[t], v);
+            }
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+        }
     }
     // drain: epilogue of the last tile (odd parity: TPS is even, so it sits in accB)
     if (PIPE && st1 > st0) {
