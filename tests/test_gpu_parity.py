@@ -411,6 +411,29 @@ def test_all_supported_dims(ops, D, metric):
     np.testing.assert_array_equal(ops.argmin_exact(xq, wq, metric).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('metric', ['L2', 'Cosine'])
+def test_d1024_one_wave_per_simd_form(ops, metric):
+    """D = 1024 has two proposal kernels, chosen per call by whole rounds of workgroups (vqhip.hip, `case 64`): 24 576 rows
+    against 1024 codes is a shape that takes the four-wave form (one wave per SIMD, 48 tokens in registers, fragments pinned
+    half to accumulation and half to vector registers); `test_all_supported_dims` (700 rows) takes the eight-wave form.
+    Every row against the all-fp32 route, a sample against the C oracle."""
+    N, K, D = 24576, 1024, 1024
+    g = torch.Generator(device='cuda').manual_seed(1024)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    x[::97] = w[torch.randint(0, K, (len(range(0, N, 97)),), device='cuda', generator=g)] + 1e-3 * torch.randn(len(range(0, N, 97)), D, device='cuda', generator=g)
+    if metric == 'Cosine':
+        xq, wq = ops.normalize_rows(x), ops.normalize_rows(w)
+    else:
+        xq, wq = x, w
+    idx = ops.argmin(xq, ops.prepare_codebook(w, metric))
+    assert torch.equal(idx, ops.argmin_exact(xq, wq, metric))
+    rows = torch.arange(0, N, 389, device='cuda')
+    xs, wn = x[rows].cpu().numpy(), w.cpu().numpy()
+    ref = co.cos_argmin(xs, wn) if metric == 'Cosine' else co.l2_argmin(xs, wn)
+    np.testing.assert_array_equal(idx[rows].cpu().numpy(), ref)
+
+
 def test_large_batch_many_slices_and_single_slice(ops):
     """Slice counts 1..16 give identical indices (tuning knob 2 forces the split)."""
     from vector_quantization_amd import _lib
