@@ -69,7 +69,7 @@ def parse():
                     help='images per GPU per step (256 tokens each); default 2048 (vqgan), 12 (cvq); '
                          'tokenize: images per step over ALL ranks, default 2048')
     ap.add_argument('--workload', choices=('vqgan', 'cvq', 'tokenize'), default='vqgan')
-    ap.add_argument('--min-seconds', type=float, default=2.0,
+    ap.add_argument('--min-seconds', type=float, default=8.0,
                     help='repeat the K-step block until this much timed GPU work has accumulated (0: one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true', help='skip the parity self-check after the timed region')
@@ -341,6 +341,11 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     rec['collectives_per_step'] = st['calls'] / n_acc
     rec['exchange_bytes_per_step'] = st['bytes'] / n_acc
     rec['collective_ms'] = (st['ms'] / n_acc) if st['ms'] is not None else None
+    from vector_quantization_amd import rccl
+    from vector_quantization_amd.utils import exchanging
+    rec['exchange_route'] = ({**rccl.status(), 'what': 'direct = vqhip_allreduce_packed on the compute stream (own ncclComm, '
+                              'bootstrapped through the torch store); otherwise torch.distributed.all_reduce'}
+                             if exchanging() else None)
     rec['dense_exchange_bytes_per_step'] = 8 * (K + 1) + 4 * K * D if B.world > 1 else 0     # int64[K+1] + fp32[K, D]: the reference's flow
     rec['loss'] = float(out[1].item())
     rec['kernel_ms'] = prof[0] / max(1, prof[1])
@@ -412,10 +417,25 @@ def lib_sha256() -> str:
     return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
 
 
+def _claim_stdout():
+    """stdout carries exactly ONE line, the JSON record: RCCL prints a version banner to stdout when a communicator is
+    created (observed: 'RCCL version : 2.26.6 ... Librccl path : ...'), and any library may do the like.  File descriptor 1
+    is pointed at stderr for the whole run; the returned writer puts the record on the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        sys.stdout.flush()
+        os.write(real, (line + '\n').encode())
+    return emit
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         sys.exit(launch_ranks(args.gpus))          # parent: no torch.cuda / HIP call has been made
+    emit = _claim_stdout()
 
     B = Bench(args)
     torch, dist = B.torch, B.dist
@@ -593,9 +613,11 @@ def main():
         out_line.update(extra)
         if not args.no_cpu_baseline and world == 1:          # reported once, at N=1 (rank 0's host cores)
             out_line['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out_line), flush=True)
+        emit(json.dumps(out_line))
     if B.distributed:
         dist.barrier()
+        from vector_quantization_amd import rccl
+        rccl.shutdown()
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VQHIP_VERSION 300   /* round 3: + sparse CVQ-VAE anchors, packed exchange, checked workspace sizes */
+#define VQHIP_VERSION 400   /* round 4: + the packed all-reduce itself (RCCL on the caller's stream) */
 
 #define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
 #define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
@@ -51,6 +51,7 @@ extern "C" {
 #define VQHIP_OK 0
 #define VQHIP_EINVAL (-22)      /* bad argument (null pointer, unsupported D, ...) */
 #define VQHIP_ELAUNCH (-5)      /* hip launch error */
+#define VQHIP_ERCCL (-71)       /* librccl.so not loadable, or an RCCL call failed (vqhip_last_error carries RCCL's text) */
 
 int vqhip_version(void);
 const char *vqhip_last_error(void); /* host string describing the last non-zero return on this thread */
@@ -219,6 +220,28 @@ int vqhip_cvq_update_rows(float *w, const float *p, const int64_t *rows, const f
 int64_t vqhip_pack_floats(int64_t K, int64_t M, int D);
 int vqhip_pack_counts(const void *hist, int hist_is_int64, int64_t numel, int64_t K, float *packed, void *stream);
 int vqhip_unpack_counts(const float *packed, int64_t K, int64_t *out, void *stream);
+
+/* ---- the collective of that exchange step, on the CALLER'S stream (vqhip_allreduce_packed) ------------
+ * Replaces the reference's per-quantity torch.distributed.all_reduce calls (vq/algorithms/vq/utils.py:34-35,
+ * vqkd/quantizers/callbacks.py:63-64, cvqvae/anchors.py:65-67) by ONE in-place fp32 SUM over the packed buffer, enqueued
+ * by RCCL on the very stream the pack / apply kernels run on: no side stream, no event hop either side, capturable into a
+ * HIP graph with the rest of the step.  libvqhip does not link RCCL: the symbols are resolved at run time from the
+ * librccl.so the process already has (PyTorch-ROCm ships one; two RCCL copies in one process must be avoided) or from
+ * `path`.  These four are HOST-side set-up calls and the only entry points that block or allocate (inside RCCL):
+ *   vqhip_rccl_load(path)            path NULL or "": the librccl.so already mapped into the process, else the loader's
+ *                                    default librccl.so; idempotent.
+ *   vqhip_rccl_unique_id(id)         HOST buffer of VQHIP_RCCL_ID_BYTES; called on ONE rank, the bytes are handed to the
+ *                                    others by whatever the application has (torch.distributed's store here).
+ *   vqhip_rccl_comm_init(&comm, nranks, id, rank)   collective over the ranks; binds the CURRENT HIP device.
+ *   vqhip_rccl_comm_destroy(comm)
+ * vqhip_allreduce_packed: buf[0..floats) += the same range of every other rank, result on every rank; the first
+ *   vqhip_pack_floats(K, M, D) floats of a packed buffer.  Never synchronises. */
+#define VQHIP_RCCL_ID_BYTES 128
+int vqhip_rccl_load(const char *path);
+int vqhip_rccl_unique_id(void *id_host);
+int vqhip_rccl_comm_init(void **comm, int nranks, const void *id_host, int rank);
+int vqhip_rccl_comm_destroy(void *comm);
+int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream);
 
 /* CVQ-VAE with anchors for the codes that can need one (quantizer_callback.py:85-103, NearestAnchor anchors.py:83-84).
  * decay_k == 1.0f — every code in regular use — multiplies the code's anchor by exactly 0.  vqhip_cvq_rows lists, from the

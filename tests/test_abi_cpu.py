@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.vqhip_version() == _lib.ABI_VERSION == 300
+    assert lib.vqhip_version() == _lib.ABI_VERSION == 400
     cb = lib.vqhip_codebook_bytes(16384, 256)
     # fp16 fragment image (K*D*2) + fp32 normalised copy (K*D*4) + norms + aux chunks
     assert cb >= 16384 * 256 * 6 and cb < 16384 * 256 * 7

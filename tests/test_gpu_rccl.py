@@ -1,0 +1,60 @@
+"""RCCL really executes: a world-size-1 `nccl` process group on the one GPU of the box.
+
+The child (tests/rccl_ws1_child.py) is started with `python -m torch.distributed.run --nproc-per-node=1` — a fresh process,
+launched before any GPU call — and sends the CVQ-VAE and VQ-KD training steps through the multi-rank flow
+(VQ_FORCE_EXCHANGE=1): pack -> ONE all-reduce on RCCL -> apply.  Reference call sites: vq/algorithms/vq/utils.py:26-35,
+vqkd/quantizers/callbacks.py:63-64, cvqvae/anchors.py:60-67.  Asserted: codebooks, probabilities and tokens equal the
+no-process-group result bit for bit — with the collective issued by torch.distributed and by libvqhip's own communicator on
+the compute stream (vqhip_allreduce_packed) — one collective per step, and the same through HIP-graph replay with the
+collective inside the capture."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope='module')
+def ws1(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp('rccl') / 'ws1.json')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.pop('VQHIP_ALLREDUCE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'rccl_ws1_child.py'), '--out', out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, f'child failed (rc={res.returncode})\n{res.stdout[-3000:]}\n{res.stderr[-3000:]}'
+    return json.load(open(out))
+
+
+def test_world_size_one_group_runs_on_rccl(ws1):
+    assert ws1['backend'] == 'nccl' and ws1['world'] == 1 and ws1['rccl_ranks'] == 1
+
+
+@pytest.mark.parametrize('kind', ['cvq', 'vqkd'])
+@pytest.mark.parametrize('route', ['torch', 'direct'])
+def test_forced_exchange_equals_the_one_rank_flow(ws1, kind, route):
+    assert ws1[f'{kind}_{route}_bit_identical'] is True
+    assert ws1[f'{kind}_{route}_collectives_per_step'] == 1.0           # ONE packed all-reduce per training step
+    if route == 'direct':
+        st = ws1['status_direct']
+        assert st['direct'] is True and st['error'] is None, st         # libvqhip's own communicator was used
+
+
+@pytest.mark.parametrize('kind', ['cvq', 'vqkd'])
+def test_graph_replay_with_the_collective_captured(ws1, kind):
+    # the direct route puts the collective on the captured stream itself; the torch route is reported alongside
+    assert ws1[f'{kind}_direct_graphed_error'] is None, ws1[f'{kind}_direct_graphed_error']
+    assert ws1[f'{kind}_direct_graphed_bit_identical'] is True

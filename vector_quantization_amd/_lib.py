@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQHIP_LIB') or os.path.join(_HERE, 'libvqhip.so')   # VQHIP_LIB: experiment builds
 
-ABI_VERSION = 300          # VQHIP_VERSION of include/vqhip.h this binding was written against
+ABI_VERSION = 400          # VQHIP_VERSION of include/vqhip.h this binding was written against
 METRIC_L2, METRIC_COS, METRIC_COS_BF16 = 0, 1, 5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
@@ -69,6 +69,11 @@ SIGNATURES = {
     'vqhip_segsum_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
     'vqhip_vq_backward_w_ordered': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp]),
     'vqhip_debug_proposal_scores': (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'vqhip_rccl_load': (_i32, [ctypes.c_char_p]),
+    'vqhip_rccl_unique_id': (_i32, [_vp]),
+    'vqhip_rccl_comm_init': (_i32, [ctypes.POINTER(_vp), _i32, _vp, _i32]),
+    'vqhip_rccl_comm_destroy': (_i32, [_vp]),
+    'vqhip_allreduce_packed': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_profile_enable': (_i32, [_i32]),
     'vqhip_set_tuning': (_i32, [_i32, _i32]),
     'vqhip_profile_collect': (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

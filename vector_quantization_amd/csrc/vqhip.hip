@@ -1189,6 +1189,89 @@ int vqhip_set_tuning(int key, int value) {
     return VQHIP_OK;
 }
 
+// ---- the packed all-reduce on the caller's stream (RCCL resolved at run time; include/vqhip.h) -----------------------
+// libvqhip never links librccl: a process that already holds one (PyTorch-ROCm's) must not get a second copy, and a
+// caller without RCCL must still be able to load the library.  The handful of symbols are looked up once.
+#include <dlfcn.h>
+struct VqRcclId { char bytes[VQHIP_RCCL_ID_BYTES]; };      // ncclUniqueId (rccl.h: 128 opaque bytes), passed by value
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*get_unique_id)(void *) = nullptr;
+    int (*comm_init_rank)(void **, int, VqRcclId, int) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+};
+}  // namespace
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+static const int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32 = 7, ncclSum = 0
+
+static int rccl_fail(const char *what, int rc) {
+    return fail(VQHIP_ERCCL, what, g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error");
+}
+
+int vqhip_rccl_load(const char *path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.handle) return VQHIP_OK;
+    void *h = nullptr;
+    if (path && path[0]) {
+        h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already has
+        for (const char *n : names)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h) return fail(VQHIP_ERCCL, "vqhip_rccl_load: librccl.so not loadable", dlerror());
+    RcclApi api;
+    api.handle = h;
+    api.get_unique_id = (decltype(api.get_unique_id))dlsym(h, "ncclGetUniqueId");
+    api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(h, "ncclCommInitRank");
+    api.comm_destroy = (decltype(api.comm_destroy))dlsym(h, "ncclCommDestroy");
+    api.all_reduce = (decltype(api.all_reduce))dlsym(h, "ncclAllReduce");
+    api.error_string = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
+    if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce || !api.error_string)
+        return fail(VQHIP_ERCCL, "vqhip_rccl_load: librccl.so lacks an nccl* symbol");
+    g_rccl = api;
+    return VQHIP_OK;
+}
+
+int vqhip_rccl_unique_id(void *id_host) {
+    if (!id_host) return fail(VQHIP_EINVAL, "vqhip_rccl_unique_id: null buffer");
+    if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_rccl_unique_id: call vqhip_rccl_load first");
+    static_assert(sizeof(VqRcclId) == 128, "ncclUniqueId is 128 bytes (rccl.h: NCCL_UNIQUE_ID_BYTES)");
+    const int rc = g_rccl.get_unique_id(id_host);
+    return rc == 0 ? VQHIP_OK : rccl_fail("ncclGetUniqueId", rc);
+}
+
+int vqhip_rccl_comm_init(void **comm, int nranks, const void *id_host, int rank) {
+    if (!comm || !id_host || nranks < 1 || rank < 0 || rank >= nranks) return fail(VQHIP_EINVAL, "vqhip_rccl_comm_init: bad argument");
+    if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_rccl_comm_init: call vqhip_rccl_load first");
+    VqRcclId id;
+    memcpy(id.bytes, id_host, sizeof(id.bytes));
+    *comm = nullptr;
+    const int rc = g_rccl.comm_init_rank(comm, nranks, id, rank);
+    return rc == 0 ? VQHIP_OK : rccl_fail("ncclCommInitRank", rc);
+}
+
+int vqhip_rccl_comm_destroy(void *comm) {
+    if (!comm) return VQHIP_OK;
+    if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_rccl_comm_destroy: RCCL not loaded");
+    const int rc = g_rccl.comm_destroy(comm);
+    return rc == 0 ? VQHIP_OK : rccl_fail("ncclCommDestroy", rc);
+}
+
+int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream) {
+    if (!buf || !comm || floats < 0) return fail(VQHIP_EINVAL, "vqhip_allreduce_packed: bad argument");
+    if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_allreduce_packed: RCCL not loaded");
+    if (floats == 0) return VQHIP_OK;
+    const int rc = g_rccl.all_reduce(buf, buf, (size_t)floats, kNcclFloat32, kNcclSum, comm, (hipStream_t)stream);
+    return rc == 0 ? VQHIP_OK : rccl_fail("ncclAllReduce", rc);
+}
+
 int vqhip_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof_on = on != 0;

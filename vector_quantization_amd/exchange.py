@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from .utils import all_reduce_sum, get_world_size
+from .utils import all_reduce_sum, exchanging, get_world_size
 
 MAX_WORLD = 256
 
@@ -27,14 +27,14 @@ def all_reduce_packed(hist: torch.Tensor, numel: int, sums: torch.Tensor) -> Tup
     """SUM over the ranks of (hist int32|int64 [K], numel, sums fp32 [K, D]) in ONE collective.
     Returns (hist int64 [K], numel as a device int64 scalar, sums [K, D]) — no host synchronisation."""
     world = get_world_size()
-    if world > MAX_WORLD:
+    if world > MAX_WORLD:          # callers route such groups through utils.all_reduce_statistics (int64 counts, no rank limit)
         raise RuntimeError(f'packed exchange: exact fp32 count sums hold for up to {MAX_WORLD} ranks, got {world}')
     K, D = sums.shape
     packed = torch.empty(ops.pack_floats(K, K, D), dtype=torch.float32, device=sums.device)
     head = 2 * K + 4
     packed[head:].view(K, D).copy_(sums)
     ops.pack_counts(hist.contiguous(), int(numel), packed)
-    if world > 1:
+    if exchanging():
         all_reduce_sum(packed)
     counts = ops.unpack_counts(packed, K)
     return counts[:K], counts[K], packed[head:].view(K, D)

@@ -16,7 +16,7 @@ import torch.distributed as dist
 from .. import exchange, ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
-from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, gather_to_rank0, get_rank,
+from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, exchanging, gather_to_rank0, get_rank,
                      get_world_size, is_sync)
 from .anchors import NearestAnchor
 from .distances import LazyDistance
@@ -226,8 +226,11 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
         K = self.vector_quantizer.codebook_size
         hist = ops.hist(quant, K)
         sums = ops.scatter_add_rows(x, quant, K)
-        if sync and get_world_size() > 1:          # histogram, token count and the K x D sums in ONE collective
-            hist, _, sums = exchange.all_reduce_packed(hist, quant.numel(), sums)
+        if sync and exchanging():
+            if get_world_size() > exchange.MAX_WORLD:      # beyond the exact range of the fp32 count pieces: the reference's
+                hist, _, sums = all_reduce_statistics(hist, quant.numel(), sums)      # unpacked flow (int64 counts, two collectives)
+                return hist, sums
+            hist, _, sums = exchange.all_reduce_packed(hist, quant.numel(), sums)     # histogram, token count, K x D sums: ONE collective
             return hist, sums
         return hist.to(torch.int64), sums
 
@@ -329,6 +332,8 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
             return False
         if self._anchor._sync and get_world_size() > 1:          # global nearest token: gathered latents (anchors.py:50-57)
             return False
+        if get_world_size() > exchange.MAX_WORLD:                # count pieces no longer exact in fp32: the dense flow below
+            return False
         p = self.probability
         return (isinstance(d, LazyDistance) and hist32 is not None and p.is_cuda and p.dtype == torch.float32
                 and ops.coarse_supported(self.quantizer.embedding_dim))
@@ -371,7 +376,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         inplace = self.quantizer.inplace_updates
         w_out = w_in if inplace else torch.empty_like(w_in)
         p_out = p_in if inplace else torch.empty_like(p_in)
-        if world <= 1:
+        if not exchanging():
             ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, hist32=hist32, numel=quant.numel(),
                           x=xr, col_idx=col)
         else:                                                    # histogram ‖ token count ‖ [cap, D] anchors: one all-reduce
@@ -401,7 +406,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         if self._sparse_ok(d, hist32):
             self._sparse_step(x, quant, d, hist32)
             return quant
-        if (get_world_size() <= 1 and type(self._anchor) is NearestAnchor and not self._anchor._sync
+        if (not exchanging() and type(self._anchor) is NearestAnchor and not self._anchor._sync
                 and isinstance(d, LazyDistance) and hist32 is not None
                 and self.probability.is_cuda and self.probability.dtype == torch.float32):
             # one rank, dense form: the whole update in one launch on the epilogue histogram, the column argmin and the

@@ -1,0 +1,125 @@
+"""The collective of the one exchange step, issued by libvqhip on the COMPUTE stream (include/vqhip.h: vqhip_allreduce_packed).
+
+The reference all-reduces through ``torch.distributed`` (vq/algorithms/vq/utils.py:34-35, vqkd/quantizers/callbacks.py:63-64,
+cvqvae/anchors.py:65-67): ProcessGroupNCCL runs the collective on its own stream, with an event hop from the compute stream
+before it and another one back after it.  The packed exchange is one small latency-bound collective between two short
+kernels (pack → all-reduce → apply), so here RCCL enqueues it on the very stream those kernels run on: an ``ncclComm`` of
+this library's own, created once per process group —
+
+    rank 0: vqhip_rccl_unique_id  →  torch.distributed's store  →  every rank: vqhip_rccl_comm_init
+
+— with RCCL resolved at run time from the ``librccl.so`` PyTorch-ROCm has already mapped (never a second copy).  The step
+stays capturable into a HIP graph (the collective is one more node of the captured stream).
+
+``VQHIP_ALLREDUCE`` selects the route: ``direct`` (this module; an error if it cannot be set up), ``torch``
+(``dist.all_reduce``), or ``auto`` (default): direct when the process group's backend is RCCL ("nccl") and the set-up —
+agreed across the ranks, with a probe all-reduce checked on every rank — succeeds, ``dist.all_reduce`` otherwise.  gloo
+groups (CPU tests, the shared-GPU plumbing runs) always take ``dist.all_reduce``."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_state = {'group': None, 'comm': None, 'error': None, 'generation': 0}
+
+
+def mode() -> str:
+    m = os.environ.get('VQHIP_ALLREDUCE', 'auto').lower()
+    if m not in ('auto', 'direct', 'torch'):
+        raise ValueError(f"VQHIP_ALLREDUCE must be 'auto', 'direct' or 'torch', got {m!r}")
+    return m
+
+
+def _agree(ok: bool, device) -> bool:
+    """True iff ``ok`` on every rank of the default group (the ranks must take the same branch around a collective)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def _librccl_path() -> Optional[bytes]:
+    path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+    return path.encode() if os.path.exists(path) else None
+
+
+def _bootstrap(device: torch.device) -> int:
+    """Create this library's communicator over the default process group; returns the ncclComm_t as an int."""
+    L = _lib.lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    err = None
+    try:
+        _lib.check(L.vqhip_rccl_load(_librccl_path()), 'vqhip_rccl_load')
+    except _lib.VqhipError as exc:
+        err = str(exc)
+    if not _agree(err is None, device):                       # nobody enters ncclCommInitRank unless everybody can
+        raise _lib.VqhipError(err or 'vqhip_rccl_load failed on another rank')
+    store = dist.distributed_c10d._get_default_store()
+    _state['generation'] += 1
+    key = f'vqhip/rccl_unique_id/{_state["generation"]}'
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(L.vqhip_rccl_unique_id(ident), 'vqhip_rccl_unique_id')
+        store.set(key, ident.raw.hex())
+    else:
+        ident = ctypes.create_string_buffer(bytes.fromhex(store.get(key).decode()), 128)     # waits until rank 0 has set it
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(L.vqhip_rccl_comm_init(ctypes.byref(comm), world, ident, rank), 'vqhip_rccl_comm_init')
+        probe = torch.ones(8, dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.vqhip_allreduce_packed(probe.data_ptr(), probe.numel(), comm, stream)
+        good = rc == 0 and bool((probe == float(world)).all().item())
+    if not _agree(good, device):
+        L.vqhip_rccl_comm_destroy(comm)
+        raise _lib.VqhipError(f'probe all-reduce through vqhip_allreduce_packed did not return {world} on every rank')
+    return comm.value
+
+
+def communicator(t: torch.Tensor) -> Optional[int]:
+    """The ncclComm_t for ``t``'s exchange, or None when ``dist.all_reduce`` is to be used (see the module docstring)."""
+    m = mode()
+    if m == 'torch' or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        return None
+    if dist.get_backend() != 'nccl':
+        if m == 'direct':
+            raise _lib.VqhipError(f"VQHIP_ALLREDUCE=direct needs the RCCL ('nccl') backend, the process group runs {dist.get_backend()!r}")
+        return None
+    group = dist.distributed_c10d._get_default_group()
+    if _state['group'] is not group:                          # first exchange of this process group (never inside a capture:
+        _state.update(group=group, comm=None, error=None)     # a captured step has run eagerly at least once before)
+        try:
+            _state['comm'] = _bootstrap(t.device)
+        except Exception as exc:                              # noqa: BLE001 — reported through `status()`, or raised in direct mode
+            _state['error'] = f'{type(exc).__name__}: {exc}'
+    if _state['comm'] is None and m == 'direct':
+        raise _lib.VqhipError(f'VQHIP_ALLREDUCE=direct: {_state["error"]}')
+    return _state['comm']
+
+
+def all_reduce(t: torch.Tensor, comm: int) -> torch.Tensor:
+    """In-place fp32 SUM of ``t`` over the ranks, enqueued on the current stream."""
+    L = _lib.lib()
+    _lib.check(L.vqhip_allreduce_packed(t.data_ptr(), t.numel(), comm, torch.cuda.current_stream(t.device).cuda_stream),
+               'vqhip_allreduce_packed')
+    return t
+
+
+def status() -> dict:
+    """Which route the exchange takes in this process (bench.py / tests)."""
+    return {'mode': mode(), 'direct': _state['comm'] is not None, 'error': _state['error']}
+
+
+def shutdown() -> None:
+    """Destroy the communicator (call before ``dist.destroy_process_group``; a process that simply exits need not)."""
+    if _state['comm'] is not None:
+        torch.cuda.synchronize()
+        _lib.lib().vqhip_rccl_comm_destroy(_state['comm'])
+    _state.update(group=None, comm=None, error=None)

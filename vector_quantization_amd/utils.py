@@ -68,6 +68,16 @@ def get_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def exchanging() -> bool:
+    """True when the codebook update has an exchange step to run: a process group of more than one rank — or, with
+    ``VQ_FORCE_EXCHANGE=1``, a process group of ANY size.  The forced world-size-1 group sends the update through the whole
+    multi-rank flow (pack, the RCCL collective, apply) on the single GPU a test box has; the results are those of the
+    one-rank flow bit for bit (tests/test_gpu_rccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('VQ_FORCE_EXCHANGE') == '1'
+
+
 # ---- collectives that also work on a backend without device-tensor support for the op (gloo: only broadcast and
 #      all_reduce take device tensors) — staged through the host there; RCCL ("nccl") takes the device tensors directly ----
 
@@ -161,8 +171,15 @@ exchange_log = _ExchangeLog()
 
 
 def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
-    """SUM all-reduce of one tensor, in place, counted by ``exchange_log``."""
-    exchange_log.collective(dist.all_reduce, t)
+    """SUM all-reduce of one tensor, in place, counted by ``exchange_log``.  An fp32 device tensor on an RCCL process group
+    goes through ``vqhip_allreduce_packed`` — the collective enqueued on the current (compute) stream — anything else, and
+    every gloo group, through ``dist.all_reduce`` (rccl.py)."""
+    from . import rccl
+    comm = rccl.communicator(t)
+    if comm is not None:
+        exchange_log.collective(rccl.all_reduce, t, comm)
+    else:
+        exchange_log.collective(dist.all_reduce, t)
     return t
 
 
