@@ -675,3 +675,53 @@ def test_graphed_quantizer_steps_match_eager(mode):
     if train:
         assert torch.equal(q1.get_buffer('_probability'), q2.get_buffer('_probability'))
         assert not torch.equal(q2.embedding.weight.detach().cpu(), torch.from_numpy(w0))   # and they did move
+
+
+# ---- the benchmarked shapes themselves (BASELINE.json configs[1] and configs[4] at the size bench.py times) ------------
+
+def test_full_size_bench_shape():
+    """524 288 x 16384 x 256, bf16 latents, through VQGANQuantizer.forward in eval mode — exactly the step bench.py times:
+    every row against the all-fp32 route (itself bit-equal to the C oracle on every fixture), 256 evenly spaced rows against
+    the C oracle directly, the straight-through output literally x + (z - x) on a row sample, the loss against float64."""
+    from vector_quantization_amd import ops
+    N, K, D = 2048 * 256, 16384, 256
+    g = torch.Generator(device='cuda').manual_seed(3407)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g).bfloat16()
+    q = build(vqgan_cfg(K, D), train=False, init=dict(type='vqgan'))
+    with torch.no_grad():
+        q.embedding.weight.copy_(w)
+        z, loss, memo = q(x, {})
+    quant = memo['quant'].reshape(-1)
+    exact = ops.argmin_exact(x, w, 'L2')
+    assert int((quant != exact).sum()) == 0
+    rows = torch.linspace(0, N - 1, 256, device='cuda').long()
+    ref = co.l2_argmin(x[rows].float().cpu().numpy(), w.cpu().numpy())
+    np.testing.assert_array_equal(quant[rows].cpu().numpy(), ref)
+    xs, zs = x[rows].float(), w[quant[rows]]
+    assert torch.equal(z[rows].float(), xs + (zs - xs))                                  # utils/ste.py:10, literally
+    loss64 = 1.25 * float(((w[exact].double() - x.double()) ** 2).mean())                # VQGANLoss: m + 0.25 m (losses.py:73,127)
+    assert abs(loss.item() - loss64) <= 1e-5 * max(1.0, abs(loss64))
+    assert int(ops.hist(quant, K).sum()) == N
+
+
+def test_full_size_tokenizer_shape():
+    """BASELINE configs[4] at the metric's size: 2048 images = 524 288 tokens, K = 16384, D = 8, NormalizeCallback + L2
+    (configs/llamagen/vqgan.py:10-20) through VQGANQuantizer.encode: every row against the all-fp32 route on the normalised
+    operands, evenly spaced rows against the C oracle, x' = F.normalize(x) returned (quantizers/base.py:123-131)."""
+    from vector_quantization_amd import ops
+    N, K, D = 2048 * 256, 16384, 8
+    g = torch.Generator(device='cuda').manual_seed(3407)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = torch.randn(N, D, device='cuda', generator=g).bfloat16()
+    q = build(vqgan_cfg(K, D, callbacks=[dict(type='NormalizeCallback')]), train=False, init=dict(type='vqgan'))
+    with torch.no_grad():
+        q.embedding.weight.copy_(w)
+        xn_out, quant, memo = q.encode(x, {})
+    xn, wn = ops.normalize_rows(x), ops.normalize_rows(w)
+    assert torch.equal(xn_out.float(), xn) and torch.equal(q.embedding.weight.detach(), wn)
+    quant = quant.reshape(-1)
+    assert int((quant != ops.argmin_exact(xn, wn, 'L2')).sum()) == 0
+    rows = torch.linspace(0, N - 1, 256, device='cuda').long()
+    xo, wo = co.normalize_rows(x[rows].float().cpu().numpy()), co.normalize_rows(w.cpu().numpy())
+    np.testing.assert_array_equal(quant[rows].cpu().numpy(), co.l2_argmin(xo, wo))

@@ -590,7 +590,8 @@ def test_randomised_shapes_sweep(ops):
 @pytest.mark.parametrize('N,K,D,metric', [(20000, 8192, 32, 'Cosine'), (16500, 1000, 32, 'Cosine'), (40000, 777, 24, 'L2'),
                                           (70001, 4099, 8, 'L2'), (33333, 300, 16, 'Cosine')])
 def test_small_d_kernel_forms_agree(ops, N, K, D, metric):
-    """D <= 32 at >= 16 384 tokens runs the group-record form (replay identification), without aux reads for cosine
+    """D <= 32 at >= 16 384 tokens runs the group-record form (identification requests served by identify32_kernel, or the
+    in-kernel replay of the 16x16x32 form), without aux reads for cosine
     (a codebook that does not fill its last stage reads them there) and with balanced workgroup sizes: every
     combination of the three knobs (8, 9, 10) returns the indices of the all-fp32 route, on the CPU oracle's definition."""
     from vector_quantization_amd import _lib
@@ -618,6 +619,31 @@ def test_small_d_kernel_forms_agree(ops, N, K, D, metric):
     finally:
         for key in (8, 9, 10):
             L.vqhip_set_tuning(key, 1)
+
+
+@pytest.mark.parametrize('N,K,D,metric,hot', [(40000, 8192, 32, 'Cosine', 1), (50000, 16384, 8, 'L2', 1), (60000, 8192, 16, 'Cosine', 40)])
+def test_group_request_lists_overflow_to_the_second_pass(ops, N, K, D, metric, hot):
+    """The D <= 32 group path files one identification request per (token, lane half) under the group of the lane's best
+    code tile; a bucket holds a fixed share of the request pool.  Latents crowded onto `hot` codes overflow those lists by an
+    order of magnitude: the overflowing groups stay bounds, the rows take the second proposal pass, and the indices are
+    still those of the all-fp32 route (the CPU oracle's definition on a row sample)."""
+    g = torch.Generator(device='cuda').manual_seed(N + K + D + hot)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    codes = torch.randint(0, K, (hot,), device='cuda', generator=g)
+    x = w[codes[torch.randint(0, hot, (N,), device='cuda', generator=g)]] + 0.05 * torch.randn(N, D, device='cuda', generator=g)
+    if metric == 'Cosine':
+        xq, wq = ops.normalize_rows(x), ops.normalize_rows(w)
+    else:
+        x, w = ops.normalize_rows(x), ops.normalize_rows(w)          # the LlamaGen form: constant-norm codebook
+        xq, wq = x, w
+    ref = ops.argmin_exact(xq, wq, metric)
+    got, st = ops.argmin(xq, ops.prepare_codebook(w, metric), return_stats=True)
+    assert torch.equal(got, ref)
+    sample = slice(0, 400)
+    oracle = (co.cos_argmin if metric == 'Cosine' else co.l2_argmin)(x[sample].cpu().numpy(), w.cpu().numpy())
+    np.testing.assert_array_equal(got[sample].cpu().numpy(), oracle)
+    if hot == 1:      # most rows could not get a request in: second pass (and from there, lists overflowing, the fp32 pass)
+        assert int(st[0]) + int(st[2]) > N // 2, st
 
 
 @pytest.mark.parametrize('kind,metric,scale', [('normal', 'L2', 1.0), ('normal', 'Cosine', 1.0), ('vqgan_init', 'L2', 1.0),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Encode time (prepare + argmin) and proposal-kernel time of several libvqhip builds for one shape, alternating
 subprocess rounds on one device; checks every build returns the shipped build's indices.
-usage: exp_shape.py N K D L2|Cosine lib1.so lib2.so ...   ('shipped' = the in-tree library)"""
+usage: exp_shape.py N K D L2|Cosine lib1.so lib2.so ...   ('shipped' = the in-tree library; 'lib@6=0' adds tuning knobs)"""
 import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,8 @@ import torch
 from vector_quantization_amd import _lib, ops
 N, K, D, metric = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 L = _lib.lib()
+for kv in filter(None, os.environ.get('VQHIP_TUNE', '').split(',')):      # e.g. VQHIP_TUNE=6=0,2=2 (vqhip_set_tuning keys)
+    k, v = kv.split('='); L.vqhip_set_tuning(int(k), int(v))
 g = torch.Generator(device='cuda').manual_seed(3407)
 w = torch.randn(K, D, device='cuda', generator=g); x = torch.randn(N, D, device='cuda', generator=g)
 if metric == 'Cosine': x = ops.normalize_rows(x)
@@ -35,7 +37,9 @@ res = {l: [] for l in libs}
 for r in range(3):
     for l in libs:
         env = dict(os.environ)
-        if l != 'shipped': env['VQHIP_LIB'] = os.path.join(ROOT, l)
+        path, _, tune = l.partition('@')                      # "lib.so@6=0,2=2": tuning knobs for that arm
+        if path != 'shipped': env['VQHIP_LIB'] = os.path.join(ROOT, path)
+        if tune: env['VQHIP_TUNE'] = tune
         out = subprocess.run([sys.executable, '-c', CHILD] + shape, env=env, capture_output=True, text=True)
         try:
             a, b, h = out.stdout.strip().splitlines()[-1].split()

@@ -128,19 +128,20 @@ static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int6
     return VQHIP_OK;
 }
 
-// D <= 16: the proposal pass on v_mfma_f32_32x32x16_f16 (vqhip_proposal32_kernels.h), same images and arguments
+// D <= 16 (and D <= 32 without aux reads): the proposal pass on v_mfma_f32_32x32x16_f16 (vqhip_proposal32_kernels.h), same
+// images; its group records are identified by identify32_kernel (launched by argmin_pipeline)
 template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS>
 static int launch_coarse32_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                                int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
-                               const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
+                               const int *n_dev, const VqGroupLists &grp, int pad_stage, int tpb, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * 2 + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
-    auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX, KS>;
+    auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX, KS, VQ_GROUP_TILES>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     const int64_t ntiles = (N + 15) / 16;
     const int64_t ntb = (ntiles + tpb - 1) / tpb;
     const long slot = prof_begin(s);
-    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, dec, pad_stage, tpb);
+    kern<<<(int)(ntb * nslices), WAVES * 64, LDS, s>>>(ximg, N, frag, nstages, nslices, rec, Np, cbst, xh2, rho2, Dp, metric, n_dev, grp, pad_stage, tpb);
     prof_end(slot, s);
     VQ_CHECK_LAUNCH("coarse32_kernel");
     return VQHIP_OK;
@@ -208,9 +209,14 @@ static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
     return ns;
 }
 
+// grp (nullable lists: the workspace has none beyond VQ_GROUP_MAX_TILES code tiles): where coarse32_kernel files its
+// identification requests; *group_path_out = 1 when that kernel ran (argmin_pipeline then launches identify32_kernel and the
+// group form of the decision stage), with *group_ks / *group_noaux / *group_pad_stage the parameters identify32_kernel needs
+struct VqGroupRun { int used, ks, noaux, pad_stage; };
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
                          const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, const VqDecideOut &dec,
-                         int *nslices_out, int *fused_decide_out, hipStream_t s) {
+                         int *nslices_out, int *fused_decide_out, hipStream_t s, VqGroupLists grp = VqGroupLists{nullptr, nullptr, nullptr, nullptr, 0, 1},
+                         VqGroupRun *grun = nullptr) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
@@ -243,7 +249,8 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         // D <= 16 always; 16 < D <= 32 (two instructions per tile) only without aux reads — measured (tools/ab_w32.py,
         // profiles/r03_w32_ab.txt): D = 32 cosine +2.5..5 %, D = 32 L2 -4..-14 % (the form is LDS-bound once the four 16-byte aux
         // reads per lane and tile come on top of 2 KiB of fragments)
-        case 2: if ((L.D <= 16 || (L.D <= VQ_W32_MAX_D && noaux)) && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load()) {
+        case 2: if ((L.D <= 16 || (L.D <= VQ_W32_MAX_D && noaux)) && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load() &&
+                    grp.bcnt != nullptr && grun != nullptr) {
                     // one 32x32x16 instruction covers the whole inner dimension: a quarter of the MFMA issue, group update per
                     // 16 scores.  Wide token tiles of 32 tokens: 1 (below 262 144 tokens) or 2 per wave.
 #ifdef VQ_W32_TT
@@ -253,15 +260,14 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
 #endif
                     const int full = 8 * tt * 2;                                    // 16-token tiles per workgroup
                     const int64_t ntb0 = (N + full * 16 - 1) / (full * 16);
-                    const int ns = pick_slices(ntb0, L.nstages, VQ_MIN_SLICES_FILTER);
+                    int ns = pick_slices(ntb0, L.nstages, VQ_MIN_SLICES_FILTER);
+                    ns = ns > VQ_GROUP_MAX_SLICES ? VQ_GROUP_MAX_SLICES : ns;
                     *nslices_out = ns;
                     int tpb = (ns == 1) ? balanced_tiles_per_block(N, full) : full;
                     tpb = (tpb + 1) & ~1;                                           // whole wide tiles
-                    const int fmode = g_tune_fused_decide.load();
-                    VqDecideOut dsel = dec;
-                    if (!(fmode == 1 || (fmode == 2 && (ns == 1 || N <= VQ_FUSED_DECIDE_MAX_N)))) dsel.idx = nullptr;
-                    *fused_decide_out = dsel.idx != nullptr ? 1 : 0;
-#define VQ_CFG32(TTW, NOAUXV, KSV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV, KSV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dsel, pad_stage, tpb, s)
+                    *fused_decide_out = 0;                                          // identification first: the decision stage is its own launch
+                    grun->used = 1; grun->ks = L.D <= 16 ? 1 : 2; grun->noaux = noaux ? 1 : 0; grun->pad_stage = pad_stage;
+#define VQ_CFG32(TTW, NOAUXV, KSV) return launch_coarse32_cfg<TTW, 8, VQ_TPS_D32, VQ_NBUF_D32, NOAUXV, KSV>(ximg, N, frag, L.nstages, ns, rec, Np, cbst, xh2, rho2, L.Dp, metric, dec.n_dev, grp, pad_stage, tpb, s)
                     if (L.D <= 16) {
                         if (tt == 1) { if (noaux) VQ_CFG32(1, true, 1); else VQ_CFG32(1, false, 1); }
                         else { if (noaux) VQ_CFG32(2, true, 1); else VQ_CFG32(2, false, 1); }
@@ -474,7 +480,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     float *thr = (float *)(w + W.off_thr);
     int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
     int *arrive = (int *)(w + W.off_arrive);
-    const int narrive = (int)(Np / 128 + 8);
+    const int narrive = (int)W.narrive;          // arrival counters + the group path's bucket counters (one zeroed range)
     const int xgrid = (int)((N + 31) / 32);
     if (!x_prepared) {
         if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
@@ -485,10 +491,32 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive, n_dev};
     VqDecideOut dec_arg = dec;                   // launch_coarse decides (knob 6, slice count) whether the proposal kernel runs the
     int fused_done = 0;                          // decision stage itself and reports it here
-    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s);
+    // D <= 32 group path: request lists of the proposal kernel (cap = an equal share of the pool per code tile, whole batches of 32)
+    VqGroupLists grp{nullptr, nullptr, nullptr, nullptr, 0, 1};
+    VqGroupRun grun{0, 0, 0, -1};
+    const int ntiles_cb = (int)(L.nstages * L.tps);
+    int nbuckets = 0;
+    if (W.nbkt > 0 && ntiles_cb <= VQ_GROUP_MAX_TILES) {
+        grp.R = vq_group_replicas(ntiles_cb / VQ_GROUP_TILES);
+        nbuckets = ntiles_cb / VQ_GROUP_TILES * grp.R;
+        grp.bcnt = (int *)(w + W.off_bcnt);
+        grp.blist = (uint32_t *)(w + W.off_blist);
+        grp.bfrag = w + W.off_bfrag;
+        grp.rece2 = (float *)(w + W.off_rece2);
+        grp.cap = (int)(W.blist_entries / nbuckets / 32 * 32);
+    }
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s, grp, &grun);
     if (rc) return rc;
+    const float *rece2 = nullptr;
+    if (grun.used) {             // identify the group records: one candidate per request, written into the records
+        const int igrid = (nbuckets + 3) / 4;                   // one wave per bucket
+        if (grun.ks == 1) identify32_kernel<1, VQ_GROUP_TILES><<<igrid, 256, 0, s>>>(c + L.off_frag, L.nstages, nslices, nbuckets, rec, Np, (const VqCbStats *)(c + L.off_stats), grp, grun.pad_stage, grun.noaux);
+        else identify32_kernel<2, VQ_GROUP_TILES><<<igrid, 256, 0, s>>>(c + L.off_frag, L.nstages, nslices, nbuckets, rec, Np, (const VqCbStats *)(c + L.off_stats), grp, grun.pad_stage, grun.noaux);
+        VQ_CHECK_LAUNCH("identify32_kernel");
+        rece2 = grp.rece2;
+    }
     if (!fused_done) {
-        refine_decide_kernel<<<(int)((N + 1023) / 1024), 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, dec);
+        refine_decide_kernel<<<(int)((N + 1023) / 1024), 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, dec, rece2);
         VQ_CHECK_LAUNCH("refine_decide_kernel");
     }
     // second-chance proposals for rows with a possibly unidentified candidate (the kernel gathers their fragments from
@@ -517,11 +545,11 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         if (x_dtype == VQHIP_DTYPE_F32)
             refine_rerank_kernel<0><<<(int)(g0 + g1), 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S0, (int)g0, rec, xh2, rho2,
                                                                   xnorm, Np, idx, hist, multi_list, rescan_list, counters,
-                                                                  rescan_cnt, cand_list, exact_list, keys);
+                                                                  rescan_cnt, cand_list, exact_list, keys, grun.used);
         else
             refine_rerank_kernel<1><<<(int)(g0 + g1), 256, 0, s>>>(x, e_exact, c, L, D, metric, nslices, S0, (int)g0, rec, xh2, rho2,
                                                                   xnorm, Np, idx, hist, multi_list, rescan_list, counters,
-                                                                  rescan_cnt, cand_list, exact_list, keys);
+                                                                  rescan_cnt, cand_list, exact_list, keys, grun.used);
         VQ_CHECK_LAUNCH("refine_rerank_kernel");
     }
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
@@ -538,8 +566,7 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
-    const int64_t Np = (N + 63) / 64 * 64;
-    const int nblk_stats = (int)((Kc + 15) / 16), xgrid = (int)((N + 31) / 32), narrive = (int)(Np / 128 + 8);
+    const int nblk_stats = (int)((Kc + 15) / 16), xgrid = (int)((N + 31) / 32), narrive = (int)W.narrive;
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
     char *ximg = w + W.off_ximg;

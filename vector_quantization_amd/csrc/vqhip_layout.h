@@ -82,7 +82,29 @@ struct VqCbStats {
 struct VqWsLayout {
     int64_t N;
     int64_t off_counters, off_xh2, off_rho2, off_rec, off_flag, off_multi, off_exact, off_thr, off_rcnt, off_rlist, off_keys, off_en, off_xn, off_arrive, off_ximg, total;
+    // group identification of the D <= 32 proposal kernels (vqhip_proposal32_kernels.h, identify32_kernel); zero-sized otherwise
+    int64_t narrive;        // ints in the zeroed counter range at off_arrive: arrival counters, then the nbkt bucket counters
+    int64_t nbkt;           // bucket counters: one per 32-code tile of the padded codebook
+    int64_t off_bcnt, off_rece2, off_blist, off_bfrag, blist_entries;
 };
+
+// the D <= 32 group path: the stream kernel files one identification request per (token, slice, lane half) under the code
+// tile of the lane's best group; identify32_kernel serves them bucket by bucket.  Up to VQ_GROUP_MAX_SLICES slices and
+// VQ_GROUP_MAX_TILES code tiles (K <= 131 072): beyond, the per-element kernels are used.
+#define VQ_GROUP_MAX_SLICES 2
+#define VQ_GROUP_MAX_TILES 4096
+// A group's requests are spread over R buckets (by the token block that files them; R = the largest power of two <= 128 with
+// groups * R <= VQ_GROUP_MAX_BUCKETS): 100 352 returning atomics on the 256 counters of BASELINE configs[2] — eight cache
+// lines — took 48 us at ~4 ns per atomic and line; with a line per counter and eight buckets per tile they take none
+#define VQ_GROUP_MAX_BUCKETS 4096
+#define VQ_GROUP_CNT_STRIDE 32         // ints between two bucket counters (128 bytes)
+#ifndef VQ_GROUP_TILES
+#define VQ_GROUP_TILES 4               // code tiles per group record of coarse32_kernel (a divisor of VQ_TPS_D32; 1, 2, 4, 8 measured: profiles/r04_group_tiles.txt)
+#endif
+VQ_HD int vq_group_replicas(int64_t ngroups) { int r = 128; while (r > 1 && ngroups * r > VQ_GROUP_MAX_BUCKETS) r >>= 1; return r; }
+VQ_HD bool vq_group_path_possible(int64_t K, int D) {
+    return vq_coarse_supported(D) && D <= 32 && (K + VQ_TILE_CODES - 1) / VQ_TILE_CODES + VQ_TPS_D32 <= VQ_GROUP_MAX_TILES;
+}
 
 // counters: [0] rescanned rows, [1] rows with >1 identified candidate, [2] rows sent to the fp32 pass
 VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
@@ -105,7 +127,21 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
     W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
     W.off_arrive = W.off_xn + Np * 4;          // arrival counters of the proposal kernel's token blocks (>= 128 tokens each)
-    W.off_ximg = (W.off_arrive + (Np / 128 + 8) * 4 + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
+    const bool grp = vq_group_path_possible(K, D);
+    W.nbkt = grp ? (int64_t)VQ_GROUP_MAX_BUCKETS * VQ_GROUP_CNT_STRIDE : 0;      // one counter per bucket, each on a 128-byte line of its own
+    W.off_bcnt = (W.off_arrive + (Np / 128 + 8) * 4 + 127) / 128 * 128;
+    W.narrive = (W.off_bcnt - W.off_arrive) / 4 + W.nbkt;
+    // second-best value inside an identified group, per (slice, lane half, token): the consumer folds it into the bound v3
+    W.off_rece2 = (W.off_bcnt + W.nbkt * 4 + 255) / 256 * 256;
+    // request lists: an equal share of one pool per bucket (4 N + 64 per bucket entries in all: >= 4x the mean at one slice);
+    // an entry is the token word and, in a second array, the token's B fragment as the requesting lanes hold it (32 bytes
+    // per 16 dims: identify32_kernel reads a batch's 32 fragments as 1-2 KiB of contiguous bytes instead of gathering 64
+    // scattered 16-byte pieces from the token image — 35 -> 9 us at 524 288 requests)
+    W.blist_entries = grp ? 4 * Np + 64 * (int64_t)VQ_GROUP_MAX_BUCKETS : 0;
+    W.off_blist = W.off_rece2 + (grp ? (int64_t)VQ_GROUP_MAX_SLICES * 2 * Np * 4 : 0);
+    W.off_bfrag = (W.off_blist + W.blist_entries * 4 + 255) / 256 * 256;
+    const int64_t frag_bytes = W.blist_entries * (D <= 16 ? 32 : 64);
+    W.off_ximg = (W.off_bfrag + frag_bytes + 1023) / 1024 * 1024;   // fp16 token image [N/32][nstep] KiB
     const int64_t img = vq_coarse_supported(D) ? ((N + 31) / 32) * (int64_t)(vq_padded_d(D) / 16) * VQ_CHUNK_BYTES : 0;
     W.total = W.off_ximg + img;
     return W;

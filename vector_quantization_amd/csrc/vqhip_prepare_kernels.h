@@ -300,7 +300,8 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
     __shared__ float tile[NCHW ? 64 : 1][33];     // NCHW: 64 dims x 32 tokens of the map, turned here
     if (blk == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // housekeeping for the later kernels of this call (stream-ordered)
     // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
-    if (arrive != nullptr && threadIdx.x == 0 && blk < narrive) arrive[blk] = 0;
+    if (arrive != nullptr)                                      // every block zeroes its stride of the counter range
+        for (int64_t i = blk * 256 + threadIdx.x; i < narrive; i += nblocks * 256) arrive[i] = 0;
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t t = blk * 32 + r;
     const bool tvalid = t < N;
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
                                                      float *__restrict__ rho2, float *__restrict__ xn,
                                                      int *__restrict__ counters, char *cb, VqCbLayout L,
                                                      int *__restrict__ arrive = nullptr, int narrive = 0) {
-    x_prep_body<DT, false>(blockIdx.x, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, nullptr, 0.0f);
+    x_prep_body<DT, false>(blockIdx.x, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, nullptr, 0.0f, 0, nullptr, 0,
+                           (int64_t)gridDim.x);
 }
 // vqhip_encode / vqhip_col_argmin: the codebook statistics and the token side in ONE launch (they are independent;
 // the image kernel that follows needs the former, the proposal kernel both)

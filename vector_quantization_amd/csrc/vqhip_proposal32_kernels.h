@@ -35,25 +35,52 @@ __device__ __forceinline__ void tile_max16(float &dst, float &sc1, float &sc2, c
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]),
           "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]), "v"(a0), "v"(a1));
 }
+// the same folded into a running maximum `run` (the group so far): the seventeenth input rides in the eighth instruction
+template <int TT>
+__device__ __forceinline__ void tile_max17(float &run, float &sc0, float &sc1, float &sc2, const f32x16 &p, const float (&after)[TT]) {
+    const float a0 = after[0], a1 = after[TT > 1 ? 1 : 0];
+    asm("v_max3_f32 %1, %4, %5, %6\n\t"
+        "v_max3_f32 %2, %7, %8, %9\n\t"
+        "v_max3_f32 %3, %10, %11, %12\n\t"
+        "v_max3_f32 %1, %1, %13, %14\n\t"
+        "v_max3_f32 %2, %2, %15, %16\n\t"
+        "v_max3_f32 %3, %3, %17, %18\n\t"
+        "v_max3_f32 %1, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %1, %19"
+        : "+v"(run), "+v"(sc0), "+v"(sc1), "+v"(sc2)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]),
+          "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]), "v"(a0), "v"(a1));
+}
 // max over the two lanes l, l ^ 32 that share a token in the 32x32 MFMA output
 __device__ __forceinline__ float pair_rows_max(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// where the identification requests of the group records go (workspace: vq_ws_layout): one counter and a list of `cap`
+// entries (token | lane half << 31) per bucket; rece2[slice][half][token] receives the runner-up inside an identified group
+// (bucket = tile * R + token block % R: vqhip_layout.h; counter of bucket b at bcnt[b * VQ_GROUP_CNT_STRIDE])
+struct VqGroupLists { int *bcnt; uint32_t *blist; char *bfrag; float *rece2; int cap, R; };
+
 // One workgroup = WAVES waves x TT wide token tiles of 32 tokens (B fragments in registers for the whole kernel); the codebook
 // image streams through the LDS ring exactly as in coarse_kernel (NBUF stages of TPS tiles, filled two ahead, the second half
-// of the waves one stage behind).  tpb: 16-token tiles per workgroup (even).  Group records + replay identification as in
-// coarse_kernel<..., GROUPS>; straight-line update (no skip test: TT <= 2).
+// of the waves one stage behind).  tpb: 16-token tiles per workgroup (even).  Group records as in coarse_kernel<..., GROUPS>,
+// straight-line update (no skip test: TT <= 2); the identification of a lane's best group is a request to identify32_kernel.
 // KS: k-steps of 16 dims — 1 for D <= 16, 2 for D <= 32 (two instructions accumulate; the chains of the TT token tiles are
 // interleaved so that no instruction waits for the one it accumulates onto).
-template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS = 1>
+// GT: code tiles per group record (a divisor of TPS).  A lane keeps the running maximum of its scores over the GT tiles of a
+// group (8 instructions per tile: the tree; the running maximum is the tree's seventeenth input) and runs the 4-instruction
+// group update once per GROUP: 8 + 4 / GT vector instructions per 16 scores.  What a group costs elsewhere is GT tiles per
+// request in identify32_kernel — GT MFMAs on 32 requests at a time — and nothing in second-pass rows: a lane identifies ONE
+// candidate whatever the group size, everything else it has seen is a bound either way.
+template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS = 1, int GT = 1>
 __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
-    const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {
+    const float *__restrict__ rho2, int Dp, int metric, const int *__restrict__ n_dev, VqGroupLists grp, int pad_stage, int tpb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(TPS % 2 == 0 && NBUF >= 4, "ring of four stages, accumulators ping-pong by tile parity");
+    static_assert(TPS % GT == 0, "a group lies inside one stage");
     constexpr int NSTEP = 2;                              // the images are those of the padded dimension 32
     constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);
     constexpr int STAGE_BYTES = NCH * VQ_CHUNK_BYTES;
@@ -64,8 +91,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     const int sub = (lane >> 4) & 1;                      // which 16-row chunk holds this lane's row
     const int piece = (half * 16 + (lane & 15)) * 16;     // byte offset of this lane's 16-byte piece inside that chunk
     const int64_t ntt = (N + 31) / 32 * 2;                // 16-token tiles in the fp16 token image (of the launch's capacity)
-    if (dec.n_dev != nullptr) {                           // device-side row count: token blocks past it have nothing to do
-        const int64_t nd = *dec.n_dev;
+    if (n_dev != nullptr) {                               // device-side row count: token blocks past it have nothing to do
+        const int64_t nd = *n_dev;
         N = nd < N ? nd : N;
         if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
     }
@@ -86,6 +113,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     float b1[TT], b2[TT], mg[TT];
     uint32_t t1[TT];
     float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;             // destinations of the asm maxima: live across the whole loop
+    float gm[TT];                                         // running maximum of the group being streamed
+#pragma unroll
+    for (int t = 0; t < TT; ++t) gm[t] = -INFINITY;
     bool const_norm;                                      // L2 on a constant-norm codebook: aux values of real codes are 0
     {
         const VqCbStats stv = cb_stats_view(cbst);
@@ -148,7 +178,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
 #pragma unroll
                     for (int q = 0; q < NE; ++q) init[q] = 0.0f;
                 }
-                const uint32_t tgp = (uint32_t)(st * TPS + ti) - 1u;   // the tile whose scores are retired below
+                // the tile whose scores are retired below is tile st * TPS + ti - 1: number (ti - 1) mod GT of group gid
+                const int pg = (ti + GT - 1) % GT;            // (a constant once the tile loop is unrolled)
+                const uint32_t gid = (uint32_t)(st * (TPS / GT)) + (uint32_t)((ti + GT - 1) / GT) - 1u;
 #pragma unroll
                 for (int s = 0; s + 1 < KS; ++s)          // all but the last k-step, token tiles interleaved
 #pragma unroll
@@ -163,11 +195,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
                     float after[TT];
 #pragma unroll
                     for (int u = 0; u < TT; ++u) after[u] = cur[u <= t ? u : t][0];
-                    tile_max16<TT>(sc0, sc1, sc2, prv[t], after);
-                    const float nb = vmax(b1[t], sc0);
-                    b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], sc0);
-                    t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? tgp : t1[t];
-                    b1[t] = nb;
+                    if (pg == 0) tile_max16<TT>(gm[t], sc1, sc2, prv[t], after);
+                    else tile_max17<TT>(gm[t], sc0, sc1, sc2, prv[t], after);
+                    if (pg == GT - 1) {                    // the group is complete
+                        const float nb = vmax(b1[t], gm[t]);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], gm[t]);
+                        t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? gid : t1[t];
+                        b1[t] = nb;
+                    }
                 }
             }
         };
@@ -186,131 +221,161 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
             float g = accB[t][0];
 #pragma unroll
             for (int e = 1; e < NE; ++e) g = __builtin_amdgcn_fmed3f(g, accB[t][e], INFINITY);   // max, NaN-transparent like v_max
+            if constexpr (GT > 1) g = __builtin_amdgcn_fmed3f(g, gm[t], INFINITY);               // the last tile closes its group
             b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], g);
             b1[t] = vmax(b1[t], g);
-            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * TPS - 1) : t1[t];
+            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * (TPS / GT) - 1) : t1[t];
         }
     }
 
-    // ---- group records -> code records: a lane whose best group can matter replays that one code tile (same fragments, same
-    // instruction, same initial value: the very scores of the stream) and runs the per-element update on its 16 elements;
-    // everything else the lane has seen stays a value bound (coarse_kernel, same section)
-    bool ident[TT];
-    {
-        auto bound_up = [](float v) {
-            const uint32_t b = __float_as_uint(v);
-            return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
-        };
-        constexpr int RB = 4;                             // tiles replayed per round trip (4 + 16 registers each)
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const float top = pair_rows_max(b1[t]);
-            const int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
-            const bool need = (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) && tokn < N &&
-                              (wave * TT + t) * 2 < tpb && t1[t] >= (uint32_t)(st0 * TPS) && t1[t] < (uint32_t)(st1 * TPS);
-            float e1 = -INFINITY, e2 = -INFINITY;
-            u64 todo = __ballot(need);
-            while (todo) {
-                uint32_t T[RB];
-                u64 rest = todo;
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int l = rest ? (__ffsll((unsigned long long)rest) - 1) : (__ffsll((unsigned long long)todo) - 1);
-                    T[i] = (uint32_t)__builtin_amdgcn_readlane((int)t1[t], l);
-                    rest &= rest - 1;
-                }
-                half8 a[RB][KS];
-                f32x16 acc[RB];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int64_t rst = T[i] / TPS;
-                    const int rti = (int)(T[i] % TPS);
-                    const char *sb = frag + rst * (int64_t)STAGE_BYTES;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) a[i][s] = *(const half8 *)(sb + (rti * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
-                    if ((NOAUX || const_norm) && rst != (int64_t)pad_stage) {
-#pragma unroll
-                        for (int q = 0; q < NE; ++q) acc[i][q] = 0.0f;
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 a4 = *(const f32x4 *)(sb + TPS * NSTEP * VQ_CHUNK_BYTES + (rti * 32 + 8 * g + 4 * half) * 4);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[i][4 * g + q] = a4[q];
-                        }
-                    }
-                }
-                u64 done = 0;
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][s], xf[t][s], acc[i], 0, 0, 0);
-                    float w1 = -INFINITY, w2 = -INFINITY;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {                 // element id = accumulator register (4 bits)
-                        float v = __uint_as_float((__float_as_uint(acc[i][e]) & 0xFFFFFFF0u) | (uint32_t)e);
-                        w2 = __builtin_amdgcn_fmed3f(w1, w2, v);
-                        w1 = vmax(w1, v);
-                    }
-                    const bool mine = need && t1[t] == T[i];
-                    e1 = mine ? w1 : e1; e2 = mine ? w2 : e2;
-                    done |= __ballot(mine);
-                }
-                todo &= ~done;
-            }
-            const float other = bound_up(b2[t]);
-            if (need) { b1[t] = e1; b2[t] = fmaxf(other, e2); }
-            else { b2[t] = fmaxf(other, bound_up(b1[t])); }
-            ident[t] = need;
-        }
-    }
-
-    // ---- merge the two lanes that share a token; lanes 0..31 write one record per (token, slice) ----
+    // ---- group records -> identification requests.  A lane whose best group can matter (within the row's margin of the best
+    // any lane of the token holds) files ONE request (token, lane half) under that group; identify32_kernel
+    // serves the requests group by group — 32 requests per MFMA, same fragments, same instruction, same initial value: the
+    // very scores of the stream — and writes the identified candidate into the record.  Everything else the lane has seen
+    // stays a value bound, raised to the largest value the index-bit form of the same score can take.  (Round 3 replayed
+    // the tile inside this kernel, one useful column per MFMA and ~55 vector instructions per token at the end of every
+    // wave: 30 % of the kernel at BASELINE configs[2], profiles/r04_c3_shares.txt.)
+    auto bound_up = [](float v) {
+        const uint32_t b = __float_as_uint(v);
+        return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
+    };
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        Top2 r; r.v1 = r.v2 = r.v3 = -INFINITY; r.c1 = r.c2 = 0xFFFFFFFFu;
-        {
-            const uint32_t bits = __float_as_uint(b1[t]);
-            const uint32_t code = t1[t] * 32u + (uint32_t)mfma_row((int)(bits & 15u), half);
-            if (ident[t] && b1[t] > -INFINITY) top_insert(r, b1[t], code);
-            r.v3 = fmaxf(r.v3, b2[t]);
-        }
-        top_merge_lane(r, 32);
+        const float top = pair_rows_max(b1[t]);
         const int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
-        if (lane < 32 && tokn < N && (wave * TT + t) * 2 < tpb) {
+        const bool live = tokn < N && (wave * TT + t) * 2 < tpb;
+        bool need = live && (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) &&
+                    t1[t] >= (uint32_t)(st0 * (TPS / GT)) && t1[t] < (uint32_t)(st1 * (TPS / GT));
+        int bucket = 0, pos = -1;
+        if (need) {
+            bucket = (int)t1[t] * grp.R + (int)(tb & (grp.R - 1));
+            pos = atomicAdd(&grp.bcnt[(int64_t)bucket * VQ_GROUP_CNT_STRIDE], 1);
+            if (pos < grp.cap) grp.blist[(int64_t)bucket * grp.cap + pos] = (uint32_t)tokn | ((uint32_t)half << 31);
+            else { need = false; pos = -1; }   // the bucket's list is full: the group stays a bound (the row takes the second pass)
+        }
+        {   // the token's B fragment travels with the request: this lane's dims into its own request's entry and its partner's
+            const int ppos = __shfl_xor(pos, 32, 64), pbucket = __shfl_xor(bucket, 32, 64);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (pos >= 0) *(half8 *)(grp.bfrag + ((((int64_t)bucket * grp.cap + pos) * 2 + half) * KS + s) * 16) = xf[t][s];
+                if (ppos >= 0) *(half8 *)(grp.bfrag + ((((int64_t)pbucket * grp.cap + ppos) * 2 + half) * KS + s) * 16) = xf[t][s];
+            }
+        }
+        float bound = need ? bound_up(b2[t]) : fmaxf(bound_up(b2[t]), bound_up(b1[t]));
+        bound = fmaxf(bound, __shfl_xor(bound, 32, 64));        // the two lanes that share the token
+        if (lane < 32 && live) {
             float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
-            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
-            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+            rp[0] = -INFINITY; rp[Np] = __uint_as_float(0xFFFFFFFFu); rp[2 * Np] = -INFINITY;
+            rp[3 * Np] = __uint_as_float(0xFFFFFFFFu); rp[4 * Np] = bound;
+            grp.rece2[(int64_t)(sl * 2) * Np + tokn] = -INFINITY;
+            grp.rece2[(int64_t)(sl * 2 + 1) * Np + tokn] = -INFINITY;
         }
     }
+}
 
-    // ---- decision stage, by the workgroup that completes a token block (coarse_kernel, same section) ----
-    if (dec.idx != nullptr) {
-        int *flags = (int *)lds;                         // the stage ring is free now (first barrier below)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int last = 1;
-            if (nslices > 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                last = (atomicAdd(&dec.arrive[tb], 1) == nslices - 1) ? 1 : 0;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// Serves the identification requests of coarse32_kernel: one wave per bucket (group of GT code tiles x replica), four batches
+// of 32 requests per trip — the group's A fragments are loaded once, the entries and the B fragments of the four batches (they
+// travel with the requests: contiguous bytes) together: two dependent round trips per 128 requests.  Per batch and tile the
+// wave runs the stream's own instruction (same fragments, same initial value: the very scores of the stream) and the
+// per-element update (element id in the 4 low mantissa bits, runner-up) on the 16 scores each lane holds, folding the GT
+// tiles' (best, runner-up) pairs; the lane that holds the requested half writes
+//   rec[slice][2 half .. 2 half + 1][token] = (best score of the group, its code)      rece2[slice][half][token] = runner-up.
+template <int KS, int GT>
+__global__ __launch_bounds__(256, 3) void identify32_kernel(const char *__restrict__ frag, int64_t nstages,
+                                                            int nslices, int nbuckets, float *__restrict__ rec,
+                                                            int64_t Np, const VqCbStats *__restrict__ cbst, VqGroupLists grp,
+                                                            int pad_stage, int noaux) {
+    constexpr int TPS = VQ_TPS_D32, NSTEP = 2, NE = 16, G = 4;
+    constexpr int STAGE_BYTES = (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bucket = (int)blockIdx.x * 4 + wave;
+    if (bucket >= nbuckets) return;
+    int cnt = grp.bcnt[(int64_t)bucket * VQ_GROUP_CNT_STRIDE];
+    cnt = cnt < grp.cap ? cnt : grp.cap;
+    if (cnt <= 0) return;
+    const int half = lane >> 5, col = lane & 31, sub = (lane >> 4) & 1;
+    const int piece = (half * 16 + (lane & 15)) * 16;
+    const int gid = bucket / grp.R;
+    const int64_t stage = (int64_t)gid * GT / TPS;
+    const int ti0 = (gid * GT) % TPS;
+    const int sl = (int)(((stage + 1) * nslices - 1) / nstages);
+    const char *sb = frag + stage * (int64_t)STAGE_BYTES;
+    const bool zero_init = (noaux || cbst->l2_const_norm != 0) && stage != (int64_t)pad_stage;
+    const uint32_t *list = grp.blist + (int64_t)bucket * grp.cap;
+    const char *bfrag = grp.bfrag + (int64_t)bucket * grp.cap * (2 * KS * 16);
+    for (int base = 0; base < cnt; base += 32 * G) {
+        // one trip: the entries and B fragments of up to G batches, then tile by tile (the tile's A fragments are fetched one
+        // tile ahead) every batch's MFMA and per-element update, folded into the batch's (best, runner-up, tile) so far
+        uint32_t entry[G];
+        half8 xf[G][KS];
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const int i = base + 32 * b + col;
+            const int ic = i < cnt ? i : base;             // (padding columns repeat a valid request and never write)
+            entry[b] = list[ic];
+            const char *fp = bfrag + (((int64_t)ic * 2 + half) * KS) * 16;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xf[b][s] = *(const half8 *)(fp + s * 16);
+        }
+        float W1[G], W2[G];
+        int Tb[G];
+#pragma unroll
+        for (int b = 0; b < G; ++b) { W1[b] = -INFINITY; W2[b] = -INFINITY; Tb[b] = 0; }
+        half8 anext[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) anext[s] = *(const half8 *)(sb + (ti0 * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
+#pragma unroll 1
+        for (int j = 0; j < GT; ++j) {
+            half8 af[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) af[s] = anext[s];
+            if (j + 1 < GT) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    anext[s] = *(const half8 *)(sb + ((ti0 + j + 1) * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
+            }
+            f32x16 init;
+            if (zero_init) {
+#pragma unroll
+                for (int q = 0; q < NE; ++q) init[q] = 0.0f;
+            } else {                   // -se |e|^2 / 2 of this lane's code rows (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a4 = *(const f32x4 *)(sb + TPS * NSTEP * VQ_CHUNK_BYTES + ((ti0 + j) * 32 + 8 * g + 4 * half) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) init[4 * g + q] = a4[q];
                 }
             }
-            flags[0] = last;
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                if (base + 32 * b >= cnt) break;           // wave-uniform
+                f32x16 acc = init;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], xf[b][s], acc, 0, 0, 0);
+                float w1 = -INFINITY, w2 = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {             // element id = accumulator register (4 bits)
+                    const float v = __uint_as_float((__float_as_uint(acc[e]) & 0xFFFFFFF0u) | (uint32_t)e);
+                    w2 = __builtin_amdgcn_fmed3f(w1, w2, v);
+                    w1 = vmax(w1, v);
+                }
+                // fold the tile's (best, runner-up) into the group's: second largest of {W1, W2, w1, w2} = med3(W1, w1, max(W2, w2))
+                W2[b] = __builtin_amdgcn_fmed3f(W1[b], w1, fmaxf(W2[b], w2));
+                Tb[b] = (w1 > W1[b]) ? j : Tb[b];
+                W1[b] = fmaxf(W1[b], w1);
+            }
         }
-        __syncthreads();
-        const bool last = flags[0] != 0;
-        __syncthreads();                                 // everybody has read the flag before the LDS words are reused
-        if (last) {
-            int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
-            int64_t n = tb * (int64_t)(tpb * 16) + threadIdx.x;      // tpb*16 <= WAVES*64 threads: one token per thread
-            const bool oob = (int)threadIdx.x >= tpb * 16 || n >= N;
-            if (n >= N) n = N - 1;
-            decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const int want = (int)(entry[b] >> 31);
+            if (base + 32 * b + col < cnt && half == want) {
+                const int64_t tk = (int64_t)(entry[b] & 0x7FFFFFFFu);
+                const uint32_t code = (uint32_t)(gid * GT + Tb[b]) * 32u + (uint32_t)mfma_row((int)(__float_as_uint(W1[b]) & 15u), half);
+                float *rp = rec + ((int64_t)sl * VQ_REC_FIELDS + 2 * want) * Np + tk;
+                rp[0] = W1[b];
+                rp[Np] = __uint_as_float(code);
+                grp.rece2[(int64_t)(sl * 2 + want) * Np + tk] = W2[b];
+            }
         }
     }
 }

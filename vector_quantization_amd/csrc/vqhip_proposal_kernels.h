@@ -19,7 +19,7 @@ struct VqDecideOut {
 template <bool AGENT>
 __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                             const float *rec, const float *xh2, const float *rho2, int64_t Np,
-                                            const VqDecideOut &o, int *wcount, int *wbase);
+                                            const VqDecideOut &o, int *wcount, int *wbase, const float *rece2 = nullptr);
 
 __device__ __forceinline__ void top_insert(Top2 &t, float v, uint32_t c) {
     if (v > t.v1) { t.v3 = fmaxf(t.v3, t.v2); t.v2 = t.v1; t.c2 = t.c1; t.v1 = v; t.c1 = c; }

@@ -121,10 +121,13 @@ __device__ __forceinline__ float bf16_tight_margin(float m, float bf16_worst, fl
     return width < bf16_worst ? m - bf16_worst + width : m;
 }
 
-template <int NSL, bool AGENT>
+// GROUPS (the D <= 32 group path: coarse32_kernel + identify32_kernel): fields (0, 1) and (2, 3) of a record hold the
+// candidates the two lane halves of the token identified — in no particular order, either may be absent (code 0xFFFFFFFF) —
+// and rece2[slice][half][n] the runner-up inside each identified group, a bound like v3.
+template <int NSL, bool AGENT, bool GROUPS = false>
 __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                                  const float *rec, const float *xh2, const float *rho2, int64_t Np,
-                                                 const VqDecideOut &o, int *wcount, int *wbase) {
+                                                 const VqDecideOut &o, int *wcount, int *wbase, const float *rece2 = nullptr) {
     const VqCbStats stv = cb_stats_view(st);
     float bf16_worst = 0.0f;
     float m = row_margin(&stv, Dp, metric, xh2[n], rho2[n], &bf16_worst);
@@ -135,15 +138,19 @@ __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCb
     uint32_t best = 0xFFFFFFFFu;
     float thr;
     if constexpr (NSL > 0) {
-        float v1[NSL], v2[NSL], v3[NSL], c1[NSL];
+        float v1[NSL], v2[NSL], v3[NSL], c1[NSL], c2[NSL];
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
             const float *rp = rec + (int64_t)s * VQ_REC_FIELDS * Np + n;
             v1[s] = rec_load<AGENT>(rp); c1[s] = rec_load<AGENT>(rp + Np);
             v2[s] = rec_load<AGENT>(rp + 2 * Np); v3[s] = rec_load<AGENT>(rp + 4 * Np);
+            if constexpr (GROUPS) {
+                c2[s] = rec_load<AGENT>(rp + 3 * Np);
+                v3[s] = fmaxf(v3[s], fmaxf(rece2[(int64_t)(2 * s) * Np + n], rece2[(int64_t)(2 * s + 1) * Np + n]));
+            }
         }
 #pragma unroll
-        for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, v1[s]);
+        for (int s = 0; s < NSL; ++s) gbest = fmaxf(gbest, GROUPS ? fmaxf(v1[s], v2[s]) : v1[s]);
         if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
         m = bf16_tight_margin(m, bf16_worst, gbest, &stv);
         thr = gbest - m;           // m > 0, so thr <= gbest and the best record always qualifies
@@ -151,9 +158,10 @@ __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCb
         for (int s = 0; s < NSL; ++s) {
             if (v3[s] >= thr) unidentified = true;
             if (v1[s] >= thr) { ++nc; best = __float_as_uint(c1[s]); }
-            if (v2[s] >= thr) ++nc;
+            if (v2[s] >= thr) { ++nc; if constexpr (GROUPS) best = __float_as_uint(c2[s]); }
         }
     } else {
+        static_assert(!GROUPS, "the group path runs with 1, 2 or 4 slices");
         for (int s = 0; s < nslices; ++s) gbest = fmaxf(gbest, rec_load<AGENT>(rec + (int64_t)s * VQ_REC_FIELDS * Np + n));
         if (!(gbest > -INFINITY) || !isfinite(gbest)) invalid = true;
         m = bf16_tight_margin(m, bf16_worst, gbest, &stv);
@@ -197,7 +205,16 @@ __device__ __forceinline__ void decide_rows_impl(int64_t n, bool oob, const VqCb
 template <bool AGENT>
 __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
                                             const float *rec, const float *xh2, const float *rho2, int64_t Np,
-                                            const VqDecideOut &o, int *wcount, int *wbase) {
+                                            const VqDecideOut &o, int *wcount, int *wbase, const float *rece2) {
+    if (rece2 != nullptr) {  // group path (uniform)
+        switch (nslices) {
+#define VQ_DECIDE_CASE(NSL) case NSL: decide_rows_impl<NSL, AGENT, true>(n, oob, st, Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase, rece2); break;
+            VQ_DECIDE_CASE(1) VQ_DECIDE_CASE(2) VQ_DECIDE_CASE(4)
+#undef VQ_DECIDE_CASE
+            default: break;  // (launch_coarse never picks another count on that path)
+        }
+        return;
+    }
     switch (nslices) {      // every thread of the workgroup takes the same case (the list appends contain barriers)
 #define VQ_DECIDE_CASE(NSL) case NSL: decide_rows_impl<NSL, AGENT>(n, oob, st, Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase); break;
         VQ_DECIDE_CASE(1) VQ_DECIDE_CASE(2) VQ_DECIDE_CASE(4) VQ_DECIDE_CASE(8) VQ_DECIDE_CASE(16)
@@ -208,7 +225,7 @@ __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats
 
 // stand-alone form (one thread per token, 1024-thread workgroups): used when the proposal kernel does not decide itself
 __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, int metric, int nslices, const float *rec,
-                                     const float *xh2, const float *rho2, int64_t Np, VqDecideOut o) {
+                                     const float *xh2, const float *rho2, int64_t Np, VqDecideOut o, const float *rece2 = nullptr) {
     __shared__ int wcount[3 * 16];
     __shared__ int wbase[3 * 16];
     if (o.n_dev != nullptr) {            // device-side row count (uniform: taken before any barrier)
@@ -219,7 +236,7 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool oob = n >= N;
     if (oob) n = N - 1;                  // out-of-range threads compute on a valid row and take part in the barriers
-    decide_rows<false>(n, oob, (const VqCbStats *)(cb + L.off_stats), L.Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase);
+    decide_rows<false>(n, oob, (const VqCbStats *)(cb + L.off_stats), L.Dp, metric, nslices, rec, xh2, rho2, Np, o, wcount, wbase, rece2);
 }
 
 // Second proposal pass over the rows of rescan_list only: same fp16 MFMA scores as coarse_kernel (bitwise: same
@@ -374,7 +391,7 @@ __device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave,
                                             const int *__restrict__ row_list, int *__restrict__ counters,
                                             const int *__restrict__ rescan_cnt,
                                             const int *__restrict__ cand_list, int *__restrict__ exact_list,
-                                            u64 *__restrict__ keys) {
+                                            u64 *__restrict__ keys, int groups = 0) {
     constexpr int XL = DT == 0 ? 8 : 4;                       // lanes per 32-dim latent row piece (16 bytes each)
     const int lane = threadIdx.x & 63;
     const VqCbStats stv = cb_stats_view((const VqCbStats *)(cb + L.off_stats));
@@ -403,7 +420,8 @@ __device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave,
                 v = rp[(2 * (j & 1)) * Np];
                 cd = __float_as_uint(rp[(2 * (j & 1) + 1) * Np]);
             }
-            float gbest = (j & 1) ? -INFINITY : v;            // best first-field value over the row's slices
+            float gbest = ((j & 1) && !groups) ? -INFINITY : v;   // best first-field value over the row's slices (group path: the
+                                                                  // two fields of a record are unordered, every slot counts)
             for (int off = 1; off < S; off <<= 1) gbest = fmaxf(gbest, __shfl_xor(gbest, off, 64));
             const float m = rvalid ? row_margin(st, L.Dp, metric, xh2[n], rho2[n]) : 0.0f;
             cand = rvalid && (j < 2 * nslices) && (v >= gbest - m) && cd != 0xFFFFFFFFu;
@@ -542,14 +560,14 @@ __global__ __launch_bounds__(256) void refine_rerank_kernel(const void *__restri
                                                             const int *__restrict__ rescan_list, int *__restrict__ counters,
                                                             const int *__restrict__ rescan_cnt,
                                                             const int *__restrict__ cand_list, int *__restrict__ exact_list,
-                                                            u64 *__restrict__ keys) {
+                                                            u64 *__restrict__ keys, int groups = 0) {
     __shared__ __attribute__((aligned(16))) float tile_e[4][32 * VQ_RR_STRIDE];
     __shared__ __attribute__((aligned(16))) float tile_x[4][8 * VQ_RR_STRIDE];
     const int wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < g0)
         rerank_rows<DT, 0>(tile_e[wave], tile_x[wave], (int64_t)blockIdx.x * 4 + wave, (int64_t)g0 * 4, x, e_exact, cb, L, D,
                            metric, nslices, S0, rec, xh2, rho2, xnorm, Np, idx, hist, multi_list, counters, nullptr, nullptr,
-                           nullptr, nullptr);
+                           nullptr, nullptr, groups);
     else
         rerank_rows<DT, 1>(tile_e[wave], tile_x[wave], (int64_t)(blockIdx.x - g0) * 4 + wave,
                            (int64_t)(gridDim.x - g0) * 4, x, e_exact, cb, L, D, metric, nslices, VQ_RESCAN_CAP, rec, xh2,
