@@ -215,7 +215,7 @@ static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
 struct VqGroupRun { int used, ks, noaux, pad_stage; };
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
                          const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, const VqDecideOut &dec,
-                         int *nslices_out, int *fused_decide_out, hipStream_t s, VqGroupLists grp = VqGroupLists{nullptr, nullptr, nullptr, nullptr, 0, 1},
+                         int *nslices_out, int *fused_decide_out, hipStream_t s, VqGroupLists grp = VqGroupLists{nullptr, nullptr, nullptr, nullptr, 0, 1, 0},
                          VqGroupRun *grun = nullptr) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
@@ -492,11 +492,11 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     VqDecideOut dec_arg = dec;                   // launch_coarse decides (knob 6, slice count) whether the proposal kernel runs the
     int fused_done = 0;                          // decision stage itself and reports it here
     // D <= 32 group path: request lists of the proposal kernel (cap = an equal share of the pool per code tile, whole batches of 32)
-    VqGroupLists grp{nullptr, nullptr, nullptr, nullptr, 0, 1};
+    VqGroupLists grp{nullptr, nullptr, nullptr, nullptr, 0, 1, 0};
     VqGroupRun grun{0, 0, 0, -1};
     const int ntiles_cb = (int)(L.nstages * L.tps);
     int nbuckets = 0;
-    if (W.nbkt > 0 && ntiles_cb <= VQ_GROUP_MAX_TILES) {
+    if (W.nbkt > 0 && ntiles_cb <= VQ_GROUP_MAX_TILES && N < (1ll << 30)) {
         grp.R = vq_group_replicas(ntiles_cb / VQ_GROUP_TILES);
         nbuckets = ntiles_cb / VQ_GROUP_TILES * grp.R;
         grp.bcnt = (int *)(w + W.off_bcnt);
@@ -504,6 +504,9 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         grp.bfrag = w + W.off_bfrag;
         grp.rece2 = (float *)(w + W.off_rece2);
         grp.cap = (int)(W.blist_entries / nbuckets / 32 * 32);
+        uint32_t bits = 1;                                   // group ids ride in the low mantissa bits of the running group maxima
+        while ((1u << bits) < (uint32_t)(ntiles_cb / VQ_GROUP_TILES)) ++bits;
+        grp.idmask = (1u << bits) - 1u;
     }
     rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s, grp, &grun);
     if (rc) return rc;

@@ -58,9 +58,11 @@ __device__ __forceinline__ float pair_rows_max(float v) {
 }
 
 // where the identification requests of the group records go (workspace: vq_ws_layout): one counter and a list of `cap`
-// entries (token | lane half << 31) per bucket; rece2[slice][half][token] receives the runner-up inside an identified group
+// entries (token | lane half << 30 | record slot << 31) per bucket, the token's B fragment beside it;
+// rece2[slice][slot][token] receives the runner-up inside an identified group; idmask: the low mantissa bits that carry a
+// group id in the stream kernel's running records (2^bits >= groups)
 // (bucket = tile * R + token block % R: vqhip_layout.h; counter of bucket b at bcnt[b * VQ_GROUP_CNT_STRIDE])
-struct VqGroupLists { int *bcnt; uint32_t *blist; char *bfrag; float *rece2; int cap, R; };
+struct VqGroupLists { int *bcnt; uint32_t *blist; char *bfrag; float *rece2; int cap, R; uint32_t idmask; };
 
 // One workgroup = WAVES waves x TT wide token tiles of 32 tokens (B fragments in registers for the whole kernel); the codebook
 // image streams through the LDS ring exactly as in coarse_kernel (NBUF stages of TPS tiles, filled two ahead, the second half
@@ -110,8 +112,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[t][s] = *(const half8 *)(ximg + t16 * (int64_t)VQ_CHUNK_BYTES + piece + s * 512);
     }
-    float b1[TT], b2[TT], mg[TT];
-    uint32_t t1[TT];
+    float b1[TT], b2[TT], b3[TT], mg[TT];                 // best / second / third group maximum, group id in the low bits
     float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;             // destinations of the asm maxima: live across the whole loop
     float gm[TT];                                         // running maximum of the group being streamed
 #pragma unroll
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
         const_norm = __builtin_amdgcn_readfirstlane((int)stv.l2_const_norm) != 0;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            b1[t] = -INFINITY; b2[t] = -INFINITY; t1[t] = 0;
+            b1[t] = -INFINITY; b2[t] = -INFINITY; b3[t] = -INFINITY;
             int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
             tokn = tokn < N ? tokn : N - 1;
             const float m = row_margin(&stv, Dp, metric, xh2[tokn], rho2[tokn]);
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
-        for (int q = 0; q < NE; ++q) accB[t][q] = -INFINITY;   // "previous tile" of the very first tile: never registers
+        for (int q = 0; q < NE; ++q) accB[t][q] = -3.0e38f;    // "previous tile" of the very first tile: its group id lies outside
+                                                               // the slice, so it never becomes a request (finite: the id bits
+                                                               // would turn -inf into a signalling NaN)
 
     for (int64_t it = st0; it < st1 + 1; ++it) {
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
@@ -197,11 +200,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
                     for (int u = 0; u < TT; ++u) after[u] = cur[u <= t ? u : t][0];
                     if (pg == 0) tile_max16<TT>(gm[t], sc1, sc2, prv[t], after);
                     else tile_max17<TT>(gm[t], sc0, sc1, sc2, prv[t], after);
-                    if (pg == GT - 1) {                    // the group is complete
-                        const float nb = vmax(b1[t], gm[t]);
-                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], gm[t]);
-                        t1[t] = (__float_as_uint(nb) != __float_as_uint(b1[t])) ? gid : t1[t];
-                        b1[t] = nb;
+                    if (pg == GT - 1) {                    // the group is complete: its maximum with the group id in the low
+                        // mantissa bits joins the lane's three best (one v_and_or, two v_med3, one v_max: the ids ride along)
+                        // (the "group" in front of the slice's first one has id -1: masked, it holds -3e38 and never matters)
+                        const float h = __uint_as_float((__float_as_uint(gm[t]) & ~grp.idmask) | (gid & grp.idmask));
+                        b3[t] = __builtin_amdgcn_fmed3f(b2[t], b3[t], h);
+                        b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], h);
+                        b1[t] = vmax(b1[t], h);
                     }
                 }
             }
@@ -217,51 +222,71 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
     if (st1 > st0) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const uint32_t old = __float_as_uint(b1[t]);
             float g = accB[t][0];
 #pragma unroll
             for (int e = 1; e < NE; ++e) g = __builtin_amdgcn_fmed3f(g, accB[t][e], INFINITY);   // max, NaN-transparent like v_max
             if constexpr (GT > 1) g = __builtin_amdgcn_fmed3f(g, gm[t], INFINITY);               // the last tile closes its group
-            b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], g);
-            b1[t] = vmax(b1[t], g);
-            t1[t] = (__float_as_uint(b1[t]) != old) ? (uint32_t)(st1 * (TPS / GT) - 1) : t1[t];
+            const float h = __uint_as_float((__float_as_uint(g) & ~grp.idmask) | (uint32_t)(st1 * (TPS / GT) - 1));
+            b3[t] = __builtin_amdgcn_fmed3f(b2[t], b3[t], h);
+            b2[t] = __builtin_amdgcn_fmed3f(b1[t], b2[t], h);
+            b1[t] = vmax(b1[t], h);
         }
     }
 
-    // ---- group records -> identification requests.  A lane whose best group can matter (within the row's margin of the best
-    // any lane of the token holds) files ONE request (token, lane half) under that group; identify32_kernel
-    // serves the requests group by group — 32 requests per MFMA, same fragments, same instruction, same initial value: the
-    // very scores of the stream — and writes the identified candidate into the record.  Everything else the lane has seen
-    // stays a value bound, raised to the largest value the index-bit form of the same score can take.  (Round 3 replayed
-    // the tile inside this kernel, one useful column per MFMA and ~55 vector instructions per token at the end of every
-    // wave: 30 % of the kernel at BASELINE configs[2], profiles/r04_c3_shares.txt.)
-    auto bound_up = [](float v) {
+    // ---- group records -> identification requests.  A lane's best group — and its second-best one — can matter when its
+    // maximum lies within the row's margin of the best any lane of the token holds; the lane then files a request (token,
+    // lane half, record slot) under that group, and identify32_kernel — 32 requests per MFMA, same fragments, same
+    // instruction, same initial value: the very scores of the stream — writes the identified candidate into the record.
+    // A record has two candidate slots per (token, slice): a lane's best group takes the slot of its half, its second-best
+    // group the partner's slot when the partner files nothing.  Everything else the lane has seen stays a value bound, raised
+    // to the largest value a score whose low bits were replaced (group id here, element id in the records) can have had.
+    // (Round 3 replayed the best tile inside this kernel, one useful column per MFMA and ~55 vector instructions per token at
+    // the end of every wave: 30 % of the kernel at BASELINE configs[2], profiles/r04_c3_shares.txt.)
+    const uint32_t idm = grp.idmask;
+    auto up = [idm](float v) {          // >= every score whose id-bit form is v
         const uint32_t b = __float_as_uint(v);
-        return __uint_as_float((b & 0x80000000u) ? (b & 0xFFFFFFF0u) : (b | 0xFu));
+        return __uint_as_float((b & 0x80000000u) ? (b & ~idm) : (b | idm));
     };
+    auto down = [idm](float v) {        // <= every such score
+        const uint32_t b = __float_as_uint(v);
+        return __uint_as_float((b & 0x80000000u) ? (b | idm) : (b & ~idm));
+    };
+    const uint32_t g0 = (uint32_t)(st0 * (TPS / GT)), g1 = (uint32_t)(st1 * (TPS / GT));
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        const float top = pair_rows_max(b1[t]);
+        const float top = pair_rows_max(down(b1[t]));           // a lower bound on the best score of the token in this slice
         const int64_t tokn = (tb * tpb + (wave * TT + t) * 2) * 16 + col;
         const bool live = tokn < N && (wave * TT + t) * 2 < tpb;
-        bool need = live && (mg[t] < INFINITY) && (b1[t] > -INFINITY) && !(b1[t] < top - mg[t]) &&
-                    t1[t] >= (uint32_t)(st0 * (TPS / GT)) && t1[t] < (uint32_t)(st1 * (TPS / GT));
-        int bucket = 0, pos = -1;
-        if (need) {
-            bucket = (int)t1[t] * grp.R + (int)(tb & (grp.R - 1));
-            pos = atomicAdd(&grp.bcnt[(int64_t)bucket * VQ_GROUP_CNT_STRIDE], 1);
-            if (pos < grp.cap) grp.blist[(int64_t)bucket * grp.cap + pos] = (uint32_t)tokn | ((uint32_t)half << 31);
-            else { need = false; pos = -1; }   // the bucket's list is full: the group stays a bound (the row takes the second pass)
+        const uint32_t id1 = __float_as_uint(b1[t]) & idm, id2 = __float_as_uint(b2[t]) & idm;
+        const bool usable = live && (mg[t] < INFINITY) && (b1[t] > -INFINITY);
+        bool need1 = usable && !(up(b1[t]) < top - mg[t]) && id1 >= g0 && id1 < g1;
+        const bool pneed1 = __shfl_xor((int)need1, 32, 64) != 0;
+        bool need2 = need1 && !pneed1 && (b2[t] > -INFINITY) && !(up(b2[t]) < top - mg[t]) && id2 >= g0 && id2 < g1;
+        int bucket[2] = {0, 0}, pos[2] = {-1, -1};
+        const uint32_t word = (uint32_t)tokn | ((uint32_t)half << 30);
+        if (need1) {
+            bucket[0] = (int)id1 * grp.R + (int)(tb & (grp.R - 1));
+            pos[0] = atomicAdd(&grp.bcnt[(int64_t)bucket[0] * VQ_GROUP_CNT_STRIDE], 1);
         }
-        {   // the token's B fragment travels with the request: this lane's dims into its own request's entry and its partner's
-            const int ppos = __shfl_xor(pos, 32, 64), pbucket = __shfl_xor(bucket, 32, 64);
+        if (need2) {
+            bucket[1] = (int)id2 * grp.R + (int)(tb & (grp.R - 1));
+            pos[1] = atomicAdd(&grp.bcnt[(int64_t)bucket[1] * VQ_GROUP_CNT_STRIDE], 1);
+        }
+        // a full list: the group stays a bound (the row takes the second pass)
+        if (need1) { if (pos[0] < grp.cap) grp.blist[(int64_t)bucket[0] * grp.cap + pos[0]] = word | ((uint32_t)half << 31); else { need1 = false; pos[0] = -1; } }
+        if (need2) { if (pos[1] < grp.cap) grp.blist[(int64_t)bucket[1] * grp.cap + pos[1]] = word | ((uint32_t)(1 - half) << 31); else { need2 = false; pos[1] = -1; } }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {   // the token's B fragment travels with the request: this lane's dims into its own entries and its partner's
+            const int ppos = __shfl_xor(pos[r], 32, 64), pbucket = __shfl_xor(bucket[r], 32, 64);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                if (pos >= 0) *(half8 *)(grp.bfrag + ((((int64_t)bucket * grp.cap + pos) * 2 + half) * KS + s) * 16) = xf[t][s];
+                if (pos[r] >= 0) *(half8 *)(grp.bfrag + ((((int64_t)bucket[r] * grp.cap + pos[r]) * 2 + half) * KS + s) * 16) = xf[t][s];
                 if (ppos >= 0) *(half8 *)(grp.bfrag + ((((int64_t)pbucket * grp.cap + ppos) * 2 + half) * KS + s) * 16) = xf[t][s];
             }
         }
-        float bound = need ? bound_up(b2[t]) : fmaxf(bound_up(b2[t]), bound_up(b1[t]));
+        float bound = up(b3[t]);
+        if (!need1) bound = fmaxf(bound, up(b1[t]));
+        if (!need2) bound = fmaxf(bound, up(b2[t]));
         bound = fmaxf(bound, __shfl_xor(bound, 32, 64));        // the two lanes that share the token
         if (lane < 32 && live) {
             float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
 // wave runs the stream's own instruction (same fragments, same initial value: the very scores of the stream) and the
 // per-element update (element id in the 4 low mantissa bits, runner-up) on the 16 scores each lane holds, folding the GT
 // tiles' (best, runner-up) pairs; the lane that holds the requested half writes
-//   rec[slice][2 half .. 2 half + 1][token] = (best score of the group, its code)      rece2[slice][half][token] = runner-up.
+//   rec[slice][2 slot .. 2 slot + 1][token] = (best score of the group, its code)      rece2[slice][slot][token] = runner-up.
 template <int KS, int GT>
 __global__ __launch_bounds__(256, 3) void identify32_kernel(const char *__restrict__ frag, int64_t nstages,
                                                             int nslices, int nbuckets, float *__restrict__ rec,
@@ -367,14 +392,14 @@ __global__ __launch_bounds__(256, 3) void identify32_kernel(const char *__restri
         }
 #pragma unroll
         for (int b = 0; b < G; ++b) {
-            const int want = (int)(entry[b] >> 31);
+            const int want = (int)((entry[b] >> 30) & 1u), slot = (int)(entry[b] >> 31);    // lane half that asked, record slot
             if (base + 32 * b + col < cnt && half == want) {
-                const int64_t tk = (int64_t)(entry[b] & 0x7FFFFFFFu);
+                const int64_t tk = (int64_t)(entry[b] & 0x3FFFFFFFu);
                 const uint32_t code = (uint32_t)(gid * GT + Tb[b]) * 32u + (uint32_t)mfma_row((int)(__float_as_uint(W1[b]) & 15u), half);
-                float *rp = rec + ((int64_t)sl * VQ_REC_FIELDS + 2 * want) * Np + tk;
+                float *rp = rec + ((int64_t)sl * VQ_REC_FIELDS + 2 * slot) * Np + tk;
                 rp[0] = W1[b];
                 rp[Np] = __uint_as_float(code);
-                grp.rece2[(int64_t)(sl * 2 + want) * Np + tk] = W2[b];
+                grp.rece2[(int64_t)(sl * 2 + slot) * Np + tk] = W2[b];
             }
         }
     }
