@@ -290,15 +290,17 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         is multiplied by 0 (include/vqhip.h, vqhip_cvq_rows).  Same codebooks bit for bit on finite data; the column argmin
         runs over a fraction of the codebook and ONE all-reduce carries histogram, token count and [M, D] anchors instead
         of three collectives and a [K, D] tensor.  The list is built on the device from the synchronised probabilities, so
-        every rank has the same one and nothing waits for the host: the count a step needs to size its exchange was
-        copied to pinned memory at the end of the previous step; under HIP-graph capture the launches are sized for K and
-        the device-side count decides.  Automatic = NearestAnchor without sync, fused distance, D with a proposal image.
+        every rank has the same one.  Eager steps size their exchange from a count that was copied to pinned memory at the
+        end of the PREVIOUS step: the one host wait of a step is on the event of that copy, queued a whole step earlier
+        (it caps the host's run-ahead at one step; a first step, or probabilities replaced from outside, count on the spot);
+        under HIP-graph capture the launches are sized for K and the device-side count decides.  Automatic = NearestAnchor without sync, fused distance, D with a proposal image.
         False: the reference's dense data flow (a [K, D] anchor tensor, all-reduced on its own)."""
         super().__init__(*args, **kwargs)
         self._anchor = anchor
         self._eps = eps
         self._sparse_anchors = sparse_anchors
         self._listed = None               # (p tensor, its _version, rows, slot, count, pinned host count, copy event)
+        self._pinned_count = None
         self.last_exchange_rows = None    # M of the last training step (diagnostics: bench.py, tests)
 
     @classmethod
@@ -319,6 +321,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         return self.quantizer.get_buffer('_probability')
 
     def _update_probability(self, value: torch.Tensor) -> None:
+        self._listed = None               # a list prefetched for the old probabilities is void (`_prefetch_listed` re-arms it)
         if self.quantizer.inplace_updates and '_probability' in self.quantizer._buffers \
                 and self.quantizer._buffers['_probability'].shape == value.shape \
                 and self.quantizer._buffers['_probability'].device == value.device:
@@ -346,7 +349,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
             rows, slot, count = ops.cvq_rows(p, K, self._ema.decay, self._eps)
             return rows, slot, count, K
         st = self._listed
-        if st is not None and st[0] is p and st[1] == p._version:
+        if st is not None and st[0] is self.probability and st[1] == st[0]._version and p.data_ptr() == st[0].data_ptr():
             st[6].synchronize()                                   # the copy was queued a whole step ago
             return st[2], st[3], st[4], int(st[5][0])
         rows, slot, count = ops.cvq_rows(p, K, self._ema.decay, self._eps)
@@ -354,7 +357,9 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
 
     def _prefetch_listed(self, p_new: torch.Tensor, K: int) -> None:
         rows, slot, count = ops.cvq_rows(p_new, K, self._ema.decay, self._eps)
-        host = self._listed[5] if self._listed is not None else torch.empty(1, dtype=torch.int32).pin_memory()
+        if self._pinned_count is None:                   # one pinned word for the life of the callback
+            self._pinned_count = torch.empty(1, dtype=torch.int32).pin_memory()
+        host = self._pinned_count
         host.copy_(count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

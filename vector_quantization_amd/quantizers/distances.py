@@ -172,8 +172,12 @@ class BaseDistance(nn.Module, ABC):
         """The codebook operand of the fp32 definition alone."""
         return e.detach()
 
+    def metric_for(self, D: int) -> str:
+        """The metric of a fused encode over D-dimensional rows (``metric``, unless a distance narrows it by D)."""
+        return self.metric
+
     def prepare(self, e: torch.Tensor, metric: Optional[str] = None) -> ops.PreparedCodebook:
-        return ops.prepare_codebook(e, metric or self.metric)
+        return ops.prepare_codebook(e, metric or self.metric_for(e.shape[-1]))
 
     def encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor] = None,
                stash: Optional[dict] = None, zero_hist: bool = False) -> torch.Tensor:
@@ -186,7 +190,7 @@ class BaseDistance(nn.Module, ABC):
 
     def _fused_encode(self, x: torch.Tensor, e: torch.Tensor, hist: Optional[torch.Tensor],
                       stash: Optional[dict], zero_hist: bool = False) -> torch.Tensor:
-        quant, cb, xq = ops.encode(x.detach(), e.detach(), self.metric, hist=hist, zero_hist=zero_hist)
+        quant, cb, xq = ops.encode(x.detach(), e.detach(), self.metric_for(e.shape[-1]), hist=hist, zero_hist=zero_hist)
         if stash is not None:
             stash['xq'] = xq if xq is not None else x.detach()
             rows = cb.exact_rows()
@@ -199,7 +203,7 @@ class BaseDistance(nn.Module, ABC):
                    stash: Optional[dict] = None, zero_hist: bool = False):
         """``encode`` on the NCHW feature map [B, D, H, W] (ops.encode_map): returns (quant [B*H*W], x_rows [B*H*W, D]) —
         x_rows = the token-major latents the rest of the step works on (L2: a copy in the map's dtype)."""
-        quant, cb, xrows, xq = ops.encode_map(x_map.detach(), e.detach(), self.metric, hist=hist, zero_hist=zero_hist)
+        quant, cb, xrows, xq = ops.encode_map(x_map.detach(), e.detach(), self.metric_for(e.shape[-1]), hist=hist, zero_hist=zero_hist)
         if stash is not None:
             stash['xq'] = xq if xq is not None else xrows
             stash['eq'] = cb.exact_rows() if xq is not None else e.detach()
@@ -273,6 +277,14 @@ class CosineDistance(BaseDistance):
     @property
     def metric(self) -> str:
         return 'CosineBF16' if self._bf16() else 'Cosine'
+
+    def metric_for(self, D: int) -> str:
+        # 'auto' follows the caller only where the library has the bf16-autocast form (D <= 1024, D % 8 == 0: it lives on
+        # the proposal image); elsewhere the fp32 definition keeps an unchanged config running as it did outside autocast.
+        # An explicit autocast='bf16' is a request and fails loudly in the library instead.
+        if self._autocast == 'auto' and not ops.coarse_supported(D):
+            return 'Cosine'
+        return self.metric
 
     def _operand(self, t: torch.Tensor, metric: Optional[str] = None) -> torch.Tensor:
         n = ops.normalize_rows(t.detach())

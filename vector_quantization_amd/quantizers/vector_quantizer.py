@@ -198,6 +198,10 @@ class VectorQuantizer(BaseQuantizer):
             return False
         if type(self)._encode is not VectorQuantizer._encode or not hasattr(self._distance, 'encode_map'):
             return False
+        # the map entry points are called directly, not through nn.Module.__call__: a registered hook (the one-shot lazy-init
+        # pre-hook of LazyInitWeightsMixin, or anything a user attached) would never run — such a module takes the token route
+        if len(self._forward_pre_hooks) > 0 or len(self._forward_hooks) > 0:
+            return False
         return all(type(cb).before_encode is BaseCallback.before_encode for cb in self._callbacks.callbacks)
 
     def encode_map(self, x_map: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:

@@ -143,8 +143,11 @@ class LlamaGenTokenizeCallback(BaseCallback):
 # ---- codebook metrics ---------------------------------------------------------------------------------------------------
 
 class CodebookMixin(BaseMetric):
-    """runners/metrics.py:25-56.  ``forward`` takes the int32 histogram the fused encode already produced
-    (``memo['quantizer']['encode']['hist']``) when the accessor points at that quantizer's tokens, else one ``vqhip_hist``."""
+    """runners/metrics.py:25-56.  ``forward`` counts the tokens the accessor points at with one ``vqhip_hist`` launch
+    (block-private LDS bins; int64 running totals like the reference's ``bincount``).  Device tokens only: like every
+    other entry of this package there is no CPU path (``ops`` raises on a CPU tensor) — the reference's metric also runs
+    on CPU tokens.  The summaries are evaluated in float64 on the device (``vqhip_codebook_metrics``) where the reference
+    goes through fp32 ``Categorical.entropy``: equal to ~1e-6 relative, not bitwise (tests/test_runners.py)."""
 
     def __init__(self, *args, quant: str, **kwargs) -> None:
         super().__init__(*args, **kwargs)

@@ -119,7 +119,9 @@ def decode_from_quant(quantizer, quant: torch.Tensor, memo: dict, token_major: b
     z [B,C,H,W] (``token_major=True``: as a zero-copy channels-last view of the gathered rows)."""
     from .quantizers.memo import get_memo
     b, h, w = quant.shape
-    if (not token_major and hasattr(quantizer, 'decode_map') and quant.is_cuda and not torch.is_grad_enabled()
+    from .quantizers.vector_quantizer import VectorQuantizer
+    if (not token_major and isinstance(quantizer, VectorQuantizer) and quant.is_cuda and not torch.is_grad_enabled()
+            and getattr(quantizer, '_fused', True) and type(quantizer)._decode is VectorQuantizer._decode
             and not quantizer._callbacks.overrides_decode_or_loss()):
         return quantizer.decode_map(quant, get_memo(memo, 'quantizer'))[0], memo     # rows gathered straight into the NCHW map
     z, memo['quantizer'] = quantizer.decode(quant.reshape(-1), get_memo(memo, 'quantizer'))
