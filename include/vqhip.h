@@ -42,7 +42,11 @@ extern "C" {
 /* CosineDistance as the reference's GPU runs evaluate it under bf16 autocast (vq/runners/base.py:30-48: normalize is on
  * autocast's fp32 list, the einsum on its bf16 list): operands rounded to bf16 after the fp32 normalisation, products
  * summed in fp32 (here: the k-ordered fma chain of the fp32 definition), the sum rounded to bf16, 1 - s rounded to bf16,
- * lowest index among equal bf16 distances.  Opt-in; the default cosine metric is the fp32 definition. */
+ * lowest index among equal bf16 distances.  This is what the reference returns inside its autocast region: a caller of
+ * this ABI that replaces distances.py:39-46 there must pass THIS metric (check torch.is_autocast_enabled('cuda') and
+ * torch.get_autocast_dtype('cuda') == torch.bfloat16, as the Python CosineDistance of this package does by itself;
+ * INTEGRATION.md, binding B) — VQHIP_METRIC_COS is the fp32 definition, the reference's result OUTSIDE autocast.  Exists
+ * where the proposal image does (D <= 1024, D % 8 == 0). */
 #define VQHIP_METRIC_COS_BF16 5
 
 #define VQHIP_DTYPE_F32 0
