@@ -16,8 +16,11 @@ for kv in filter(None, os.environ.get('VQHIP_TUNE', '').split(',')):      # e.g.
     k, v = kv.split('='); L.vqhip_set_tuning(int(k), int(v))
 g = torch.Generator(device='cuda').manual_seed(3407)
 w = torch.randn(K, D, device='cuda', generator=g); x = torch.randn(N, D, device='cuda', generator=g)
-if metric == 'Cosine': x = ops.normalize_rows(x)
+one_call = bool(os.environ.get('VQ_EXP_ENCODE'))      # the training-time form: ops.encode on the raw latents (one library call)
+if metric == 'Cosine' and not one_call: x = ops.normalize_rows(x)
 def enc():
+    if one_call:
+        return ops.encode(x, w, metric)[0]
     cb = ops.prepare_codebook(w, metric)
     return ops.argmin(x, cb)
 for _ in range(8): idx = enc()

@@ -435,6 +435,11 @@ static int codebook_prepare_impl(const float *e, int64_t K, int D, int metric, v
     hipStream_t s = (hipStream_t)stream;
     VqCbLayout L = vq_cb_layout(K, D);
     char *c = (char *)cb;
+    if (VQ_IS_COS(metric) && vq_coarse_supported(D)) {      // cosine: statistics and image in ONE launch (cb_cos_body)
+        cb_cos_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(e, K, D, metric, c, L);
+        VQ_CHECK_LAUNCH("cb_cos_kernel");
+        return VQHIP_OK;
+    }
     cb_stats_kernel<<<(int)((K + 15) / 16), 256, 0, s>>>(e, K, D, metric, c, L);
     VQ_CHECK_LAUNCH("cb_stats_kernel");
     if (vq_coarse_supported(D)) {
@@ -569,20 +574,25 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
-    const int nblk_stats = (int)((Kc + 15) / 16), xgrid = (int)((N + 31) / 32), narrive = (int)W.narrive;
+    const bool cosimg = VQ_IS_COS(cb_metric);            // cosine: the whole codebook preparation rides in the same launch
+    const int nblk_stats = cosimg ? (int)(L.nstages * L.tps) : (int)((Kc + 15) / 16);
+    const int xgrid = (int)((N + 31) / 32), narrive = (int)W.narrive;
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
     char *ximg = w + W.off_ximg;
-#define VQ_PRE(DT, XN, MAP) pre_kernel<DT, XN, MAP><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
+#define VQ_PRE(DT, XN, MAP, COSI) pre_kernel<DT, XN, MAP, COSI><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
+#define VQ_PRE2(DT, XN, MAP) do { if (cosimg) VQ_PRE(DT, XN, MAP, true); else VQ_PRE(DT, XN, MAP, false); } while (0)
     if (hw > 0) {
-        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true, true); else VQ_PRE(0, false, true); }
-        else { if (xnorm) VQ_PRE(1, true, true); else VQ_PRE(1, false, true); }
+        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE2(0, true, true); else VQ_PRE2(0, false, true); }
+        else { if (xnorm) VQ_PRE2(1, true, true); else VQ_PRE2(1, false, true); }
     } else {
-        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE(0, true, false); else VQ_PRE(0, false, false); }
-        else { if (xnorm) VQ_PRE(1, true, false); else VQ_PRE(1, false, false); }
+        if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE2(0, true, false); else VQ_PRE2(0, false, false); }
+        else { if (xnorm) VQ_PRE2(1, true, false); else VQ_PRE2(1, false, false); }
     }
+#undef VQ_PRE2
 #undef VQ_PRE
     VQ_CHECK_LAUNCH("pre_kernel");
+    if (cosimg) return VQHIP_OK;
     cb_image_kernel<<<(int)(L.nstages * L.tps), 256, 0, s>>>(codes, Kc, D, cb_metric, c, L);
     VQ_CHECK_LAUNCH("cb_image_kernel");
     return VQHIP_OK;

@@ -206,6 +206,30 @@ __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
         const uint32_t r2 = __shfl_xor(r, off, 64), h2 = __shfl_xor(h, off, 64), b2 = __shfl_xor(bad, off, 64);
         r = r > r2 ? r : r2; h = h > h2 ? h : h2; bad |= b2;
     }
+    if (v.part2_n != 0u) {      // cosine image made in one launch: per-tile partials instead of the slots (wave-uniform)
+        const f32x4 *part = (const f32x4 *)((const char *)st + v.part2_off);
+        float pr = 0.0f, ph = 0.0f, pb = 0.0f, pe = 0.0f;
+        // 512 partials (K = 16 384) per pass: the lane's eight loads are all in flight before the first is used (a plain
+        // loop waited for each in turn: eight serialized L2 round trips in front of every consumer wave's first instruction)
+        for (uint32_t base = 0; base < v.part2_n; base += 512u) {
+            f32x4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = base + (uint32_t)lane + 64u * (uint32_t)u;
+                q[u] = part[i < v.part2_n ? i : 0u];            // (a repeated entry changes no maximum)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { pr = fmaxf(pr, q[u][0]); ph = fmaxf(ph, q[u][1]); pb = fmaxf(pb, q[u][2]); pe = fmaxf(pe, q[u][3]); }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            pr = fmaxf(pr, __shfl_xor(pr, off, 64)); ph = fmaxf(ph, __shfl_xor(ph, off, 64));
+            pb = fmaxf(pb, __shfl_xor(pb, off, 64)); pe = fmaxf(pe, __shfl_xor(pe, off, 64));
+        }
+        v.r2max_bits = __float_as_uint(pr); v.eh2max_bits = __float_as_uint(ph); v.e2max_bits = __float_as_uint(pe);
+        v.nonfinite |= (pb > 0.0f || !(pr == pr) || !(ph == ph) || !(pe == pe)) ? 1u : 0u;
+        return v;
+    }
     v.r2max_bits = r; v.eh2max_bits = h; v.nonfinite |= bad;
     return v;
 }

@@ -55,7 +55,7 @@ VQ_HD VqCbLayout vq_cb_layout(int64_t K, int D) {
     L.nblk2 = L.nstages * L.tps;             // cb_image_kernel: one tile per block
     // [256, 256 + 16*128): VQ_CB_SLOTS maxima slots of cb_image_kernel, one 128-byte line each (see cb_stats_view)
     L.off_part1 = 256 + VQ_CB_SLOTS * 128;   // float4 {max|e|, max e2, L2: -(min |e|^2) / else 0, bad} per stats block
-    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // (unused since round 2: the image kernel raises the header maxima itself)
+    L.off_part2 = L.off_part1 + L.nblk1 * 16;  // cosine: one float4 per image tile (cb_cos_body); unused for L2 / DOT
     L.off_en = (L.off_part2 + L.nblk2 * 16 + 255) / 256 * 256;
     L.off_eexact = (L.off_en + L.Kp * 4 + 255) / 256 * 256;
     L.off_frag = (L.off_eexact + K * (int64_t)D * 4 + 1023) / 1024 * 1024;
@@ -74,6 +74,9 @@ struct VqCbStats {
     int32_t metric;
     uint32_t finalized;     // the image kernel has run (r2max/eh2max/nonfinite are raised by it with filtered atomics)
     uint32_t en_spread_bits;  // L2, constant-norm codebook (below): max_k |e_k|^2 - min_k |e_k|^2, else 0
+    uint32_t part2_n;         // cosine (one-launch preparation, cb_cos_body): the image's per-tile maxima are NOT in the slots
+    uint32_t part2_off;       // but in part2_n float4 partials {max residual^2, max image norm^2, bad, max |e_hat|^2} at this byte
+                              // offset from the header (no zeroing launch needed in front); 0: the slots (L2 / DOT)
     uint32_t l2_const_norm;   // L2 and the norms agree to 2^-16 relative (a NormalizeCallback codebook): the proposal scores
                               // carry NO -|e_k|^2/2 term (aux values of real codes are 0) and the row margin carries the
                               // spread instead — the aux reads were a third of the D <= 16 kernel's time (vqhip_proposal32_kernels.h)

@@ -62,23 +62,13 @@ __device__ __forceinline__ float block_max4(float v, float *red) {    // max ove
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
-// The four rows of a wave are loaded together and reduced with interleaved shuffle trees; maxima are reduced per
-// block and written as one partial per block (same-line atomics from ~1000 concurrent blocks cost ~25 us).
-__device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64_t K, int D, int metric, char *cb, const VqCbLayout &L) {
-    __shared__ float red[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
-    float *en = (float *)(cb + L.off_en);
-    float *ex = (float *)(cb + L.off_eexact);
-    // the maxima slots cb_image_kernel (the next launch) raises start from zero
-    if (blk == 0 && threadIdx.x < VQ_CB_SLOTS) {
-        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + threadIdx.x * 128);
-        slot[0] = 0u; slot[1] = 0u; slot[2] = 0u;
-    }
-    const int64_t k0 = (blk * 4 + wave) * 4;
-    float p[4] = {0, 0, 0, 0}, amax = 0.0f;
-    bool bad = false;
+// Four codebook rows k0 .. k0 + 3 by one wave: |e_k|^2 in oracle order, optional normalisation into e_exact (cosine), max |e|,
+// flags — folded into the caller's running maxima (amax per lane; m_e2 / m_en wave-uniform; bad per lane).
+// The four rows are loaded together and reduced with interleaved shuffle trees.
+__device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, int D, int metric, float *en, float *ex,
+                                         float &amax, float &m_e2, float &m_en, bool &bad) {
+    const int lane = threadIdx.x & 63;
+    float p[4] = {0, 0, 0, 0};
     // D <= 256: the wave's four rows live in registers (lane l holds dims l, l + 64, l + 128, l + 192 of each): all 16 loads
     // are in flight together and the cosine form below normalises from the registers instead of reading the rows again
     // (19.7 -> us at K = 16 384, D = 256, cosine).  Same per-lane chains in the same order: same |e_k|^2 to the bit.
@@ -111,7 +101,6 @@ __device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64
     for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
         for (int c = 0; c < 4; ++c) p[c] = p[c] + __shfl_xor(p[c], off, 64);
-    float m_e2 = 0.0f, m_en = VQ_IS_L2(metric) ? -INFINITY : 0.0f;   // L2: m_en = -(smallest |e_k|^2) (max-reduced like the rest)
     if (VQ_IS_COS(metric)) {
         amax = 0.0f;
 #pragma unroll
@@ -153,6 +142,27 @@ __device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64
             if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, -p[c]);
         }
     }
+}
+
+// pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
+// The four rows of a wave are loaded together and reduced with interleaved shuffle trees; maxima are reduced per
+// block and written as one partial per block (same-line atomics from ~1000 concurrent blocks cost ~25 us).
+__device__ __forceinline__ void cb_stats_body(int64_t blk, const float *e, int64_t K, int D, int metric, char *cb, const VqCbLayout &L) {
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6;
+    VqCbStats *st = (VqCbStats *)(cb + L.off_stats);
+    float *en = (float *)(cb + L.off_en);
+    float *ex = (float *)(cb + L.off_eexact);
+    // the maxima slots cb_image_kernel (the next launch) raises start from zero
+    if (blk == 0 && threadIdx.x < VQ_CB_SLOTS) {
+        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + threadIdx.x * 128);
+        slot[0] = 0u; slot[1] = 0u; slot[2] = 0u;
+    }
+    const int64_t k0 = (blk * 4 + wave) * 4;
+    float amax = 0.0f;
+    bool bad = false;
+    float m_e2 = 0.0f, m_en = VQ_IS_L2(metric) ? -INFINITY : 0.0f;   // L2: m_en = -(smallest |e_k|^2) (max-reduced like the rest)
+    cb_rows4(k0, e, K, D, metric, en, ex, amax, m_e2, m_en, bad);
     amax = wave_max(amax);
     bad = __any(bad);
     amax = block_max4(amax, red); m_e2 = block_max4(m_e2, red); m_en = block_max4(m_en, red);
@@ -169,10 +179,14 @@ __global__ __launch_bounds__(256) void cb_stats_kernel(const float *e, int64_t K
 // residual / image norms with the final scale.
 // chunk (tile T, k-step s of 32 dims, half c) holds, for lane l, code T*32 + 16c + (l&15), dims 32s + 8(l>>4) .. +8 —
 // exactly the A operand of v_mfma_f32_16x16x32_f16 — so a linear global_load_lds copy gives a conflict-free LDS image.
-__global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+// COSFUSED: the cosine preparation in ONE launch (cb_cos_body below calls this behind its own normalisation pass): the scale is
+// the constant 2^13 (normalised rows: max |e_hat| <= 1, header maxabs = 1.0f), nothing is reduced from the statistics
+// partials, and the tile's maxima go into its own float4 of the part2 array instead of the zero-initialised slots.
+template <bool COSFUSED>
+__device__ __forceinline__ void cb_image_body(int64_t tile, const float *e, int64_t K, int D, int metric, char *cb, const VqCbLayout &L,
+                                              float tile_e2max = 0.0f, float tile_bad = 0.0f) {
     __shared__ float red[2][8][32];
     __shared__ float red4[4];
-    const int64_t tile = blockIdx.x;
     const int64_t stage = tile / L.tps;
     const int ti = (int)(tile % L.tps);
     const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -181,7 +195,14 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     const float *en = (const float *)(cb + L.off_en);
     // every block reduces the statistics partials (16 KiB, L2-resident) to the global maxima -> the common scale
     VqCbStats g_st;
-    {
+    if constexpr (COSFUSED) {
+        g_st.maxabs_bits = __float_as_uint(1.0f); g_st.nonfinite = 0u; g_st.l2_const_norm = 0u;
+        if (tile == 0 && threadIdx.x == 0) {
+            st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = 0u; st->enmax_bits = 0u; st->nonfinite = 0u; st->metric = metric;
+            st->finalized = 1u; st->en_spread_bits = 0u; st->l2_const_norm = 0u; st->r2max_bits = 0u; st->eh2max_bits = 0u;
+            st->part2_n = (uint32_t)L.nblk2; st->part2_off = (uint32_t)(L.off_part2 - L.off_stats);
+        }
+    } else {
         const f32x4 *part = (const f32x4 *)(cb + L.off_part1);
         float a0 = 0.0f, a1 = 0.0f, a2 = VQ_IS_L2(metric) ? -INFINITY : 0.0f, a3 = 0.0f;
         for (int64_t i = threadIdx.x; i < L.nblk1; i += 256) {
@@ -201,11 +222,12 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
         g_st.en_spread_bits = const_norm ? __float_as_uint(spread) : 0u;
         g_st.l2_const_norm = const_norm ? 1u : 0u;
         g_st.nonfinite = a3 > 0.0f ? 1u : 0u;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (tile == 0 && threadIdx.x == 0) {
             st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = g_st.e2max_bits; st->enmax_bits = g_st.enmax_bits;
             st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 1u;
             st->en_spread_bits = g_st.en_spread_bits; st->l2_const_norm = g_st.l2_const_norm;
             st->r2max_bits = 0u; st->eh2max_bits = 0u;       // (the image's own maxima live in the slots: cb_stats_view)
+            st->part2_n = 0u; st->part2_off = 0u;
         }
     }
     const float se = cb_scale(&g_st), inv = 1.0f / se;
@@ -262,12 +284,44 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     // (Tried first: an arrival ticket with the last workgroup folding per-block partials — its agent-scope release writes the
     // XCD's dirty L2 lines, i.e. the image, back: 8.5 -> 19 us at K = 16 384, D = 256; and read-then-atomic on three header
     // words — two dependent device-scope round trips at the end of every workgroup: 15 us.)
-    if (threadIdx.x == 0) {
-        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + (blockIdx.x % VQ_CB_SLOTS) * 128);
+    if constexpr (COSFUSED) {
+        if (threadIdx.x == 0) ((f32x4 *)(cb + L.off_part2))[tile] = f32x4{a, b, fmaxf(badf, tile_bad), tile_e2max};
+    } else if (threadIdx.x == 0) {
+        uint32_t *slot = (uint32_t *)(cb + L.off_stats + 256 + (tile % VQ_CB_SLOTS) * 128);
         atomicMax(&slot[0], __float_as_uint(a));
         atomicMax(&slot[1], __float_as_uint(b));
         if (badf > 0.0f) atomicMax(&slot[2], 1u);
     }
+}
+__global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    cb_image_body<false>(blockIdx.x, e, K, D, metric, cb, L);
+}
+
+// Cosine codebooks in ONE launch (one 256-thread block per tile of 32 codes): the tile's rows are normalised first — cb_rows4's
+// arithmetic, a wave per 8 rows — into e_exact, then the block turns them into its piece of the fragment-major image.
+// Possible because a normalised codebook needs no statistics pass for its scale (|e_hat| <= 1: the power-of-two scale is
+// 2^13 whatever the data; fp16's relative precision does not depend on it), and because the tile's maxima go into a per-tile
+// partial instead of slots somebody would have to zero first.  One launch less in front of every cosine encode; the blocks
+// can share a launch with the token side (pre_kernel).
+__device__ __forceinline__ void cb_cos_body(int64_t tile, const float *e, int64_t K, int D, int metric, char *cb, const VqCbLayout &L) {
+    __shared__ float cred[4];
+    const int wave = threadIdx.x >> 6;
+    float *en = (float *)(cb + L.off_en);
+    float *ex = (float *)(cb + L.off_eexact);
+    float amax = 0.0f, m_e2 = 0.0f, m_en = 0.0f;
+    bool bad = false;
+    cb_rows4(tile * VQ_TILE_CODES + wave * 8, e, K, D, metric, en, ex, amax, m_e2, m_en, bad);
+    cb_rows4(tile * VQ_TILE_CODES + wave * 8 + 4, e, K, D, metric, en, ex, amax, m_e2, m_en, bad);
+    const float e2 = block_max4(m_e2, cred);
+    const float badf = block_max4(__any(bad) ? 1.0f : 0.0f, cred);
+    // the rows this block has just written are read back below by other waves of the block (same CU: workgroup scope)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    cb_image_body<true>(tile, e, K, D, metric, cb, L, e2, badf);
+}
+__global__ __launch_bounds__(256) void cb_cos_kernel(const float *e, int64_t K, int D, int metric, char *cb, VqCbLayout L) {
+    cb_cos_body(blockIdx.x, e, K, D, metric, cb, L);
 }
 
 // Token side at a padded dimension of 32 (D <= 32: the VQ-KD and LlamaGen shapes): a wave = 16 tokens x 4 pieces of 8 dims,
@@ -577,7 +631,9 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 }
 // vqhip_encode / vqhip_col_argmin: the codebook statistics and the token side in ONE launch (they are independent;
 // the image kernel that follows needs the former, the proposal kernel both)
-template <int DT, bool XNORM, bool NCHW = false>
+// COSIMG: `nblk_stats` blocks of cb_cos_body (one per image tile: the whole cosine preparation) instead of statistics blocks —
+// no image launch follows.
+template <int DT, bool XNORM, bool NCHW = false, bool COSIMG = false>
 __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int metric, char *cb, VqCbLayout L, int nblk_stats,
                                                   const void *__restrict__ x, int64_t N, int D, int nstep,
                                                   char *__restrict__ ximg, float *__restrict__ xh2,
@@ -592,7 +648,10 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
     const bool x_first = xgrid < nblk_stats;
     const int b = (int)blockIdx.x;
     const bool is_x = x_first ? b < xgrid : b >= nblk_stats;
-    if (!is_x) cb_stats_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
+    if (!is_x) {
+        if constexpr (COSIMG) cb_cos_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
+        else cb_stats_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
+    }
     else x_prep_body<DT, XNORM, NCHW>((int64_t)(x_first ? b : b - nblk_stats), x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
                                       VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows);
 }

@@ -112,6 +112,19 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[t][s] = *(const half8 *)(ximg + t16 * (int64_t)VQ_CHUNK_BYTES + piece + s * 512);
     }
+    auto issue_stage = [&](int64_t st, int buf) {
+        const char *src = frag + st * (int64_t)STAGE_BYTES;
+        char *dstb = lds + buf * STAGE_BYTES;
+        for (int c = wave; c < NCH; c += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
+                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
+    };
+    constexpr int AHEAD = 2;
+    const int lag = (wave >= WAVES / 2) ? 1 : 0;
+    if (st0 < st1) issue_stage(st0, 0);
+    if (st0 + 1 < st1) issue_stage(st0 + 1, 1);
+    // (the first two stages are on their way before the statistics are folded and the margins computed: their round trips overlap)
     float b1[TT], b2[TT], b3[TT], mg[TT];                 // best / second / third group maximum, group id in the low bits
     float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;             // destinations of the asm maxima: live across the whole loop
     float gm[TT];                                         // running maximum of the group being streamed
@@ -131,18 +144,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
         }
     }
 
-    auto issue_stage = [&](int64_t st, int buf) {
-        const char *src = frag + st * (int64_t)STAGE_BYTES;
-        char *dstb = lds + buf * STAGE_BYTES;
-        for (int c = wave; c < NCH; c += WAVES)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + c * VQ_CHUNK_BYTES + lane * 16),
-                (__attribute__((address_space(3))) void *)(dstb + c * VQ_CHUNK_BYTES), 16, 0, 0);
-    };
-    constexpr int AHEAD = 2;
-    const int lag = (wave >= WAVES / 2) ? 1 : 0;
-    if (st0 < st1) issue_stage(st0, 0);
-    if (st0 + 1 < st1) issue_stage(st0 + 1, 1);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
 
     f32x16 accA[TT], accB[TT];
