@@ -64,5 +64,5 @@ with torch.no_grad():
     xm = torch.randn(B, C, H, W, device='cuda', generator=g).bfloat16()
     for name, fmt in (('NCHW', torch.contiguous_format), ('channels-last', torch.channels_last)):
         xi = xm.contiguous(memory_format=fmt)
-        t = timeit(lambda: T.quantize(q, xi, {}))
+        t = timeit(lambda: T.quantize(q, xi, {}), warm=100)     # (the host-side pool growth described in timeit lasts a few dozen calls)
         print(f'quantize() {name:14s} B={B} {C}x{H}x{W} K={K}: {t*1e3:.3f} ms  {B*H*W/t/1e6:.1f} Mtok/s')

@@ -524,6 +524,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         rece2 = grp.rece2;
     }
     if (!fused_done) {
+        // (1024-thread workgroups: 256 and 512 measured 1-2 % slower per encode at configs[2] and the tokenizer shape, level at D = 256)
         refine_decide_kernel<<<(int)((N + 1023) / 1024), 1024, 0, s>>>(c, L, N, metric, nslices, rec, xh2, rho2, Np, dec, rece2);
         VQ_CHECK_LAUNCH("refine_decide_kernel");
     }

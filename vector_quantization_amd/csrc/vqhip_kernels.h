@@ -206,6 +206,7 @@ __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
         const uint32_t r2 = __shfl_xor(r, off, 64), h2 = __shfl_xor(h, off, 64), b2 = __shfl_xor(bad, off, 64);
         r = r > r2 ? r : r2; h = h > h2 ? h : h2; bad |= b2;
     }
+    if (v.folded != 0u) return v;   // cosine, already folded into the header by an earlier launch (cb_stats_publish)
     if (v.part2_n != 0u) {      // cosine image made in one launch: per-tile partials instead of the slots (wave-uniform)
         const f32x4 *part = (const f32x4 *)((const char *)st + v.part2_off);
         float pr = 0.0f, ph = 0.0f, pb = 0.0f, pe = 0.0f;
@@ -232,6 +233,26 @@ __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
     }
     v.r2max_bits = r; v.eh2max_bits = h; v.nonfinite |= bad;
     return v;
+}
+
+// Cosine images (cb_cos_body) keep their maxima as per-tile partials; folding them costs every consumer WAVE 4-8 loads and a
+// 64-lane reduction (2-4 us in front of the latency-bound decision and re-rank kernels).  The proposal kernel of an argmin —
+// the first launch behind the image — has ONE wave do it for everybody that comes later: fold, write the header, set `folded`
+// (plain stores: visible to the launches that follow; waves of the same launch still fold for themselves).  Idempotent: a
+// second argmin on the same image writes the same values.
+__device__ __forceinline__ void cb_stats_publish(const VqCbStats *st) {
+    if (blockIdx.x != 0 || (threadIdx.x >> 6) != 0) return;
+    if (st->part2_n == 0u || st->folded != 0u) return;
+    const VqCbStats v = cb_stats_view(st);
+    if ((threadIdx.x & 63) == 0) {
+        VqCbStats *w = const_cast<VqCbStats *>(st);
+        w->r2max_bits = v.r2max_bits; w->eh2max_bits = v.eh2max_bits; w->e2max_bits = v.e2max_bits; w->nonfinite = v.nonfinite;
+        // the four words have reached L2 before the flag is stored (no agent-scope release: its L2 write-back put 3-4 us on this
+        // workgroup, i.e. on the kernel; launches that follow see everything anyway, a concurrent launch on another stream sees
+        // the flag only behind the words)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        w->folded = 1u;
+    }
 }
 
 // ---- the units (one translation unit: vqhip.hip includes this header) ----

@@ -74,6 +74,8 @@ struct VqCbStats {
     int32_t metric;
     uint32_t finalized;     // the image kernel has run (r2max/eh2max/nonfinite are raised by it with filtered atomics)
     uint32_t en_spread_bits;  // L2, constant-norm codebook (below): max_k |e_k|^2 - min_k |e_k|^2, else 0
+    uint32_t folded;          // cosine: the partials below have been folded into r2max / eh2max / e2max / nonfinite of this header by
+                              // the proposal kernel of the first argmin on the image (cb_stats_publish): later launches read the header
     uint32_t part2_n;         // cosine (one-launch preparation, cb_cos_body): the image's per-tile maxima are NOT in the slots
     uint32_t part2_off;       // but in part2_n float4 partials {max residual^2, max image norm^2, bad, max |e_hat|^2} at this byte
                               // offset from the header (no zeroing launch needed in front); 0: the slots (L2 / DOT)

@@ -200,7 +200,7 @@ __device__ __forceinline__ void cb_image_body(int64_t tile, const float *e, int6
         if (tile == 0 && threadIdx.x == 0) {
             st->maxabs_bits = g_st.maxabs_bits; st->e2max_bits = 0u; st->enmax_bits = 0u; st->nonfinite = 0u; st->metric = metric;
             st->finalized = 1u; st->en_spread_bits = 0u; st->l2_const_norm = 0u; st->r2max_bits = 0u; st->eh2max_bits = 0u;
-            st->part2_n = (uint32_t)L.nblk2; st->part2_off = (uint32_t)(L.off_part2 - L.off_stats);
+            st->part2_n = (uint32_t)L.nblk2; st->part2_off = (uint32_t)(L.off_part2 - L.off_stats); st->folded = 0u;
         }
     } else {
         const f32x4 *part = (const f32x4 *)(cb + L.off_part1);
@@ -227,7 +227,7 @@ __device__ __forceinline__ void cb_image_body(int64_t tile, const float *e, int6
             st->nonfinite = g_st.nonfinite; st->metric = metric; st->finalized = 1u;
             st->en_spread_bits = g_st.en_spread_bits; st->l2_const_norm = g_st.l2_const_norm;
             st->r2max_bits = 0u; st->eh2max_bits = 0u;       // (the image's own maxima live in the slots: cb_stats_view)
-            st->part2_n = 0u; st->part2_off = 0u;
+            st->part2_n = 0u; st->part2_off = 0u; st->folded = 0u;
         }
     }
     const float se = cb_scale(&g_st), inv = 1.0f / se;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
         N = nd < N ? nd : N;
         if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
     }
+    cb_stats_publish(cbst);
     const bool wave_active = wave * TT * 2 < tpb;
     const int sl = blockIdx.x % nslices;
     const int64_t tb = blockIdx.x / nslices;

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4)
     // (A stream-K split of the (token block x stage) space into equal shares per CU was built for the D <= 32 kernels and
     //  measured slower, -4.6 % at configs[2], -14 % at small N: profiles/r02_ab_streamk.txt; removed.)
     const bool wave_active = wave * TT < tpb;
+    cb_stats_publish(cbst);
     const int sl = blockIdx.x % nslices;
     const int64_t tb = blockIdx.x / nslices;
     const int64_t st0 = (nstages * sl) / nslices, st1 = (nstages * (sl + 1)) / nslices;
