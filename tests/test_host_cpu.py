@@ -252,3 +252,55 @@ def test_cosine_distance_follows_autocast(monkeypatch):
     assert d.metric == 'Cosine' and Q.CosineDistance(autocast='bf16').metric == 'CosineBF16'
     with pytest.raises(ValueError):
         Q.CosineDistance(autocast='fp16')
+
+
+def test_autocast_auto_keeps_fp32_definition_where_the_bf16_form_does_not_exist(monkeypatch):
+    """'auto' must not turn a config that ran outside autocast into a failure inside it — at a D without the
+    proposal image (D % 8 != 0 or D > 1024) the fused encode keeps the fp32 definition; an explicit 'bf16' still asks for it."""
+    monkeypatch.setattr(torch, 'is_autocast_enabled', lambda *a: True)
+    monkeypatch.setattr(torch, 'get_autocast_dtype', lambda *a: torch.bfloat16)
+    d = Q.CosineDistance()
+    assert d.metric == 'CosineBF16'
+    assert d.metric_for(32) == 'CosineBF16' and d.metric_for(1024) == 'CosineBF16'
+    assert d.metric_for(12) == 'Cosine' and d.metric_for(1032) == 'Cosine'
+    assert Q.CosineDistance(autocast='bf16').metric_for(12) == 'CosineBF16'
+    assert Q.L2Distance().metric_for(12) == 'L2'
+
+
+def test_exchange_route_selection(monkeypatch):
+    """rccl.py: which route the packed all-reduce takes.  No process group: none (callers skip the exchange); an invalid
+    VQHIP_ALLREDUCE is refused; a CPU tensor never takes the library's communicator; VQ_FORCE_EXCHANGE only matters inside a
+    process group."""
+    from vector_quantization_amd import rccl, utils
+    monkeypatch.delenv('VQHIP_ALLREDUCE', raising=False)
+    assert rccl.mode() == 'auto'
+    monkeypatch.setenv('VQHIP_ALLREDUCE', 'sideways')
+    with pytest.raises(ValueError):
+        rccl.mode()
+    monkeypatch.setenv('VQHIP_ALLREDUCE', 'direct')
+    assert rccl.communicator(torch.zeros(4)) is None            # no process group here
+    monkeypatch.setenv('VQ_FORCE_EXCHANGE', '1')
+    assert utils.exchanging() is False and utils.get_world_size() == 1
+    assert rccl.status()['direct'] is False
+
+
+def test_map_route_declines_modules_with_forward_hooks():
+    """the NCHW map entry points are called directly (not through nn.Module.__call__), so a module with a
+    registered forward (pre-)hook must take the token route, where the hook runs."""
+    q = build_quantizer(dict(type='VQGANQuantizer', embedding=dict(type=EMB, num_embeddings=64, embedding_dim=8),
+                             distance=dict(type='L2Distance'), losses=dict(vqgan_loss=dict(type='VQGANLoss'))))
+
+    class FakeMap:                                               # what map_fusable looks at, without a device
+        shape = (2, 8, 4, 4)
+        dtype = torch.float32
+        is_cuda = True
+        def dim(self): return 4
+        def is_contiguous(self): return True
+        def data_ptr(self): return 0
+    assert q.map_fusable(FakeMap()) is True
+    h = q.register_forward_pre_hook(lambda m, a: None)
+    assert q.map_fusable(FakeMap()) is False
+    h.remove()
+    assert q.map_fusable(FakeMap()) is True
+    h = q.register_forward_hook(lambda m, a, o: None)
+    assert q.map_fusable(FakeMap()) is False

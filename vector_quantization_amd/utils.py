@@ -175,6 +175,8 @@ def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
     goes through ``vqhip_allreduce_packed`` — the collective enqueued on the current (compute) stream — anything else, and
     every gloo group, through ``dist.all_reduce`` (rccl.py)."""
     from . import rccl
+    if os.environ.get('VQ_DEBUG_SKIP_ALLREDUCE') == '1' and get_world_size() == 1:      # measurement aid: a one-rank SUM is the identity
+        return t
     comm = rccl.communicator(t)
     if comm is not None:
         exchange_log.collective(rccl.all_reduce, t, comm)
