@@ -65,7 +65,7 @@ const char *vqhip_last_error(void); /* host string describing the last non-zero 
 int64_t vqhip_codebook_bytes(int64_t K, int D);
 /* vqhip_codebook_prepare + (cosine: vqhip_normalize_rows of x) + vqhip_argmin in one call with two launches less on the
  * critical path: the codebook statistics and the whole token side (normalisation included) are independent and run as ONE
- * launch.  This is the training-time shape of vq/algorithms/vq/quantizers.py:92-100, where the codebook changes every
+ * launch (cosine: the whole codebook preparation — statistics AND image — rides in that launch).  This is the training-time shape of vq/algorithms/vq/quantizers.py:92-100, where the codebook changes every
  * step; with a frozen codebook prepare once and call vqhip_argmin.
  *   x [N,D] fp32|bf16: the latents as the quantizer receives them (NOT normalised, also for cosine);
  *   cb: vqhip_codebook_bytes(K,D), written; idx [N] int64; hist [K] int32 or NULL (counts are ADDED);
@@ -353,7 +353,7 @@ int vqhip_profile_enable(int on);
  * key 3 = workgroup cap of the gather kernel (0 = automatic); key 4 = its streaming mode (1 on, 2 off, 0 = automatic:
  * on when the outputs exceed 192 MiB); key 5 = filtered epilogue of the D <= 128 proposal kernels (default 1); key 6 = decision
  * stage inside the proposal kernel (0 never, 1 always, 2 = where one slice covers the codebook: default); key 8 = no aux reads
- * for cosine / dot codebooks at D <= 32 (1); key 9 = group records with replay identification at D <= 32 (1); key 10 = balanced
+ * for cosine / dot codebooks at D <= 32 (1); key 9 = group records at D <= 32, identified by identify32_kernel (32x32x16 form: K <= 131 072, N < 2^30) or by an in-kernel replay (16x16x32 form) (1); key 10 = balanced
  * tiles per workgroup (1); key 11 = the 32x32x16 proposal kernel at D <= 16 (1).  Any other key: VQHIP_EINVAL. */
 int vqhip_set_tuning(int key, int value);
 int vqhip_profile_collect(double *ms_sum, int64_t *launches);

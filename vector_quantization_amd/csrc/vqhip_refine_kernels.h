@@ -90,7 +90,9 @@ __device__ __forceinline__ float row_margin(const VqCbStats *st, int Dp, int met
 }
 
 #define VQ_RESCAN_CAP 32     // candidate slots per rescanned row
+#ifndef VQ_RESCAN_LOCAL
 #define VQ_RESCAN_LOCAL 8    // ... of which one (row block, slice) item of the second pass may contribute
+#endif
 
 // thread per token: merge the slice records under the margin.  Outcomes:
 //   one candidate                         -> idx written here
