@@ -478,6 +478,22 @@ def test_col_argmin_fast_path(ops, metric, dtype):
     assert ref[5] == 7
 
 
+@pytest.mark.parametrize('N,K,D,metric', [(2500, 20000, 32, 'Cosine'), (3000, 18000, 8, 'L2'), (1200, 16500, 16, 'Cosine')])
+def test_col_argmin_small_d_many_codes(ops, N, K, D, metric):
+    """NearestAnchor's role-swapped pass with >= 16 384 codes as its "rows" and D <= 32: the group-record proposal kernel with
+    identify32_kernel behind it (dot-product metric, no aux reads) — against the materialised fp32 matrix's d.argmin(0)."""
+    g = torch.Generator(device='cuda').manual_seed(N + K + D)
+    x = torch.randn(N, D, device='cuda', generator=g)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    w[17] = x[3]; x[N - 1] = x[3]                 # a code on a duplicated latent: the lower token index wins
+    if metric == 'Cosine':
+        x, w = ops.normalize_rows(x), ops.normalize_rows(w)
+    col = ops.col_argmin(x, w, metric)
+    d = ops.distance(x, w, metric).cpu().numpy()
+    np.testing.assert_array_equal(col.cpu().numpy(), d.argmin(0))          # numpy: first occurrence on ties
+    assert int(col[17]) == 3
+
+
 @pytest.mark.parametrize('name,N,K,D,metric,normalize', [
     ('C3 VQ-KD', 512 * 196, 8192, 32, 'Cosine', False),          # configs[2]: K=8192 D=32, 14x14 tokens, batch 512
     ('C5 LlamaGen', 65536, 16384, 8, 'L2', True),                 # configs[4] reference shape: D=8 + NormalizeCallback

@@ -66,25 +66,43 @@ def _bootstrap(device: torch.device) -> int:
         err = str(exc)
     if not _agree(err is None, device):                       # nobody enters ncclCommInitRank unless everybody can
         raise _lib.VqhipError(err or 'vqhip_rccl_load failed on another rank')
+    # From here on every rank reaches BOTH agreement points below whatever fails locally: a rank that raised early would
+    # leave the others waiting inside ncclCommInitRank or the agreement all-reduce.
     store = dist.distributed_c10d._get_default_store()
     _state['generation'] += 1
     key = f'vqhip/rccl_unique_id/{_state["generation"]}'
-    ident = ctypes.create_string_buffer(128)
-    if rank == 0:
-        _lib.check(L.vqhip_rccl_unique_id(ident), 'vqhip_rccl_unique_id')
-        store.set(key, ident.raw.hex())
-    else:
-        ident = ctypes.create_string_buffer(bytes.fromhex(store.get(key).decode()), 128)     # waits until rank 0 has set it
-    comm = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        _lib.check(L.vqhip_rccl_comm_init(ctypes.byref(comm), world, ident, rank), 'vqhip_rccl_comm_init')
-        probe = torch.ones(8, dtype=torch.float32, device=device)
-        stream = torch.cuda.current_stream(device).cuda_stream
-        rc = L.vqhip_allreduce_packed(probe.data_ptr(), probe.numel(), comm, stream)
-        good = rc == 0 and bool((probe == float(world)).all().item())
+    ident, err = ctypes.create_string_buffer(128), None
+    try:
+        if rank == 0:
+            try:
+                _lib.check(L.vqhip_rccl_unique_id(ident), 'vqhip_rccl_unique_id')
+                store.set(key, ident.raw.hex())
+            except Exception:
+                store.set(key, 'failed')                     # the other ranks are waiting for this key
+                raise
+        else:
+            word = store.get(key).decode()                   # waits until rank 0 has set it
+            if word == 'failed':
+                raise _lib.VqhipError('vqhip_rccl_unique_id failed on rank 0')
+            ident = ctypes.create_string_buffer(bytes.fromhex(word), 128)
+    except Exception as exc:                                  # noqa: BLE001
+        err = f'{type(exc).__name__}: {exc}'
+    if not _agree(err is None, device):                       # nobody enters ncclCommInitRank unless everybody has the id
+        raise _lib.VqhipError(err or 'the RCCL unique id did not reach every rank')
+    comm, good = ctypes.c_void_p(), False
+    try:
+        with torch.cuda.device(device):
+            _lib.check(L.vqhip_rccl_comm_init(ctypes.byref(comm), world, ident, rank), 'vqhip_rccl_comm_init')
+            probe = torch.ones(8, dtype=torch.float32, device=device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.vqhip_allreduce_packed(probe.data_ptr(), probe.numel(), comm, stream)
+            good = rc == 0 and bool((probe == float(world)).all().item())
+    except Exception as exc:                                  # noqa: BLE001
+        err = f'{type(exc).__name__}: {exc}'
     if not _agree(good, device):
-        L.vqhip_rccl_comm_destroy(comm)
-        raise _lib.VqhipError(f'probe all-reduce through vqhip_allreduce_packed did not return {world} on every rank')
+        if comm.value:
+            L.vqhip_rccl_comm_destroy(comm)
+        raise _lib.VqhipError(err or f'probe all-reduce through vqhip_allreduce_packed did not return {world} on every rank')
     return comm.value
 
 
