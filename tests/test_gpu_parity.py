@@ -662,6 +662,44 @@ def test_group_request_lists_overflow_to_the_second_pass(ops, N, K, D, metric, h
         assert int(st[0]) + int(st[2]) > N // 2, st
 
 
+@pytest.mark.parametrize('N,K,D,metric,dtype', [
+    (3072, 16384, 256, 'Cosine', torch.float32),      # the CVQ-VAE step's shape
+    (3072, 16384, 256, 'L2', torch.float32),
+    (500, 1000, 24, 'L2', torch.float32),             # D % 32 != 0: a tail block; K % 64 != 0: a ragged code tile
+    (700, 5000, 200, 'Cosine', torch.float32),
+    (900, 8192, 768, 'L2', torch.float32),            # D > 256: the e-tile ring is refilled as it is consumed
+    (640, 4099, 1024, 'L2', torch.bfloat16),          # bf16 rows, the largest D of the few-rows form
+    (17, 777, 8, 'L2', torch.float32),
+])
+def test_last_resort_pass_both_forms(ops, N, K, D, metric, dtype):
+    """The whole-codebook fp32 pass over listed rows has two forms chosen on the device by the length of the list — up to 16
+    rows the VALU form (a lane per code, v_pk_fma_f32 chains), longer lists the MFMA form.  vqhip_set_tuning key 12 sends
+    the first V rows of the batch through it whatever the earlier stages decided: the indices must stay those of the
+    all-fp32 route, for list lengths on both sides of the switch, odd lengths (a half-empty row pair) and a single row."""
+    from vector_quantization_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(N + K + D)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = w[torch.randint(0, K, (N,), device='cuda', generator=g)] + 0.3 * torch.randn(N, D, device='cuda', generator=g)
+    x[1] = w[7]                                        # an exact hit and a duplicated code: ties go to the lowest index
+    w[K - 1] = w[7]
+    if metric == 'Cosine':
+        xq, wq = ops.normalize_rows(x), ops.normalize_rows(w)
+    else:
+        xq, wq = x, w
+    xq = xq.to(dtype)
+    ref = ops.argmin_exact(xq, wq, metric)
+    cb = ops.prepare_codebook(w, metric)
+    try:
+        for V in (1, 2, 5, 12, 15, 16, 17, 40):
+            L.vqhip_set_tuning(12, V)
+            got, st = ops.argmin(xq, cb, return_stats=True)
+            assert int(st[2]) >= min(V, N), (V, st)
+            assert torch.equal(got, ref), (V, int((got != ref).sum()))
+    finally:
+        L.vqhip_set_tuning(12, 0)
+
+
 @pytest.mark.parametrize('kind,metric,scale', [('normal', 'L2', 1.0), ('normal', 'Cosine', 1.0), ('vqgan_init', 'L2', 1.0),
                                                 ('normal', 'L2', 1e-3), ('normal', 'L2', 300.0), ('planted', 'L2', 1.0)])
 def test_margin_holds(ops, kind, metric, scale, D=256):

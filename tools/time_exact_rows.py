@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Duration of the last-resort whole-codebook fp32 pass (exact_kernel, row-list form) as a function of the number of listed
 rows: rows with a non-finite entry have no usable bound and take that path.  usage (under rocprofv3 --kernel-trace --stats):
-time_exact_rows.py [K] [D]"""
+time_exact_rows.py [K] [D]; VQ_ROWS=12 for one list length"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,8 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 g = torch.Generator(device='cuda').manual_seed(1)
 w = torch.randn(K, D, device='cuda', generator=g)
 cb = ops.prepare_codebook(w, 'L2')
-for bad in (0, 1, 8, 32, 64, 256):
+ROWS = [int(v) for v in os.environ.get('VQ_ROWS', '0,1,8,12,16,32,64,128,256,512,1024').split(',')]
+for bad in ROWS:
     x = torch.randn(3072, D, device='cuda', generator=g)
     if bad:
         x[torch.randperm(3072, device='cuda', generator=g)[:bad], 3] = float('inf')

@@ -104,6 +104,7 @@ static std::atomic<int> g_tune_fused_decide{2};
 // whatever the slice count (a launch less on a chain of ~5 us launches: 12 images -2.6 %, 32 images -0.5 %, tools/ab_small_batch.py;
 // at 256 images and more the last-arriving workgroup's merge is the longer tail)
 #define VQ_FUSED_DECIDE_MAX_N 16384
+static std::atomic<int> g_tune_force_exact{0};   // key 12 (verification aid): the first V rows of a batch also take the whole-codebook fp32 pass
 static std::atomic<int> g_tune_w32{1};      // key 11: 0 = D <= 16 keeps the 16x16x32 proposal kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
@@ -346,12 +347,18 @@ static int run_exact_rows(const void *x, int x_dtype, const float *e, const floa
                           int32_t *hist, hipStream_t s) {
     // last-resort path of vqhip_argmin: a few listed rows against the whole codebook (small work items); the workgroup
     // that finishes last turns the keys into indices (ticket: zeroed by x_prep_kernel with the other counters)
-    const int grid = 256;
+    const int64_t ncb = (K + 63) / 64;           // work items of the few-rows form per 16 listed rows
+    const int grid = (int)(ncb < 256 ? 256 : (ncb > 1024 ? 1024 : ncb));
     if (D % 4) return fail(VQHIP_EINVAL, "exact_kernel: D % 4 != 0 (the proposal route has D % 8 == 0)");
-    if (x_dtype == VQHIP_DTYPE_F32)
-        exact_kernel<0><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist);
+    const int few_max = D <= VQ_FEW_MAX_D ? VQ_EXACT_FEW_MAX : 0;
+    const int lds = few_max ? vq_few_lds_bytes(D) : 0;
+    static LdsCache sets[2];
+    const int bf = x_dtype == VQHIP_DTYPE_F32 ? 0 : 1;
+    if (int rc = ensure_dyn_lds(bf ? (const void *)exact_kernel<1> : (const void *)exact_kernel<0>, lds, sets[bf])) return rc;
+    if (!bf)
+        exact_kernel<0><<<grid, 256, lds, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist, few_max);
     else
-        exact_kernel<1><<<grid, 256, 0, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist);
+        exact_kernel<1><<<grid, 256, lds, s>>>(x, e, en, xn, N, K, D, metric, row_list, nrows_dev, keys, ticket, idx, hist, few_max);
     VQ_CHECK_LAUNCH("exact_kernel");
     return VQHIP_OK;
 }
@@ -562,6 +569,10 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         VQ_CHECK_LAUNCH("refine_rerank_kernel");
     }
     // last resort: whole-codebook fp32 pass (non-finite data, overflowing candidate lists)
+    if (const int force = g_tune_force_exact.load()) {
+        force_exact_rows_kernel<<<1, 1024, 0, s>>>((int)(force < N ? force : N), exact_list, counters, keys);
+        VQ_CHECK_LAUNCH("force_exact_rows_kernel");
+    }
     return run_exact_rows(x, x_dtype, e_exact, en, xnorm, N, K, D, metric, exact_list, counters + 2, keys, counters + 3, idx, hist, s);
 }
 
@@ -1226,6 +1237,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 9) g_tune_groups = value != 0;
     else if (key == 10) g_tune_balance = value != 0;
     else if (key == 11) g_tune_w32 = value != 0;
+    else if (key == 12) g_tune_force_exact = value > 0 ? (value < 1024 ? value : 1024) : 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;
 }

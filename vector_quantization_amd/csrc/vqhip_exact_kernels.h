@@ -10,7 +10,7 @@
 // instructions) are skipped.  NaN radicands never compare >= and always go through (NaN sorts first in dist_key).
 __device__ __forceinline__ bool l2_skip(float t, float tb) { return t >= tb; }
 
-// Last-resort path of vqhip_argmin: a few LISTED rows against the whole codebook, row argmin via 64-bit atomicMin keys[row].
+// Last-resort path of vqhip_argmin (MFMA form, long lists): LISTED rows against the whole codebook, row argmin via 64-bit atomicMin keys[row].
 // Work item = (tile of 32 listed rows, chunk of 128 codes: one 32-code tile per wave); persistent grid-stride loop over items.
 // A lane owns one latent row (as B operand: row j, k-parity h) and one code row (A operand) and walks them in batches of 32
 // dims — 8 pieces of 16 bytes each — through a ring of RING batches requested ahead; the chain of D/2 dependent
@@ -18,16 +18,11 @@ __device__ __forceinline__ bool l2_skip(float t, float tb) { return t >= tb; }
 // unrolled all 64 pieces of a 256-dim block (11 600 instructions, 93 KB of code executed once per wave) and a handful of
 // listed rows cost 29-36 us whatever was taken out of the data path — MFMAs, atomics, the ticket, the order of the loads
 // (profiles/r03_exact_rows.txt): the waves were waiting for their own instruction stream.
-// ticket: the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows itself, so the path is ONE launch;
-// with an empty list every workgroup returns at once.
 template <int DT>
-__global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
-                                                    const float *__restrict__ en_in,
-                                                    const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
-                                                    int metric, const int *__restrict__ row_list,
-                                                    const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
-                                                    int *__restrict__ ticket, int64_t *__restrict__ fin_idx,
-                                                    int32_t *__restrict__ fin_hist) {
+__device__ __forceinline__ void exact_rows_mfma(const void *__restrict__ x, const float *__restrict__ e,
+                                                const float *__restrict__ en_in, const float *__restrict__ xn_in, int64_t N,
+                                                int64_t K, int D, int metric, const int *__restrict__ row_list,
+                                                const int *__restrict__ nrows_dev, u64 *__restrict__ keys) {
     constexpr int CHUNK = 4 * 32;               // codes per work item (4 waves)
     constexpr int RING = 4;                     // batches in flight
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,19 +117,283 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
         best = o < best ? o : best;
         if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
     }
-    if (ticket != nullptr && nrows > 0) {
-        // arrival counter (MI355X guide, Guideline 16): the key atomics execute at the memory side; every wave drains
-        // its own, the workgroup meets, one lane publishes; whoever draws the last ticket reads the keys with loads that
-        // bypass its L1 (agent-scope relaxed atomic loads)
+}
+
+// The same last-resort pass on the VALU, for what it is nearly always asked to do: a HANDFUL of listed rows (a CVQ-VAE step
+// sends 4-35 of 3072 rows here) against the whole codebook.  The MFMA form's work item is a chain of D dependent
+// v_mfma_f32_32x32x2_f32 whatever the number of rows — 16 384 cycles at D = 256 before the first key exists, 24-28 us a launch
+// with its load latency — and nearly all of the 32 x 32 outputs of each MFMA belong to rows that are not there.  Here a lane
+// owns ONE code and a wave up to 4 of the listed rows (2 pairs): acc[i] = fmaf(e[k][d], sx * x[row_i][d], acc[i]) for
+// d = 0 .. D-1, the oracle's k-ordered chain by definition (what the MFMA form was verified to equal), 4 independent chains
+// per lane, two per v_pk_fma_f32.
+// Work item = (64 codes, 16 listed rows): the 4 waves of a workgroup share the code tile and split the row pairs evenly.
+// The x tile of the item — 16 rows x D, scaled by sx and widened to fp32, the two rows of a pair interleaved value by value —
+// is staged once (D <= VQ_FEW_MAX_D) and read back as broadcasts (every lane the same address).  The e tile, 64 codes x 128 B
+// per block of 32 dims, arrives by LDS-DMA in whole 128-byte lines through a ring of VQ_FEW_RING blocks, all but one of them
+// requested ahead (at D = 256 the whole 64 KB tile is in flight before the first fma: with one block ahead the pass waited
+// out a memory latency per block, 13 us per item): DMA j (2 per wave), lane i -> code 8 (i >> 3) + j, 16-byte piece
+// (i & 7) ^ j.  Lane l reads piece p of its code l = 8 a + b at slot 64 b + 8 a + (p ^ b): within each of ds_read_b128's four
+// 16-lane groups the 16 slots are distinct mod 16 (conflict-free).  One barrier per block.  Then the epilogue of the MFMA form
+// per (code, row), the wave's smallest key and ONE atomicMin per (wave, row).
+// Where a launch's time goes (tools/micro/exact_rows.hip, 12 rows, K = 16384, D = 256, us after the first workgroup starts,
+// median over workgroups; profiles/r04_exact_rows_stamps.txt): x tile staged 2.3 (row ids -> x rows: two dependent memory
+// latencies; the e tile lands meanwhile), blocks done 8.3 (one wave per SIMD: 1600 cycles per block for 40 LDS reads and 64
+// v_pk_fma_f32), keys sent 10.0, atomics drained 11.1, last workgroup done 11.6 — 17.7 us by HIP events against 29.1 for the
+// MFMA form.  Tried and not kept: the whole tile resident and no barrier between blocks, reads of the next half block ahead
+// of the fmas (slower as compiled: 6.6 us of blocks for 2 pairs per wave; faster, 2.9 against 3.4, for 1).
+typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
+
+// one block of NP pieces (4 dims each) for the M row pairs of a wave: v_pk_fma_f32 — the two halves are the two rows of a pair
+// (each half a correctly rounded fma like v_fma_f32), the code's value feeds both.  NP == 8 (a whole block): every LDS read of
+// the block is issued before the first fma (one wave per SIMD: nobody else hides a read's latency; read-then-use piece by
+// piece took 2000 cycles per block, 6.6 us of a 9 us item).  NP < 8: the tail block of a D that is not a multiple of 32.
+template <int M, int NP>
+__device__ __forceinline__ void exact_few_block(const float4 *__restrict__ et, const float4 *__restrict__ xt, int npcp, int eslot,
+                                                int sw, int np, vq_f32x2 (&acc)[2]) {
+    if constexpr (NP == 8) {
+        float4 ev[8], xa[M][8], xb[M][8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            ev[p] = et[eslot + (p ^ sw)];
+#pragma unroll
+            for (int i = 0; i < M; ++i) { xa[i][p] = xt[(i * npcp + p) * 2]; xb[i][p] = xt[(i * npcp + p) * 2 + 1]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev[p].x, ev[p].x}, vq_f32x2{xa[i][p].x, xa[i][p].y}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev[p].y, ev[p].y}, vq_f32x2{xa[i][p].z, xa[i][p].w}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev[p].z, ev[p].z}, vq_f32x2{xb[i][p].x, xb[i][p].y}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev[p].w, ev[p].w}, vq_f32x2{xb[i][p].z, xb[i][p].w}, acc[i]);
+            }
+        }
+    } else {
+        for (int p = 0; p < np; ++p) {
+            const float4 ev = et[eslot + (p ^ sw)];
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const float4 xa = xt[(i * npcp + p) * 2], xb = xt[(i * npcp + p) * 2 + 1];   // (row0, row1) of dims 0,1 | 2,3
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev.x, ev.x}, vq_f32x2{xa.x, xa.y}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev.y, ev.y}, vq_f32x2{xa.z, xa.w}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev.z, ev.z}, vq_f32x2{xb.x, xb.y}, acc[i]);
+                acc[i] = __builtin_elementwise_fma(vq_f32x2{ev.w, ev.w}, vq_f32x2{xb.z, xb.w}, acc[i]);
+            }
+        }
+    }
+}
+
+#ifdef VQ_EXACT_STAMPS      // tools/micro/exact_rows.hip: where a workgroup's time goes (100 MHz counter, wave 0)
+__device__ unsigned long long vq_exact_stamps[1024 * 8];
+__device__ unsigned long long vq_exact_cycles[1024 * 8];
+#define VQ_STAMP(i) do { if (threadIdx.x == 0) { vq_exact_stamps[(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); vq_exact_cycles[(blockIdx.x & 1023) * 8 + (i)] = clock64(); } } while (0)
+#else
+#define VQ_STAMP(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ void wait_vm_pairs(int n) {       // s_waitcnt vmcnt(2 n), n = 0 .. 6 (the count is an immediate)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+
+#define VQ_FEW_RING 8                 // e tiles (blocks of 32 dims) in LDS: VQ_FEW_RING - 1 requested ahead
+#define VQ_FEW_MAX_D 1024             // the x tile of an item is 16 x D floats of LDS
+static inline int vq_few_lds_bytes(int D) { return VQ_FEW_RING * 8192 + 16 * ((D + 31) / 32 * 32) * 4; }
+
+// Smallest dist_key of the wave when lane l holds the key of code k0 + l (so that among equal distances the lowest lane is
+// the lowest code): the minimum of the high words — xor-1, xor-2, half-mirror and mirror DPP steps make each row of 16 lanes
+// uniform, four v_readlane and scalar minima finish it — and the first lane that holds it.  Wave-uniform result.  (As a 64-bit
+// __shfl_xor butterfly — two LDS-crossbar round trips per step and half — the four reductions of a wave took 2.8 us.)
+__device__ __forceinline__ u64 wave_min_key(u64 key, int64_t k0) {
+    const uint32_t hi = (uint32_t)(key >> 32);
+    uint32_t h = hi;
+#define VQ_DPP_MIN(ctrl) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)h, (int)h, ctrl, 0xf, 0xf, false); h = o < h ? o : h; }
+    VQ_DPP_MIN(0xB1) VQ_DPP_MIN(0x4E) VQ_DPP_MIN(0x141) VQ_DPP_MIN(0x140)
+#undef VQ_DPP_MIN
+    uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)h, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)h, 16 * r); m = o < m ? o : m; }
+    const u64 holders = __ballot(hi == m);
+    return ((u64)m << 32) | (u64)(uint32_t)(k0 + (__ffsll((unsigned long long)holders) - 1));
+}
+
+template <int DT>
+__device__ __forceinline__ void exact_rows_few(const void *__restrict__ x, const float *__restrict__ e,
+                                               const float *__restrict__ en_in, const float *__restrict__ xn_in, int64_t K,
+                                               int D, int metric, const int *__restrict__ row_list, int64_t nrows,
+                                               u64 *__restrict__ keys) {
+    constexpr int RT = 16;                       // listed rows per work item: 8 pairs, up to 2 pairs per wave
+    extern __shared__ __attribute__((aligned(16))) char few_lds[];
+    float4 *ering = (float4 *)few_lds;                               // [VQ_FEW_RING][512]
+    float *xtile = (float *)(few_lds + VQ_FEW_RING * 8192);          // [pair][piece of the row][dim of the piece][row of the pair]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nrt = (nrows + RT - 1) / RT, ncb = (K + 63) / 64;
+    const float sx = (VQ_IS_L2(metric)) ? -2.0f : 1.0f;
+    const int nb = (D + 31) / 32, npc = D >> 2, npcp = nb * 8;      // pieces of a row: valid, padded
+    const int eslot = 64 * (lane & 7) + 8 * (lane >> 3);          // + (p ^ (lane & 7))
+
+    for (int64_t item = blockIdx.x; item < ncb * nrt; item += gridDim.x) {
+        const int64_t rt = item / ncb, k0 = (item % ncb) * 64;
+        const int nr = (int)((nrows - rt * RT) < RT ? (nrows - rt * RT) : RT);
+        const int npair = (nr + 1) >> 1;
+        const int pg = (npair + 3) >> 2;                           // pairs per wave (even split): 1 or 2
+        const int p_lo = wave * pg;
+        const int myn = npair - p_lo < pg ? (npair - p_lo > 0 ? npair - p_lo : 0) : pg;
+
+        auto issue_e = [&](int b) {
+            const int np = (D - 32 * b) >= 32 ? 8 : (D - 32 * b) >> 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * wave + u;
+                int64_t c = k0 + 8 * (lane >> 3) + j;
+                int p = (lane & 7) ^ j;
+                c = c < K ? c : K - 1;                             // clamped: what lands there is never used
+                p = p < np ? p : 0;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(e + c * D + 32 * b + 4 * p),
+                                                 (__attribute__((address_space(3))) void *)(&ering[(b % VQ_FEW_RING) * 512 + 64 * j]), 16, 0, 0);
+            }
+        };
+        // The item's latency chain is kept to: row ids -> x rows -> fma.  Row ids first (one load, lane r holds row r);
+        // then everything that depends on them or on nothing — |e|^2 of the lane's code and |x|^2 of the wave's rows for the
+        // epilogue, the x tile — and behind those requests the e tiles of the first VQ_FEW_RING - 1 blocks; the x tile is
+        // written (scaled, widened) while the e tiles are on their way.  Wave w stages rows w, w + 4, w + 8, w + 12, a lane
+        // pieces lane, lane + 64, ... (4 x 4 requests cover D <= VQ_FEW_MAX_D).
+        VQ_STAMP(0);
+        const int rid_v = row_list[rt * RT + ((lane & 15) < nr ? (lane & 15) : 0)];
+        const int64_t k = k0 + lane;
+        const float enk = (VQ_IS_L2(metric) && k < K) ? en_in[k] : 0.0f;
+        // (the ids move to scalar registers in one go: a v_readlane next to each request made hipcc wait for all earlier
+        // requests before each of them)
+        int64_t rx[4], re[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rx[u] = (int64_t)__builtin_amdgcn_readlane(rid_v, (wave + 4 * u) & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) re[i] = (int64_t)__builtin_amdgcn_readlane(rid_v, ((p_lo + (i >> 1)) * 2 + (i & 1)) & 15);
+        float xnv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xnv[i] = VQ_IS_L2(metric) ? xn_in[re[i]] : 0.0f;
+        float4 xv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t == 0 || 64 * t < npc) {                          // wave-uniform; inside, every request at a clamped address
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pc = lane + 64 * t;
+                    const int64_t off = rx[u] * D + 4 * (pc < npc ? pc : 0);
+                    if (DT == 0) xv[t][u] = *(const float4 *)((const float *)x + off);
+                    else {
+                        const uint2 w2 = *(const uint2 *)((const uint16_t *)x + off);
+                        xv[t][u] = float4{__uint_as_float(w2.x << 16), __uint_as_float(w2.x & 0xFFFF0000u),
+                                          __uint_as_float(w2.y << 16), __uint_as_float(w2.y & 0xFFFF0000u)};
+                    }
+                }
+            }
+        }
+        if (nb >= VQ_FEW_RING - 1) {
+#pragma unroll
+            for (int b = 0; b < VQ_FEW_RING - 1; ++b) issue_e(b);
+        } else {
+            for (int b = 0; b < nb; ++b) issue_e(b);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = wave + 4 * u, pc = lane + 64 * t;
+                if (r < 2 * npair && pc < npc) {                   // (the missing row of an odd last pair: zeros)
+                    float *xs = xtile + ((r >> 1) * npcp + pc) * 8 + (r & 1);
+                    xs[0] = r < nr ? sx * xv[t][u].x : 0.0f; xs[2] = r < nr ? sx * xv[t][u].y : 0.0f;
+                    xs[4] = r < nr ? sx * xv[t][u].z : 0.0f; xs[6] = r < nr ? sx * xv[t][u].w : 0.0f;
+                }
+            }
+        }
+
+        VQ_STAMP(1);
+        vq_f32x2 acc[2] = {vq_f32x2{0.0f, 0.0f}, vq_f32x2{0.0f, 0.0f}};
+        for (int b = 0; b < nb; ++b) {
+            // block b landed once the DMAs of the blocks requested after it (b + 1 .. b + RING - 2) are all that is pending
+            const int after = nb - 1 - b < VQ_FEW_RING - 2 ? nb - 1 - b : VQ_FEW_RING - 2;
+            wait_vm_pairs(after);
+            __syncthreads();                                       // ... for every wave's part; everybody is done with block b - 1
+            if (b == 0) VQ_STAMP(2);
+            if (b + VQ_FEW_RING - 1 < nb) issue_e(b + VQ_FEW_RING - 1);   // into the buffer of block b - 1
+            const int np = (D - 32 * b) >= 32 ? 8 : (D - 32 * b) >> 2;
+            const float4 *et = ering + (b % VQ_FEW_RING) * 512, *xt = (const float4 *)xtile + (p_lo * npcp + b * 8) * 2;
+            if (np == 8) {
+                if (myn == 2) exact_few_block<2, 8>(et, xt, npcp, eslot, lane & 7, 8, acc);
+                else if (myn == 1) exact_few_block<1, 8>(et, xt, npcp, eslot, lane & 7, 8, acc);
+            } else {
+                if (myn == 2) exact_few_block<2, 7>(et, xt, npcp, eslot, lane & 7, np, acc);
+                else if (myn == 1) exact_few_block<1, 7>(et, xt, npcp, eslot, lane & 7, np, acc);
+            }
+        }
+        VQ_STAMP(3);
+        __syncthreads();                                           // the next item refills the ring and the x tile
+
+        // keys of the wave's (up to) 4 rows and their wave-wide minima.  A run-time loop on purpose: this code runs once per
+        // item, straight from a cold instruction cache — unrolled four times it was 2.4 us of a 13 us launch.
+#pragma unroll 1
+        for (int i = 0; i < 2 * myn; ++i) {
+            const int lr = (p_lo + (i >> 1)) * 2 + (i & 1);
+            if (lr >= nr) break;                                   // (the missing row of an odd last pair)
+            const int64_t row = (i & 2) ? ((i & 1) ? re[3] : re[2]) : ((i & 1) ? re[1] : re[0]);
+            const vq_f32x2 ap = (i & 2) ? acc[1] : acc[0];
+            const float a = (i & 1) ? ap[1] : ap[0];
+            float d;
+            if (VQ_IS_L2(metric)) {
+                const float xn = (i & 2) ? ((i & 1) ? xnv[3] : xnv[2]) : ((i & 1) ? xnv[1] : xnv[0]);   // (xn_in: always given here)
+                float t = VQ_SWAPPED(metric) ? (a + enk) + xn : (a + xn) + enk;
+                t = (t < 0.0f) ? 0.0f : t;
+                d = sqrtf(t);
+            } else {
+                d = cos_distance(a, metric);
+            }
+            const u64 m = wave_min_key(k < K ? dist_key(d, (uint32_t)k) : ~0ull, k0);
+            if (lane == 0) atomicMin(&keys[row], m);
+        }
+    }
+}
+
+// One launch for both forms, chosen on the device by the length of the list (the host does not know it): up to
+// few_max (VQ_EXACT_FEW_MAX; 0 when D > VQ_FEW_MAX_D) listed rows take the VALU form, longer lists the MFMA form (twice the fma
+// rate once its 32-row tiles are full).  ticket: the workgroup that finishes last decodes keys -> idx (+hist) for the listed rows itself, so the path is ONE
+// launch; with an empty list every workgroup returns at once.
+#ifndef VQ_EXACT_FEW_MAX
+#define VQ_EXACT_FEW_MAX 16
+#endif
+template <int DT>
+__global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                    const float *__restrict__ en_in,
+                                                    const float *__restrict__ xn_in, int64_t N, int64_t K, int D,
+                                                    int metric, const int *__restrict__ row_list,
+                                                    const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
+                                                    int *__restrict__ ticket, int64_t *__restrict__ fin_idx,
+                                                    int32_t *__restrict__ fin_hist, int few_max) {
+    const int64_t nrows = (int64_t)(*nrows_dev);
+    if (nrows <= 0) return;
+    if (nrows <= few_max) exact_rows_few<DT>(x, e, en_in, xn_in, K, D, metric, row_list, nrows, keys);
+    else exact_rows_mfma<DT>(x, e, en_in, xn_in, N, K, D, metric, row_list, nrows_dev, keys);
+    {
+        // arrival counter (MI355X guide, Guideline 16, form R1): the only payload is the keys, written by agent-scope atomics —
+        // performed at the memory side, past the XCD's L2 — so there is nothing for a release fence to write back (it cost
+        // 1.5 us here): every wave drains its own atomics, the workgroup meets, one lane draws the ticket; whoever draws the
+        // last one reads the keys with loads that bypass its L1 and L2 (agent-scope relaxed atomic loads)
         __shared__ int is_last;
+        VQ_STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-        }
+        VQ_STAMP(5);
+        if (threadIdx.x == 0) is_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
         __syncthreads();
+        VQ_STAMP(6);
         if (is_last) {
             for (int64_t i = threadIdx.x; i < nrows; i += blockDim.x) {
                 const int64_t r = (int64_t)row_list[i];
@@ -144,6 +403,17 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                 if (fin_hist) atomicAdd(&fin_hist[kk], 1);
             }
         }
+        VQ_STAMP(7);
+    }
+}
+
+// vqhip_set_tuning key 12 (verification aid): rows 0 .. V-1 of the batch join the list of the last-resort pass whatever the
+// earlier stages decided for them (a row already listed is left alone); the pass then overwrites their indices.
+__global__ void force_exact_rows_kernel(int V, int *__restrict__ exact_list, int *__restrict__ counters, u64 *__restrict__ keys) {
+    const int n = threadIdx.x;
+    if (n < V && keys[n] != ~0ull) {
+        exact_list[atomicAdd(&counters[2], 1)] = n;
+        keys[n] = ~0ull;
     }
 }
 
