@@ -211,6 +211,46 @@ def test_connector_quantize_path_matches_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,D,H,W,K,dtype', [(256, 256, 16, 16, 16384, torch.bfloat16),     # the bench's map: channels shared by 2 workgroups
+                                             (3, 256, 16, 16, 4096, torch.float32),       # few tiles: channels shared by 8
+                                             (2, 32, 32, 32, 1000, torch.float32),        # 4 tiles per image, one chunk
+                                             (5, 96, 16, 16, 777, torch.bfloat16),        # 3 chunks: no sharing possible
+                                             (1, 768, 32, 16, 512, torch.float32),
+                                             (2, 64, 16, 16, 300, None)])                 # decode: no latents, no loss
+def test_gather_ste_map_whole_image_tiles(B, D, H, W, K, dtype):
+    """vqhip_gather_ste_map takes tiles of 256 consecutive positions of one image when the images hold a multiple of 256
+    positions (gather_ste_map256_kernel: 1 KiB channel rows per wave-store); vqhip_set_tuning key 13 = 0 keeps the 64-token
+    tiles.  Both must write the map of the token-major gather ('(b h w) c -> b c h w', models/base.py:126-127) bit for bit
+    and the same loss to double-sum rounding."""
+    from vector_quantization_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(B + D + H * W + K)
+    N = B * H * W
+    e = torch.randn(K, D, device='cuda', generator=g)
+    idx = torch.randint(0, K, (N,), device='cuda', generator=g)
+    x = None if dtype is None else torch.randn(N, D, device='cuda', generator=g).to(dtype)
+    try:
+        L.vqhip_set_tuning(13, 1)
+        new_map, new_mse = ops.gather_ste_map(x, e, idx, B, H, W, beta=0.25)
+        L.vqhip_set_tuning(13, 0)
+        old_map, old_mse = ops.gather_ste_map(x, e, idx, B, H, W, beta=0.25)
+    finally:
+        L.vqhip_set_tuning(13, 1)
+    assert torch.equal(new_map, old_map)
+    if x is None:
+        ref = e[idx]
+    else:
+        xf = x.float()
+        ref = xf + (e[idx] - xf)
+    ref_map = ref.reshape(B, H * W, D).permute(0, 2, 1).reshape(B, D, H, W)
+    assert torch.equal(new_map, ref_map)
+    if x is not None:
+        want = ((e[idx].double() - x.double()) ** 2).mean().item()
+        assert abs(new_mse[0].item() - want) <= 1e-6 * want and abs(old_mse[0].item() - want) <= 1e-6 * want
+        assert abs(new_mse[2].item() - (want + 0.25 * want)) <= 2e-6 * want
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,D,H,W,K,dist,dtype', [(4, 256, 16, 16, 4096, 'L2', torch.bfloat16), (3, 32, 14, 14, 1000, 'Cosine', torch.float32),
                                                   (2, 8, 16, 16, 2048, 'L2', torch.float32), (5, 64, 7, 9, 777, 'L2', torch.float32),
                                                   (2, 768, 14, 14, 512, 'Cosine', torch.bfloat16)])

@@ -66,3 +66,16 @@ with torch.no_grad():
         xi = xm.contiguous(memory_format=fmt)
         t = timeit(lambda: T.quantize(q, xi, {}), warm=100)     # (the host-side pool growth described in timeit lasts a few dozen calls)
         print(f'quantize() {name:14s} B={B} {C}x{H}x{W} K={K}: {t*1e3:.3f} ms  {B*H*W/t/1e6:.1f} Mtok/s')
+# the same in train mode with the backward from a given upstream gradient of the map (what the decoder would hand back)
+q.train()
+gmap = torch.randn(B, C, H, W, device='cuda', generator=g) / (B * C * H * W)
+for name, fmt in (('NCHW', torch.contiguous_format), ('channels-last', torch.channels_last)):
+    xi = xm.contiguous(memory_format=fmt).requires_grad_(True)
+    gi = gmap.contiguous(memory_format=fmt)
+    def fb():
+        xi.grad = None
+        q.embedding.weight.grad = None
+        z, loss, _ = T.quantize(q, xi, {})
+        torch.autograd.backward([z, loss], [gi, None])
+    t = timeit(fb, warm=100)
+    print(f'quantize() fwd+bwd {name:14s} B={B} {C}x{H}x{W} K={K}: {t*1e3:.3f} ms  {B*H*W/t/1e6:.1f} Mtok/s')

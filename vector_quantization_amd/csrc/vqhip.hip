@@ -104,6 +104,7 @@ static std::atomic<int> g_tune_fused_decide{2};
 // whatever the slice count (a launch less on a chain of ~5 us launches: 12 images -2.6 %, 32 images -0.5 %, tools/ab_small_batch.py;
 // at 256 images and more the last-arriving workgroup's merge is the longer tail)
 #define VQ_FUSED_DECIDE_MAX_N 16384
+static std::atomic<int> g_tune_map256{1};   // key 13: 0 = maps of 256-position images keep the 64-token tiles of gather_ste_map_kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_force_exact{0};   // key 12 (verification aid): the first V rows of a batch also take the whole-codebook fp32 pass
 static std::atomic<int> g_tune_w32{1};      // key 11: 0 = D <= 16 keeps the 16x16x32 proposal kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update inside the stream of the D <= 32 kernels (A/B; results unchanged)
@@ -880,6 +881,23 @@ int vqhip_gather_ste_map(const void *x_rows, int x_dtype, const float *e, const 
         return fail(VQHIP_EINVAL, "vqhip_gather_ste_map: bad argument");
     hipStream_t s = (hipStream_t)stream;
     double *sse = x_rows ? (double *)scratch16 : nullptr;
+    if (x_rows && x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_gather_ste_map: x_dtype");
+    if (HW % 256 == 0 && D % 32 == 0 && g_tune_map256.load()) {
+        // images of a multiple of 256 positions: whole 1 KiB channel rows per wave-store (gather_ste_map256_kernel)
+        const int64_t nt = N / 256;
+        int csplit = 1;                                     // share the channels while that still leaves whole chunks and the grid is short
+        while (nt * csplit < 512 && (D / 32) % (csplit * 2) == 0) csplit *= 2;
+        const int64_t items = nt * csplit;
+        const int grid256 = (int)(items < 1024 ? items : 1024);
+        constexpr int LDS = 2 * 32 * 256 * 4;
+        static LdsCache sets[2];
+        const int bf = (x_rows && x_dtype == VQHIP_DTYPE_BF16) ? 1 : 0;
+        if (int rc = ensure_dyn_lds(bf ? (const void *)gather_ste_map256_kernel<1> : (const void *)gather_ste_map256_kernel<0>, LDS, sets[bf])) return rc;
+        if (!bf) gather_ste_map256_kernel<0><<<grid256, 512, LDS, s>>>(x_rows, e, idx, N, D, HW, csplit, out_map, sse, mse, beta);
+        else gather_ste_map256_kernel<1><<<grid256, 512, LDS, s>>>(x_rows, e, idx, N, D, HW, csplit, out_map, sse, mse, beta);
+        VQ_CHECK_LAUNCH("gather_ste_map256_kernel");
+        return VQHIP_OK;
+    }
     int64_t ntiles = (N + 63) / 64;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     if (!x_rows || x_dtype == VQHIP_DTYPE_F32) gather_ste_map_kernel<0><<<grid, 256, 0, s>>>(x_rows, e, idx, N, D, HW, out_map, sse, mse, beta);
@@ -1237,6 +1255,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 9) g_tune_groups = value != 0;
     else if (key == 10) g_tune_balance = value != 0;
     else if (key == 11) g_tune_w32 = value != 0;
+    else if (key == 13) g_tune_map256 = value != 0;
     else if (key == 12) g_tune_force_exact = value > 0 ? (value < 1024 ? value : 1024) : 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

@@ -243,6 +243,112 @@ __global__ __launch_bounds__(256) void gather_ste_map_kernel(const void *__restr
     }
 }
 
+// gather_ste_map for maps whose images hold a multiple of 256 positions (16 x 16, 32 x 32, ...) and D % 32 == 0: a tile is
+// 256 CONSECUTIVE positions of one image, so a chunk of 32 channels of it is ONE contiguous 32 KiB block of the output map
+// (channel rows of 1 KiB, next to each other) — every wave-store is 1 KiB of one channel row, and DRAM sees the block being
+// completed within the chunk's lifetime instead of 256-byte segments of 1024 tiles open across the whole launch.  Work item
+// = (tile, share of the channels): 512 threads, 32 channels x 256 tokens per chunk through LDS, two chunk buffers (one
+// barrier per chunk), the next chunk's codebook rows and latents requested before the current one is turned.
+//   in:   thread -> (token tl = q >> 3, 16-byte piece cp = q & 7) for q = tid, tid + 512, ... : 8 lanes read the 128 bytes of
+//         a token's codebook row (and 64 or 128 of its latent row) that belong to the chunk;
+//   LDS:  tile[ch][256] with the token index XOR-ed by ((ch >> 2) & 7) << 2: the 4 values a thread writes and the
+//         float4 a lane reads back are conflict-free (ds_write_b32 groups of 32 lanes, ds_read_b128 groups of 16);
+//   out:  wave w, row r = w, w + 8, ...: lane l stores the float4 of tokens 4 l .. 4 l + 3.
+template <int DT>
+__global__ __launch_bounds__(512) void gather_ste_map256_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                                const int64_t *__restrict__ idx, int64_t N, int D, int64_t hw,
+                                                                int csplit, float *__restrict__ out_map, double *sse,
+                                                                float *mse, float beta) {
+    extern __shared__ __attribute__((aligned(16))) char map_lds[];
+    float *tile = (float *)map_lds;                               // [2][32][256]
+    __shared__ double red[8];
+    __shared__ int64_t code_s[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ntiles = N / 256;
+    const int nchunk = D / 32 / csplit;                          // chunks per work item
+    double s = 0.0;
+    for (int64_t item = blockIdx.x; item < ntiles * csplit; item += gridDim.x) {
+        const int64_t tb = item / csplit;
+        const int cbase = (int)(item % csplit) * nchunk * 32;
+        const int64_t n0 = tb * 256;
+        const int64_t obase = (n0 / hw) * (int64_t)D * hw + (n0 % hw);         // + channel * hw + token of the tile
+        __syncthreads();
+        if (threadIdx.x < 256) code_s[threadIdx.x] = idx[n0 + threadIdx.x];
+        __syncthreads();
+        float4 zc[4], zn[4];
+        typename std::conditional<DT == 0, float4, uint2>::type xc[4], xnx[4];
+        auto load_chunk = [&](int c0, float4 (&zr)[4], decltype(xc) &xr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = threadIdx.x + 512 * i, tl = q >> 3, cp = q & 7;
+                zr[i] = *(const float4 *)(e + code_s[tl] * D + c0 + 4 * cp);
+                if (x != nullptr) {
+                    if constexpr (DT == 0) xr[i] = *(const float4 *)((const float *)x + (n0 + tl) * D + c0 + 4 * cp);
+                    else xr[i] = *(const uint2 *)((const uint16_t *)x + (n0 + tl) * D + c0 + 4 * cp);
+                }
+            }
+        };
+        load_chunk(cbase, zc, xc);
+        for (int c = 0; c < nchunk; ++c) {
+            const int c0 = cbase + 32 * c;
+            float *tb_lds = tile + (c & 1) * (32 * 256);
+            if (c + 1 < nchunk) load_chunk(c0 + 32, zn, xnx);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = threadIdx.x + 512 * i, tl = q >> 3, cp = q & 7;
+                const float4 zv = zc[i];
+                float o[4];
+                if (x != nullptr) {
+                    float xv[4];
+                    if constexpr (DT == 0) { xv[0] = xc[i].x; xv[1] = xc[i].y; xv[2] = xc[i].z; xv[3] = xc[i].w; }
+                    else {
+                        xv[0] = __uint_as_float(xc[i].x << 16); xv[1] = __uint_as_float(xc[i].x & 0xFFFF0000u);
+                        xv[2] = __uint_as_float(xc[i].y << 16); xv[3] = __uint_as_float(xc[i].y & 0xFFFF0000u);
+                    }
+                    const float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
+                    s += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                    o[0] = xv[0] + d0; o[1] = xv[1] + d1; o[2] = xv[2] + d2; o[3] = xv[3] + d3;
+                } else {
+                    o[0] = zv.x; o[1] = zv.y; o[2] = zv.z; o[3] = zv.w;
+                }
+                const int col = tl ^ (cp << 2);                   // (ch >> 2) & 7 == cp for ch = 4 cp + j
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tb_lds[(4 * cp + j) * 256 + col] = o[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave + 8 * i;
+                const float4 v = *(const float4 *)(tb_lds + r * 256 + 4 * (lane ^ ((r >> 2) & 7)));
+                *(float4 *)(out_map + obase + (int64_t)(c0 + r) * hw + 4 * lane) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { zc[i] = zn[i]; xc[i] = xnx[i]; }
+        }
+    }
+    if (sse) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            int *ticket = (int *)(sse + 1);
+            const double before = atomicAdd(sse, t);          // (returning atomic: complete before the ticket is taken)
+            asm volatile("" :: "v"(before) : "memory");
+            if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+                const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float mean = (float)(total / ((double)N * (double)D));
+                mse[0] = mean; mse[1] = mean;
+                const float weighted = beta * mean;
+                mse[2] = mean + weighted; mse[3] = 0.0f;
+                __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 __global__ void hist_kernel(const int64_t *idx, int64_t N, int64_t K, int32_t *hist) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t k = idx[i];
