@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised campaign on the GPU: vqhip_argmin (fp16 proposals + exact re-rank) against vqhip_argmin_exact (all-fp32
 MFMA, itself bit-equal to the CPU oracle in tests/) at sizes the CPU oracle cannot reach.  Any mismatch is a bug.
-usage: fuzz_vs_exact.py [seconds] [seed]"""
+usage: fuzz_vs_exact.py [seconds] [seed]   (VQ_FUZZ_DIMS=8,16: only those D; VQ_FUZZ_FORCE_EXACT=1: see below)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -41,6 +41,9 @@ while time.time() < t_end:
         w = torch.nn.functional.normalize(w)
         if ri(0, 2): x = torch.nn.functional.normalize(x)
     x, w = x * scale, w * scale
+    if 'VQ_FUZZ_FORCE_EXACT' in os.environ:        # send the first V rows of every batch through the last-resort fp32 pass as well
+        from vector_quantization_amd import _lib       # (tuning key 12: both forms of that pass, list lengths around the switch at 16)
+        _lib.lib().vqhip_set_tuning(12, [0, 1, 2, 3, 7, 12, 15, 16, 17, 33, 100][ri(0, 11)])
     if os.environ.get('VQ_FUZZ_VERBOSE'): print(f'trial {trials + 1}: N={N} K={K} D={D} {metric} kind={kind} scale={scale}', flush=True)
     xd = x.bfloat16() if ri(0, 3) == 0 else x
     if metric != 'L2':

@@ -581,9 +581,11 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
 // token side (they are independent), then the image kernel.  `rows` are the N rows to quantize (normalised into `xq`
 // first when xnorm), `codes` the Kc rows the image is made from, `ws` the workspace of argmin_pipeline(N rows, Kc codes).
 // hw > 0: `rows` is the feature map [N / hw, D, hw] (NCHW); the token-major rows go to `xrows` (input dtype; cosine: xq)
+// grows != nullptr (vqhip_col_argmin_rows, fp32 `rows` = the codebook, no normalisation): row t of the call is rows[grows[t]] for
+// t < *gcount and zeros up to N; the gathered rows are written to `xrows`
 static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const float *codes, int64_t Kc, int D, int cb_metric,
                               void *cb, void *ws, bool xnorm, float *xq, hipStream_t s, int32_t *hist_zero = nullptr,
-                              int64_t hw = 0, void *xrows = nullptr) {
+                              int64_t hw = 0, void *xrows = nullptr, const int32_t *grows = nullptr, const int32_t *gcount = nullptr) {
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
@@ -595,6 +597,10 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     char *ximg = w + W.off_ximg;
 #define VQ_PRE(DT, XN, MAP, COSI) pre_kernel<DT, XN, MAP, COSI><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
 #define VQ_PRE2(DT, XN, MAP) do { if (cosimg) VQ_PRE(DT, XN, MAP, true); else VQ_PRE(DT, XN, MAP, false); } while (0)
+    if (grows != nullptr) {
+        if (rows_dtype != VQHIP_DTYPE_F32 || xnorm || hw > 0 || cosimg || L.nstep == 2) return fail(VQHIP_EINVAL, "encode_fused_front: gather form");
+        pre_kernel<0, false, false, false, true><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows, grows, gcount);
+    } else
     if (hw > 0) {
         if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE2(0, true, true); else VQ_PRE2(0, false, true); }
         else { if (xnorm) VQ_PRE2(1, true, true); else VQ_PRE2(1, false, true); }
@@ -815,8 +821,13 @@ int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int3
     const int64_t c = (cap * (int64_t)D * 4 + 1023) / 1024 * 1024;
     char *pipe_ws = w, *img = w + a;
     float *esub = (float *)(w + a + b);
-    gather_listed_rows_kernel<<<waves_grid(cap, 4), 256, 0, s>>>(e, rows, count, cap, D, esub);
-    VQ_CHECK_LAUNCH("gather_listed_rows_kernel");
+    // the gather of the listed rows rides in the front launch of the pipeline (token side of pre_kernel) except at a padded
+    // dimension of 32, whose token side is the wave-level form
+    const bool fused_gather = vq_cb_layout(N, D).nstep != 2;
+    if (!fused_gather) {
+        gather_listed_rows_kernel<<<waves_grid(cap, 4), 256, 0, s>>>(e, rows, count, cap, D, esub);
+        VQ_CHECK_LAUNCH("gather_listed_rows_kernel");
+    }
     const float *codes = (const float *)x;
     if (x_dtype == VQHIP_DTYPE_BF16) {
         float *copy = (float *)(w + a + b + c);
@@ -828,7 +839,8 @@ int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int3
     }
     // the role-swapped pipeline of vqhip_col_argmin on the listed codes: sized for `cap` rows, live for *count of them
     const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : (VQ_METRIC_DOT | (metric & VQ_METRIC_BF16));
-    int rc = encode_fused_front(esub, VQHIP_DTYPE_F32, cap, codes, N, D, m, img, pipe_ws, false, nullptr, s);
+    int rc = fused_gather ? encode_fused_front(e, VQHIP_DTYPE_F32, cap, codes, N, D, m, img, pipe_ws, false, nullptr, s, nullptr, 0, esub, rows, count)
+                          : encode_fused_front(esub, VQHIP_DTYPE_F32, cap, codes, N, D, m, img, pipe_ws, false, nullptr, s);
     if (rc) return rc;
     return argmin_pipeline(esub, VQHIP_DTYPE_F32, codes, img, cap, N, D, m, col_idx, nullptr, pipe_ws, stream, /*x_prepared=*/true, count);
 }

@@ -403,14 +403,20 @@ __device__ __forceinline__ void x_prep_small(int64_t blk, const void *__restrict
 // with the tokens along the lanes (coalesced 64/128-byte segments per channel), turned through LDS, and from there on the
 // kernel is the token-major one; the rows it has in registers anyway are also written out token-major (`xrows`, in the
 // input's dtype; cosine: additionally the normalised fp32 rows `xq`) for the exact re-rank, the gather and the backward.
-template <int DT, bool XNORM = false, bool NCHW = false>
+// GATHER (vqhip_col_argmin_rows: the rows are the LISTED codes of the codebook `x`): row t is x[grows[t]] for t < *gcount and
+// zeros up to N (the launch is sized for a capacity, the count stays on the device); the gathered fp32 rows are written to
+// `xrows` for the exact re-rank — the separate gather launch in front of the role-swapped pipeline is gone.
+template <int DT, bool XNORM = false, bool NCHW = false, bool GATHER = false>
 __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict__ x, int64_t N, int D, int nstep,
                                             char *__restrict__ ximg, float *__restrict__ xh2,
                                             float *__restrict__ rho2, float *__restrict__ xn,
                                             int *__restrict__ counters, int *__restrict__ arrive, int narrive,
                                             float *__restrict__ xq, float eps, int xround = 0,
                                             int32_t *__restrict__ hist_zero = nullptr, int64_t hist_len = 0,
-                                            int64_t nblocks = 1, int64_t hw = 0, void *__restrict__ xrows = nullptr) {
+                                            int64_t nblocks = 1, int64_t hw = 0, void *__restrict__ xrows = nullptr,
+                                            const int32_t *__restrict__ grows = nullptr,
+                                            const int32_t *__restrict__ gcount = nullptr) {
+    static_assert(!GATHER || (DT == 0 && !XNORM && !NCHW), "GATHER: fp32 codebook rows, as given");
     __shared__ float red[2][8][32];
     // vqhip_encode(VQHIP_ENCODE_ZERO_HIST): the code-hit histogram the later kernels of this call add into starts from zero
     if (hist_zero != nullptr)
@@ -422,7 +428,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
     // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
     if (arrive != nullptr)                                      // every block zeroes its stride of the counter range
         for (int64_t i = blk * 256 + threadIdx.x; i < narrive; i += nblocks * 256) arrive[i] = 0;
-    if constexpr (!NCHW) {
+    if constexpr (!NCHW && !GATHER) {
         if (nstep == 2) {                                       // padded dimension 32: the wave-level form (no LDS, no barrier)
             x_prep_small<DT, XNORM>(blk, x, N, D, ximg, xh2, rho2, xn, xq, eps, xround);
             return;
@@ -432,6 +438,8 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
     const int64_t t = blk * 32 + r;
     const bool tvalid = t < N;
     const int64_t trow = tvalid ? t : (N - 1);
+    const bool live = !GATHER || trow < (int64_t)gcount[0];
+    const int64_t srow = GATHER ? (live ? (int64_t)grows[trow] : 0) : trow;      // the row the values come from
     const int ns32 = nstep >> 1;
     // NCHW: element (token trow, dim d) lives at map_base + d * hw
     const int64_t map_base = NCHW ? ((trow / hw) * (int64_t)D * hw + (trow % hw)) : 0;
@@ -481,7 +489,13 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = tile[(8 * piece + j) & 63][r];
         } else {
-            load8<DT>(x, trow * D + 32 * (piece >> 2) + 8 * (piece & 3), v);
+            load8<DT>(x, srow * D + 32 * (piece >> 2) + 8 * (piece & 3), v);
+            if constexpr (GATHER) {
+                if (!live) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+                }
+            }
         }
     };
     const int npieces = ns32 * 4, niter = (npieces + 7) / 8;
@@ -564,7 +578,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
                 }
             }
             if (!have) fetch(piece, v);
-            if constexpr (NCHW) {                  // the token-major rows as given, in the input's own dtype (exact: a copy)
+            if constexpr (NCHW || GATHER) {        // the token-major rows as given, in the input's own dtype (exact: a copy)
                 if (DT == 0) {
                     float *o = (float *)xrows + trow * D + d0;
                     *(f32x4 *)o = f32x4{v[0], v[1], v[2], v[3]};
@@ -633,14 +647,16 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
 // the image kernel that follows needs the former, the proposal kernel both)
 // COSIMG: `nblk_stats` blocks of cb_cos_body (one per image tile: the whole cosine preparation) instead of statistics blocks —
 // no image launch follows.
-template <int DT, bool XNORM, bool NCHW = false, bool COSIMG = false>
+template <int DT, bool XNORM, bool NCHW = false, bool COSIMG = false, bool GATHER = false>
 __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int metric, char *cb, VqCbLayout L, int nblk_stats,
                                                   const void *__restrict__ x, int64_t N, int D, int nstep,
                                                   char *__restrict__ ximg, float *__restrict__ xh2,
                                                   float *__restrict__ rho2, float *__restrict__ xn,
                                                   int *__restrict__ counters, int *__restrict__ arrive, int narrive,
                                                   float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero,
-                                                  int64_t hw = 0, void *__restrict__ xrows = nullptr) {
+                                                  int64_t hw = 0, void *__restrict__ xrows = nullptr,
+                                                  const int32_t *__restrict__ grows = nullptr,
+                                                  const int32_t *__restrict__ gcount = nullptr) {
     // the smaller of the two groups of workgroups goes FIRST in the grid: dispatched behind the larger one it starts when that
     // one drains and its own latency (a chain of round trips either way) is added to the kernel — at 3072 tokens against 1024
     // statistics workgroups the token side started ~8 us into a 16 us kernel
@@ -652,6 +668,6 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
         if constexpr (COSIMG) cb_cos_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
         else cb_stats_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
     }
-    else x_prep_body<DT, XNORM, NCHW>((int64_t)(x_first ? b : b - nblk_stats), x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, eps,
-                                      VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows);
+    else x_prep_body<DT, XNORM, NCHW, GATHER>((int64_t)(x_first ? b : b - nblk_stats), x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive,
+                                              xq, eps, VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows, grows, gcount);
 }
