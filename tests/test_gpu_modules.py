@@ -382,6 +382,27 @@ def test_cvq_sparse_anchor_exchange_same_result(dist):
     assert 0 < int(count) < K
 
 
+@pytest.mark.parametrize('scale', [1.0, 3.0, 40.0, 1e4])
+def test_column_pass_under_cosine_with_rows_that_are_not_unit_norm(scale):
+    """NearestAnchor's role-swapped pass runs on the operands as given (include/vqhip.h: "COS: x and e already normalised") and
+    builds its fp16 image in one launch with the scale of unit rows (2^13).  Rows that break the contract must still give
+    the fp32 definition 1 - x.e bit for bit: moderately large values keep rigorous margins (the tile maxima come from the data),
+    values beyond fp16 range at that scale raise the non-finite flag and every row takes the fp32 pass."""
+    from vector_quantization_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(int(scale) + 11)
+    N, K, D = 1500, 1024, 64
+    x = torch.randn(N, D, device='cuda', generator=g) * scale
+    w = torch.randn(K, D, device='cuda', generator=g)
+    d = ops.distance(x, w, 'Cosine')
+    rows_n = torch.arange(N, device='cuda')[:, None].expand(N, K)
+    want = torch.where(d == d.min(0, keepdim=True).values, rows_n, N).min(0).values
+    assert torch.equal(ops.col_argmin(x, w, 'Cosine'), want)
+    rows = torch.arange(0, K, 3, device='cuda', dtype=torch.int32)
+    count = torch.tensor([rows.numel()], device='cuda', dtype=torch.int32)
+    sub = ops.col_argmin_rows(x, w, rows, count, rows.numel() + 5, 'Cosine')
+    assert torch.equal(sub[:rows.numel()], want[rows.long()])
+
+
 def test_sparse_anchor_pieces_match_the_dense_ops():
     """vqhip_col_argmin_rows == vqhip_col_argmin on the listed codes (every metric, bf16 latents, a capacity above the
     count), the packed count header survives a float SUM exactly, and vqhip_cvq_apply == vqhip_cvq_step."""

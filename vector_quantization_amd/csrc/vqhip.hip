@@ -589,7 +589,12 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     VqCbLayout L = vq_cb_layout(Kc, D);
     VqWsLayout W = vq_ws_layout(N, Kc, D);
     char *w = (char *)ws, *c = (char *)cb;
-    const bool cosimg = VQ_IS_COS(cb_metric);            // cosine: the whole codebook preparation rides in the same launch
+    // cosine: the whole codebook preparation rides in the same launch (normalised rows need no statistics pass for their
+    // scale).  DOT — the role-swapped NearestAnchor pass under the cosine metric, whose operands the caller has normalised
+    // (include/vqhip.h: "COS: x and e already normalised") — takes the same form on the rows as given: constant scale 2^13,
+    // the tile maxima from the actual data (rows that are not unit-norm keep exact results: values beyond fp16 range at that
+    // scale raise the non-finite flag and the rows take the fp32 pass)
+    const bool cosimg = VQ_IS_COS(cb_metric) || (cb_metric & 3) == VQ_METRIC_DOT;
     const int nblk_stats = cosimg ? (int)(L.nstages * L.tps) : (int)((Kc + 15) / 16);
     const int xgrid = (int)((N + 31) / 32), narrive = (int)W.narrive;
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
@@ -598,8 +603,9 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
 #define VQ_PRE(DT, XN, MAP, COSI) pre_kernel<DT, XN, MAP, COSI><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
 #define VQ_PRE2(DT, XN, MAP) do { if (cosimg) VQ_PRE(DT, XN, MAP, true); else VQ_PRE(DT, XN, MAP, false); } while (0)
     if (grows != nullptr) {
-        if (rows_dtype != VQHIP_DTYPE_F32 || xnorm || hw > 0 || cosimg || L.nstep == 2) return fail(VQHIP_EINVAL, "encode_fused_front: gather form");
-        pre_kernel<0, false, false, false, true><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows, grows, gcount);
+        if (rows_dtype != VQHIP_DTYPE_F32 || xnorm || hw > 0 || L.nstep == 2) return fail(VQHIP_EINVAL, "encode_fused_front: gather form");
+        if (cosimg) pre_kernel<0, false, false, true, true><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows, grows, gcount);
+        else pre_kernel<0, false, false, false, true><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows, grows, gcount);
     } else
     if (hw > 0) {
         if (rows_dtype == VQHIP_DTYPE_F32) { if (xnorm) VQ_PRE2(0, true, true); else VQ_PRE2(0, false, true); }

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void cb_image_kernel(const float *e, int64_t K
     cb_image_body<false>(blockIdx.x, e, K, D, metric, cb, L);
 }
 
-// Cosine codebooks in ONE launch (one 256-thread block per tile of 32 codes): the tile's rows are normalised first — cb_rows4's
+// Cosine (and DOT: unit rows as given, nothing normalised or copied) codebooks in ONE launch (one 256-thread block per tile of
+// 32 codes): the tile's rows are normalised first — cb_rows4's
 // arithmetic, a wave per 8 rows — into e_exact, then the block turns them into its piece of the fragment-major image.
 // Possible because a normalised codebook needs no statistics pass for its scale (|e_hat| <= 1: the power-of-two scale is
 // 2^13 whatever the data; fp16's relative precision does not depend on it), and because the tile's maxima go into a per-tile
