@@ -65,37 +65,51 @@ __device__ __forceinline__ float block_max4(float v, float *red) {    // max ove
 // Four codebook rows k0 .. k0 + 3 by one wave: |e_k|^2 in oracle order, optional normalisation into e_exact (cosine), max |e|,
 // flags — folded into the caller's running maxima (amax per lane; m_e2 / m_en wave-uniform; bad per lane).
 // The four rows are loaded together and reduced with interleaved shuffle trees.
-__device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, int D, int metric, float *en, float *ex,
-                                         float &amax, float &m_e2, float &m_en, bool &bad) {
+// NI = 4 (D <= 256): the wave's four rows live in registers (lane l holds dims l, l + 64, l + 128, l + 192 of each): all 16
+// loads are in flight together and the cosine form normalises from the registers instead of reading the rows again (19.7 -> us
+// at K = 16 384, D = 256, cosine).  NI = 0 (larger D): the same 16 requests at a time over chunks of 256 dims, rows read a second
+// time for the normalisation — element by element, these loops made cb_cos_kernel 54 us at D = 768 for the 63 MB it moves;
+// holding the rows of D <= 1024 in registers instead cost the D <= 256 kernels that share the launch 1-2 us in occupancy.
+// Same per-lane chains in the same order: same |e_k|^2 to the bit.
+template <int NI>
+__device__ __forceinline__ void cb_rows4_impl(int64_t k0, const float *e, int64_t K, int D, int metric, float *en, float *ex,
+                                              float &amax, float &m_e2, float &m_en, bool &bad) {
     const int lane = threadIdx.x & 63;
     float p[4] = {0, 0, 0, 0};
-    // D <= 256: the wave's four rows live in registers (lane l holds dims l, l + 64, l + 128, l + 192 of each): all 16 loads
-    // are in flight together and the cosine form below normalises from the registers instead of reading the rows again
-    // (19.7 -> us at K = 16 384, D = 256, cosine).  Same per-lane chains in the same order: same |e_k|^2 to the bit.
-    const bool inreg = D <= 256;
-    float av[4][4];
-    if (inreg) {
+    constexpr bool inreg = NI > 0;
+    float av[4][inreg ? NI : 1];
+    if constexpr (inreg) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int d = lane + 64 * i;
                 av[c][i] = (d < D && k0 + c < K) ? e[(k0 + c) * D + d] : 0.0f;
             }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float a = av[c][i];
-                p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);
+                p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);     // (a = 0 past D: p + 0 = p exactly)
             }
     } else
-    for (int d = lane; d < D; d += 64) {
+    for (int d0 = lane; d0 < D; d0 += 256) {                    // 16 requests in flight (4 per row), consumed in the order of d
+        float t[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float a = (k0 + c < K) ? e[(k0 + c) * D + d] : 0.0f;
-            p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int d = d0 + 64 * i;
+                t[c][i] = (d < D && k0 + c < K) ? e[(k0 + c) * D + d] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a = t[c][i];
+                p[c] = fmaf(a, a, p[c]); amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a);     // (a = 0 past D: p + 0 = p exactly)
+            }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
@@ -109,9 +123,9 @@ __device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, 
             float nrm = sqrtf(p[c]);
             float den = (nrm < 1e-12f) ? 1e-12f : nrm;
             float q2 = 0.0f;
-            if (inreg) {
+            if constexpr (inreg) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int d = lane + 64 * i;
                     if (d < D) {
                         float a = av[c][i] / den;
@@ -121,11 +135,20 @@ __device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, 
                     }
                 }
             } else
-            for (int d = lane; d < D; d += 64) {
-                float a = e[(k0 + c) * D + d] / den;
-                if (VQ_IS_BF16(metric)) a = bf16_rne(a);            // bf16-autocast: the einsum sees bf16(normalize(e))
-                ex[(k0 + c) * D + d] = a;
-                amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+            for (int d0 = lane; d0 < D; d0 += 256) {            // the row again (L2), four requests in flight
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = (d0 + 64 * i < D) ? e[(k0 + c) * D + d0 + 64 * i] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = d0 + 64 * i;
+                    if (d < D) {
+                        float a = t[i] / den;
+                        if (VQ_IS_BF16(metric)) a = bf16_rne(a);    // bf16-autocast: the einsum sees bf16(normalize(e))
+                        ex[(k0 + c) * D + d] = a;
+                        amax = fmaxf(amax, fabsf(a)); bad |= !isfinite(a); q2 = fmaf(a, a, q2);
+                    }
+                }
             }
             q2 = wave_sum_tree(q2);
             bad |= !isfinite(q2);
@@ -142,6 +165,11 @@ __device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, 
             if (VQ_IS_L2(metric)) m_en = fmaxf(m_en, -p[c]);
         }
     }
+}
+__device__ __forceinline__ void cb_rows4(int64_t k0, const float *e, int64_t K, int D, int metric, float *en, float *ex,
+                                         float &amax, float &m_e2, float &m_en, bool &bad) {
+    if (D <= 256) cb_rows4_impl<4>(k0, e, K, D, metric, en, ex, amax, m_e2, m_en, bad);
+    else cb_rows4_impl<0>(k0, e, K, D, metric, en, ex, amax, m_e2, m_en, bad);
 }
 
 // pass 1 (one wave per 4 codes): |e_k|^2 in oracle order, optional normalisation into e_exact, max|e|, flags.
@@ -236,29 +264,70 @@ __device__ __forceinline__ void cb_image_body(int64_t tile, const float *e, int6
     float r2 = 0.0f, h2 = 0.0f;
     // pieces of 8 dims: k-step of 32 dims s32 = piece/4, quarter q4 = piece%4; the tile's two 16-code halves go
     // to chunks (s32, 0) and (s32, 1); within a chunk lane = q4*16 + (code & 15)
-    for (int piece = g; piece < L.nstep * 2; piece += 8) {
-        const int s = piece >> 2, q4 = piece & 3;
-        const int d0 = 32 * s + 8 * q4;
-        half8 o;
-        if (k < K && d0 < D) {
-            float v[8];
-            if (d0 + 8 <= D && (D % 4) == 0) { load8<0>(src, k * D + d0, v); }
-            else {
+    // (four pieces of a thread are requested before the first is converted: one piece at a time, the 12 pieces a thread has at
+    //  D = 768 were 12 memory latencies in a row)
+    const int npieces = L.nstep * 2;
+    if (npieces <= 32) {                                       // D <= 256: at most 4 pieces per thread, one at a time (measured:
+        for (int piece = g; piece < npieces; piece += 8) {     // requesting them together is 2 % slower per encode there)
+            const int s = piece >> 2, q4 = piece & 3;
+            const int d0 = 32 * s + 8 * q4;
+            half8 o;
+            if (k < K && d0 < D) {
+                float v[8];
+                if (d0 + 8 <= D && (D % 4) == 0) { load8<0>(src, k * D + d0, v); }
+                else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+                    for (int j = 0; j < 8; ++j) v[j] = (d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 q = to_f16_ftz(v[j] * se);
+                    float back = (float)q * inv, res = v[j] - back;
+                    r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+                    o[j] = q;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 q = to_f16_ftz(v[j] * se);
-                float back = (float)q * inv, res = v[j] - back;
-                r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
-                o[j] = q;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+            *(half8 *)(stage_base + (int64_t)(ti * L.nstep + 2 * s + (r >> 4)) * VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = o;
         }
-        *(half8 *)(stage_base + (int64_t)(ti * L.nstep + 2 * s + (r >> 4)) * VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = o;
+    } else
+    for (int p0 = g; p0 < npieces; p0 += 32) {
+        float vv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int piece = p0 + 8 * u;
+            const int d0 = 32 * (piece >> 2) + 8 * (piece & 3);
+            if (piece < npieces && k < K && d0 < D) {
+                if (d0 + 8 <= D && (D % 4) == 0) { load8<0>(src, k * D + d0, vv[u]); }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[u][j] = (d0 + j < D) ? src[k * D + d0 + j] : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int piece = p0 + 8 * u;
+            if (piece >= npieces) break;
+            const int s = piece >> 2, q4 = piece & 3;
+            const int d0 = 32 * s + 8 * q4;
+            half8 o;
+            if (k < K && d0 < D) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 q = to_f16_ftz(vv[u][j] * se);
+                    float back = (float)q * inv, res = vv[u][j] - back;
+                    r2 = fmaf(res, res, r2); h2 = fmaf(back, back, h2);
+                    o[j] = q;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+            }
+            *(half8 *)(stage_base + (int64_t)(ti * L.nstep + 2 * s + (r >> 4)) * VQ_CHUNK_BYTES + (q4 * 16 + (r & 15)) * 16) = o;
+        }
     }
     // aux chunk slice of this tile: -se*|e_k|^2/2 for its 32 codes (padded codes: a large FINITE negative score;
     // -inf with the register index or-ed into its mantissa would be a signalling NaN and poison v_max_f32)
