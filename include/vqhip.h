@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VQHIP_VERSION 400   /* round 4: + the packed all-reduce itself (RCCL on the caller's stream) */
+#define VQHIP_VERSION 500   /* round 5: + one host call per training forward (vqhip_cvq_forward, vqhip_vqkd_forward) */
 
 #define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
 #define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
@@ -69,7 +69,8 @@ int64_t vqhip_codebook_bytes(int64_t K, int D);
  * step; with a frozen codebook prepare once and call vqhip_argmin.
  *   x [N,D] fp32|bf16: the latents as the quantizer receives them (NOT normalised, also for cosine);
  *   cb: vqhip_codebook_bytes(K,D), written; idx [N] int64; hist [K] int32 or NULL (counts are ADDED);
- *   xq [N,D] fp32: cosine only — receives F.normalize(x, dim=1) (bit-identical to vqhip_normalize_rows), which is also the
+ *   xq [N,D] fp32: cosine only — receives F.normalize(x, dim=1) (bit-identical to vqhip_normalize_rows; under
+ *   VQHIP_METRIC_COS_BF16 each element additionally rounded to the nearest bf16: the operand of THAT metric), which is also the
  *   operand of the exact re-rank: keep it alive until the call has completed on the stream; NULL for L2;
  *   ws: vqhip_workspace_bytes(N,K,D).  Results are those of the separate calls, bit for bit. */
 int vqhip_encode(const void *x, int x_dtype, const float *e, int64_t N, int64_t K, int D, int metric, void *cb, int64_t cb_bytes,
@@ -273,6 +274,97 @@ int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtyp
 int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
                     const void *x, int x_dtype, const int64_t *col_idx, const float *packed, int world, const int32_t *slot,
                     int64_t K, int D, float ema_decay, float eps, void *stream);
+/* ---- ONE host call per training forward (round 5) -------------------------------------------------------------------------
+ * The reference's training step runs the quantizer's forward as ~20 ATen calls; the entry points above
+ * replace them one for one, which leaves an eager nn.Module step with ~10 host calls — at the reference's per-rank batches
+ * (3 072-12 544 tokens) the HOST is then the bound.  The two entry points below enqueue a whole training forward from one
+ * call: encode -> the codebook update of the callback, exchange included -> decode / straight-through / loss.  Every launch
+ * is one the separate entry points would have made, in the same order on the same stream: the results are those of the
+ * chain, bit for bit.  The argument block is a plain struct of pointers and sizes (struct_bytes = sizeof, checked).
+ *
+ * `phases`: VQHIP_STEP_ALL — everything, with the all-reduce issued by the library on `comm` (a vqhip_rccl_comm_init
+ *   communicator) when `exchange` != 0; comm may be NULL only for world == 1 (a one-rank SUM is the identity).
+ *   VQHIP_STEP_BEFORE_EXCHANGE / VQHIP_STEP_AFTER_EXCHANGE — the two halves around a collective the CALLER issues on
+ *   packed[0 .. exchange_floats) (torch.distributed.all_reduce: the default route of the Python callbacks); the same struct,
+ *   untouched, goes into both calls.
+ * `exchange` == 0: one rank, no packed buffer (counts from the epilogue histogram).
+ *
+ * vqhip_cvq_forward — VQGANQuantizer + CVQVAECallback(NearestAnchor) in train mode (vq/algorithms/vq/quantizers.py:92-117,
+ *   vq/algorithms/cvqvae/quantizer_callback.py:75-105, anchors.py:41-85; sparse anchors as vqhip_cvq_rows describes):
+ *   vqhip_encode_ex(x, w_in; ZERO_HIST) -> [vqhip_cvq_rows(p_in) unless list_ready] -> vqhip_col_argmin_rows(cap) ->
+ *   [vqhip_cvq_pack -> all-reduce] -> vqhip_cvq_apply(w_in, p_in -> w_out, p_out) -> [prefetch: vqhip_cvq_rows(p_out) into
+ *   rows/slot/count for the NEXT step, count copied to the pinned HOST word count_host, count_event recorded] ->
+ *   vqhip_gather_ste_mse(x, w_out, idx).
+ *   cap >= 0: the capacity the listed-code launches are sized for (>= the count; K under HIP-graph capture).
+ *   cap <  0: the call reads it from *count_host after hipEventSynchronize(count_event) — the copy the PREVIOUS call's
+ *   prefetch queued a whole step earlier; the wait sits behind the enqueue of the encode, so the GPU has work while the host
+ *   looks.  This is the ONE place a compute entry point of this library may block the host, and only on the caller's event.
+ *   rows / slot / count: K, K, 1 int32, caller-owned and persistent across steps.  cap_used / exchange_floats: written by the
+ *   BEFORE phase (host fields).  ws: vqhip_cvq_forward_ws_bytes(N, K, D, cap_max) with cap_max >= cap; packed: at least
+ *   vqhip_pack_floats(K, cap, D) floats (exchange != 0).  xq: cosine only (as vqhip_encode).  z_ste / mse nullable together
+ *   (no decode tail).  w_out / p_out may alias w_in / p_in.
+ *
+ * vqhip_vqkd_forward — VQKDQuantizer + VQKDCallback in train mode (vq/algorithms/vq/callbacks/normalize.py:22-29,
+ *   vq/algorithms/vqkd/quantizers/callbacks.py:44-75,114-129, vq/algorithms/vq/losses.py:53-62 with mse norm=True):
+ *   w_mid = normalize(normalize(w_in)), xn = normalize(x), payload zeroed (ONE launch) -> vqhip_encode_ex(xn, w_mid, cosine)
+ *   -> histogram header + centroid sums of normalize(xn) scattered straight into the packed buffer (ONE launch; `ordered`
+ *   != 0: vqhip_token_order + vqhip_segsum_rows instead, bit-reproducible) -> [all-reduce] -> the EMA update read straight
+ *   from the packed buffer (w_mid -> w_out) -> tail (tail != 0): z_ste = xn + (w_out[idx] - xn), mse[0] = mse[1] =
+ *   mean((normalize(w_out[idx]) - normalize(xn))^2), mse[2] = mse[3] = 0.  xq: the encode's by-product (as vqhip_encode).
+ *   packed: vqhip_pack_floats(K, K, D) floats, always used.
+ *   metric: VQHIP_METRIC_COS or VQHIP_METRIC_COS_BF16.  ws: vqhip_vqkd_forward_ws_bytes(N, K, D).
+ * vqhip_vqkd_backward — gradient of that tail with respect to x: grad_x = normalize_bwd(x; g_zste + normalize_bwd(xn;
+ *   g_loss * 2/(N D) * (normalize(xn) - normalize(w[idx])))); g_zste [N, D] / g_loss (DEVICE scalar) nullable. */
+#define VQHIP_STEP_BEFORE_EXCHANGE 1
+#define VQHIP_STEP_AFTER_EXCHANGE 2
+#define VQHIP_STEP_ALL 3
+typedef struct vqhip_cvq_forward_t {
+    int64_t struct_bytes;
+    int64_t N, K;
+    int32_t D, x_dtype, metric, world;
+    float ema_decay, eps, beta;
+    int32_t phases, exchange, list_ready, prefetch, reserved0;
+    int64_t cap;
+    const void *x;
+    const float *w_in, *p_in;
+    float *w_out, *p_out;
+    int32_t *rows, *slot, *count;
+    int32_t *count_host;            /* pinned HOST word (nullable) */
+    void *count_event;              /* hipEvent_t of the caller (nullable) */
+    void *comm;
+    void *cb; int64_t cb_bytes;
+    int64_t *idx; int32_t *hist; float *xq;
+    float *packed; int64_t packed_floats;
+    float *z_ste, *mse; void *scratch16;
+    void *ws; int64_t ws_bytes;
+    int64_t cap_used, exchange_floats;      /* OUT (host), written by the BEFORE phase */
+} vqhip_cvq_forward_t;
+int64_t vqhip_cvq_forward_ws_bytes(int64_t N, int64_t K, int D, int64_t cap_max);
+int vqhip_cvq_forward(vqhip_cvq_forward_t *args, void *stream);
+
+typedef struct vqhip_vqkd_forward_t {
+    int64_t struct_bytes;
+    int64_t N, K;
+    int32_t D, x_dtype, metric, world;
+    float ema_decay;
+    int32_t phases, exchange, ordered, tail, reserved0;
+    const void *x;
+    const float *w_in;
+    float *w_mid, *w_out;           /* w_out may alias w_mid */
+    float *xn, *xq;                 /* [N, D] fp32 each */
+    void *comm;
+    void *cb; int64_t cb_bytes;
+    int64_t *idx; int32_t *hist;
+    float *packed; int64_t packed_floats;
+    float *z_ste, *mse; void *scratch16;
+    void *ws; int64_t ws_bytes;
+    int64_t exchange_floats;        /* OUT (host), written by the BEFORE phase */
+} vqhip_vqkd_forward_t;
+int64_t vqhip_vqkd_forward_ws_bytes(int64_t N, int64_t K, int D);
+int vqhip_vqkd_forward(vqhip_vqkd_forward_t *args, void *stream);
+int vqhip_vqkd_backward(const void *x, int x_dtype, const float *xn, const float *w, const int64_t *idx, int64_t N, int D,
+                        const float *g_zste, const float *g_loss, float *grad_x, void *stream);
+
 /* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
 int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
                       void *stream);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.vqhip_version() == _lib.ABI_VERSION == 400
+    assert lib.vqhip_version() == _lib.ABI_VERSION == 500
     cb = lib.vqhip_codebook_bytes(16384, 256)
     # fp16 fragment image (K*D*2) + fp32 normalised copy (K*D*4) + norms + aux chunks
     assert cb >= 16384 * 256 * 6 and cb < 16384 * 256 * 7
@@ -90,3 +90,41 @@ def test_ops_refuse_cpu_tensors():
     from vector_quantization_amd import ops
     with pytest.raises(_lib.VqhipError):
         ops.prepare_codebook(torch.zeros(8, 8), 'L2')
+
+
+def test_one_call_forwards_validate_their_argument_blocks(lib):
+    """vqhip_cvq_forward / vqhip_vqkd_forward take a struct of pointers and sizes: a block of another size, a missing
+    pointer, an undersized workspace or exchange buffer are VQHIP_EINVAL before any launch."""
+    import ctypes
+    N, K, D = 1000, 512, 64
+    a = _lib.CvqForwardArgs()
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'struct_bytes' in lib.vqhip_last_error()
+    a.struct_bytes = ctypes.sizeof(_lib.CvqForwardArgs)
+    a.N, a.K, a.D, a.phases, a.world = N, K, D, _lib.STEP_ALL, 1
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'null pointer' in lib.vqhip_last_error()
+    for f in ('x', 'w_in', 'p_in', 'w_out', 'p_out', 'rows', 'slot', 'count', 'cb', 'idx', 'hist', 'ws'):
+        setattr(a, f, 0x1000)
+    need = lib.vqhip_cvq_forward_ws_bytes(N, K, D, K)
+    assert need > lib.vqhip_workspace_bytes(N, K, D) + lib.vqhip_col_rows_workspace_bytes(N, K, D)
+    a.ws_bytes = lib.vqhip_workspace_bytes(N, K, D) - 1
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'ws too small' in lib.vqhip_last_error()
+    a.ws_bytes, a.exchange, a.world = need, 1, 2
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'packed' in lib.vqhip_last_error()
+    a.packed = 0x1000
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'communicator' in lib.vqhip_last_error()
+    a.D = 12
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22
+    b = _lib.VqkdForwardArgs()
+    assert lib.vqhip_vqkd_forward(ctypes.byref(b), None) == -22 and b'struct_bytes' in lib.vqhip_last_error()
+    b.struct_bytes = ctypes.sizeof(_lib.VqkdForwardArgs)
+    b.N, b.K, b.D, b.phases, b.world, b.metric = N, K, D, _lib.STEP_ALL, 1, 0
+    assert lib.vqhip_vqkd_forward(ctypes.byref(b), None) == -22 and b'cosine' in lib.vqhip_last_error()
+    b.metric = 1
+    for f in ('x', 'w_in', 'w_mid', 'w_out', 'xn', 'xq', 'cb', 'idx', 'hist', 'packed', 'ws'):
+        setattr(b, f, 0x1000)
+    b.packed_floats = lib.vqhip_pack_floats(K, K, D) - 1
+    assert lib.vqhip_vqkd_forward(ctypes.byref(b), None) == -22 and b'packed' in lib.vqhip_last_error()
+    b.packed_floats += 1
+    b.ws_bytes = lib.vqhip_vqkd_forward_ws_bytes(N, K, D) - 1
+    assert lib.vqhip_vqkd_forward(ctypes.byref(b), None) == -22 and b'ws too small' in lib.vqhip_last_error()
+    assert lib.vqhip_vqkd_backward(None, 0, None, None, None, N, D, None, None, None, None) == -22

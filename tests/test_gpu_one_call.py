@@ -1,0 +1,220 @@
+"""vqhip_cvq_forward / vqhip_vqkd_forward (include/vqhip.h, round 5): ONE host call per training forward.  The reference
+runs the same step hook by hook (vq/algorithms/cvqvae/quantizer_callback.py:75-105, vq/algorithms/vqkd/quantizers/
+callbacks.py:114-129); the golden fixtures produced by the reference's own modules (update_cvq_*.npz, update_vqkd.npz) are
+checked through the one-call route in tests/test_gpu_modules.py (it is the default).  Here: the one-call route against the
+hook-by-hook route of this package step after step — tokens, codebooks, probabilities and straight-through outputs bit for
+bit, losses and gradients within 1e-6 — eager, under bf16 autocast, with in-place updates, and with the exchange forced
+through its two-phase form."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+EMB = 'torch_nn_modules_sparse_Embedding'
+
+
+def build(cfg, w, no_grad_params=False):
+    from vector_quantization_amd import Config, build_quantizer
+    q = build_quantizer(cfg)
+    q.train(True)
+    q.init_weights(Config(type='vqgan') if cfg['type'] == 'VQGANQuantizer' else Config())
+    q = q.cuda()
+    q._forward_pre_hooks.clear()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(w))
+    if no_grad_params:
+        for p in q.parameters():
+            p.requires_grad_(False)
+    return q
+
+
+def cvq_cfg(K, D, dist, loss='VQGANLoss'):
+    return dict(type='VQGANQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D),
+                distance=dict(type=f'{dist}Distance'), losses=dict(vqgan_loss=dict(type=loss)),
+                callbacks=[dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))])
+
+
+def vqkd_cfg(K, D):
+    return dict(type='VQKDQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D),
+                distance=dict(type='CosineDistance'), callbacks=[dict(type='VQKDCallback', ema=dict())],
+                losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True))))
+
+
+def batches(N, K, D, w0, steps, seed, bf16=False):
+    g = synth.rng(seed)
+    out = []
+    for _ in range(steps):                       # most tokens sit on an eighth of the codes: the rest go stale and get listed
+        x = g.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + w0[g.integers(0, max(1, K // 8), N)]
+        t = torch.from_numpy(x).cuda()
+        out.append(t.bfloat16() if bf16 else t)
+    return out
+
+
+def run_steps(q, xs, gz, one_call, autocast=False):
+    q.one_call_steps = one_call
+    rec = []
+    for x in xs:
+        xin = x.clone().requires_grad_(True)
+        for p in q.parameters():
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            z, loss, memo = q(xin, {})
+        torch.autograd.backward([loss, z], [None, gz])
+        wg = q.embedding.weight.grad
+        rec.append(dict(quant=memo['quant'].clone(), z=z.detach().clone(), loss=loss.detach().clone(), gx=xin.grad.clone(),
+                        gw=None if wg is None else wg.clone(), w=q.embedding.weight.detach().clone(),
+                        hist=memo['encode']['hist'].clone(), memo_x=memo['x'].detach().clone(),
+                        loss_memo={k: v.detach().clone() for k, v in memo['loss'].items()}))
+    return rec
+
+
+def assert_same(a, b, exact_w=True, tol=1e-6):
+    for sa, sb in zip(a, b):
+        assert torch.equal(sa['quant'], sb['quant'])
+        assert torch.equal(sa['hist'], sb['hist'])
+        assert torch.equal(sa['memo_x'], sb['memo_x'])
+        if exact_w:
+            assert torch.equal(sa['w'], sb['w']) and torch.equal(sa['z'], sb['z'])
+        else:
+            torch.testing.assert_close(sa['w'], sb['w'], rtol=0, atol=3e-6)
+            torch.testing.assert_close(sa['z'], sb['z'], rtol=0, atol=3e-6)
+        assert abs(float(sa['loss']) - float(sb['loss'])) <= tol * max(1.0, abs(float(sb['loss'])))
+        assert sa['loss_memo'].keys() == sb['loss_memo'].keys()
+        torch.testing.assert_close(sa['gx'], sb['gx'], rtol=1e-5, atol=1e-9)
+        assert (sa['gw'] is None) == (sb['gw'] is None)
+        if sa['gw'] is not None:
+            torch.testing.assert_close(sa['gw'], sb['gw'], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('dist,D,bf16', [('L2', 64, False), ('Cosine', 64, False), ('Cosine', 256, True), ('L2', 8, True)])
+def test_cvq_one_call_equals_hook_by_hook(dist, D, bf16):
+    N, K = 3000, 2048
+    w0 = synth.unit_rows(synth.rng(5).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 6, 31, bf16)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) / (N * D)
+    recs, rows = [], []
+    for one_call in (False, True):
+        q = build(cvq_cfg(K, D, dist), w0)
+        recs.append(run_steps(q, xs, gz, one_call))
+        rows.append(q._callbacks.callbacks[0].last_exchange_rows)
+        recs[-1].append(dict(p=q.get_buffer('_probability').clone()))
+    assert torch.equal(recs[0][-1]['p'], recs[1][-1]['p'])
+    assert_same(recs[0][:-1], recs[1][:-1])
+    assert rows[0] == rows[1] and 0 < rows[1] < K, rows           # the one-call route sized its launches from the prefetched count
+
+
+def test_cvq_one_call_under_autocast_and_other_losses():
+    N, K, D = 2048, 1024, 32
+    w0 = synth.unit_rows(synth.rng(6).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 4, 32)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2)) / (N * D)
+    for loss in ('VQGANLoss', 'CodebookLoss'):                    # configs/cluster/model.py: CodebookLoss
+        recs = []
+        for one_call in (False, True):
+            q = build(cvq_cfg(K, D, 'Cosine', loss), w0)
+            recs.append(run_steps(q, xs, gz, one_call, autocast=True))
+        assert_same(recs[0], recs[1])
+
+
+def test_cvq_one_call_in_place_updates_and_external_probability_change():
+    """inplace_updates (what graph capture uses) writes codebook and probabilities into their storage; a probability buffer
+    replaced from outside (a loaded checkpoint) voids the prefetched list and is counted on the spot."""
+    N, K, D = 1500, 1024, 64
+    w0 = synth.unit_rows(synth.rng(7).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 5, 33)
+    gz = torch.zeros(N, D, device='cuda')
+    outs = []
+    for one_call, inplace in ((False, False), (True, True), (True, False)):
+        q = build(cvq_cfg(K, D, 'L2'), w0)
+        q.inplace_updates = inplace
+        ptr = q.embedding.weight.data_ptr()
+        rec = run_steps(q, xs[:3], gz, one_call)
+        if inplace:
+            assert q.embedding.weight.data_ptr() == ptr
+        sd = {k: v.clone() for k, v in q.state_dict().items()}
+        q.load_state_dict(sd)                                     # in-place copy_: bumps the buffer's version
+        with torch.no_grad():
+            q.get_buffer('_probability').mul_(0.5)                # ... and a change of values from outside
+        rec += run_steps(q, xs[3:], gz, one_call)
+        outs.append((rec, q.get_buffer('_probability').clone()))
+    for other in outs[1:]:
+        assert_same(outs[0][0], other[0])
+        assert torch.equal(outs[0][1], other[1])
+
+
+@pytest.mark.parametrize('N', [3000, 40000])                      # 40 000 tokens: the ordered (bit-reproducible) centroid sums
+def test_vqkd_one_call_equals_hook_by_hook(N):
+    K, D = 1024, 32
+    w0 = synth.unit_rows(synth.rng(8).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 4, 34)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) / (N * D)
+    recs = []
+    for one_call in (False, True):
+        q = build(vqkd_cfg(K, D), w0, no_grad_params=True)
+        recs.append(run_steps(q, xs, gz, one_call))
+    assert_same(recs[0], recs[1], exact_w=(N >= 32768))
+    # autocast: the bf16 cosine metric inside the one call as well
+    recs = []
+    for one_call in (False, True):
+        q = build(vqkd_cfg(K, D), w0, no_grad_params=True)
+        recs.append(run_steps(q, xs[:2], gz, one_call, autocast=True))
+    assert_same(recs[0], recs[1], exact_w=(N >= 32768))
+
+
+def test_vqkd_one_call_matches_the_reference_fixture_and_its_gradient():
+    g = np.load(os.path.join(GOLDEN, 'update_vqkd.npz'))
+    spec = json.loads(str(g['spec']))
+    N, K, D = spec['N'], spec['K'], spec['D']
+    x, w = synth.make_inputs('normal', spec['seed'], N, K, D)
+    w = synth.unit_rows(w)
+    q = build(vqkd_cfg(K, D), w)
+    assert q._one_call_step(torch.from_numpy(x).cuda()) is not None
+    xd = torch.from_numpy(x).cuda().requires_grad_(True)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(4))
+    z, loss, memo = q(xd, {})
+    np.testing.assert_array_equal(memo['quant'].cpu().numpy(), g['quant'].astype(np.int64))
+    np.testing.assert_allclose(q.embedding.weight.detach().cpu().numpy(), g['w_new'], rtol=0, atol=3e-6)
+    torch.autograd.backward([loss, z], [None, gz])
+    xt = torch.from_numpy(x).requires_grad_(True)
+    xn = torch.nn.functional.normalize(xt)
+    zt = tr.decode(torch.from_numpy(g['quant'].astype(np.int64)), torch.from_numpy(g['w_new']))
+    rl = tr.commitment_loss(zt, xn, norm=True)
+    zs = tr.ste(zt, xn)
+    (rl + (zs * gz.cpu()).sum()).backward()
+    assert abs(loss.item() - rl.item()) <= 1e-5
+    np.testing.assert_allclose(z.detach().cpu().numpy(), zs.detach().numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(memo['x'].detach().cpu().numpy(), xn.detach().numpy(), rtol=0, atol=1e-7)
+
+
+def test_forced_exchange_takes_the_two_phase_route(monkeypatch):
+    """With an exchange to run and no communicator of the library's own, the forward is two calls around the caller's
+    collective: forced here at one rank (the collective is then any callable; identity for a one-rank SUM)."""
+    from vector_quantization_amd import train_step
+    from vector_quantization_amd.quantizers import callbacks as cbm
+    N, K, D = 2000, 1024, 64
+    w0 = synth.unit_rows(synth.rng(9).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 4, 35)
+    gz = torch.zeros(N, D, device='cuda')
+    base = run_steps(build(cvq_cfg(K, D, 'Cosine'), w0), xs, gz, True)
+    wk, xk, gk = w0[:, :32].copy(), [x[:, :32].contiguous() for x in xs], gz[:, :32].contiguous()
+    base_k = run_steps(build(vqkd_cfg(K, 32), wk, True), xk, gk, True)
+    calls = []
+    monkeypatch.setattr(cbm, 'exchanging', lambda: True)
+    import vector_quantization_amd.utils as U
+    monkeypatch.setattr(U, 'all_reduce_sum', lambda t: calls.append(t.numel()) or t)
+    forced = run_steps(build(cvq_cfg(K, D, 'Cosine'), w0), xs, gz, True)
+    assert_same(base, forced)
+    assert len(calls) == len(xs) and calls[0] == 2 * K + 4 + K * D and calls[-1] < calls[0]     # the payload shrinks with the list
+    calls.clear()
+    forced_k = run_steps(build(vqkd_cfg(K, 32), wk, True), xk, gk, True)
+    assert len(calls) == len(xs) and calls[0] == 2 * K + 4 + K * 32
+    assert_same(base_k, forced_k, exact_w=False)
+    del train_step

@@ -1089,6 +1089,189 @@ int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p
     return VQHIP_OK;
 }
 
+// ---- one host call per training forward (include/vqhip.h) ------------------------------------------------------------
+static inline int64_t vq_align1k(int64_t v) { return (v + 1023) / 1024 * 1024; }
+
+// workspace of vqhip_cvq_forward: [row pass: vqhip_workspace_bytes(N, K, D)][col_idx: K int64][column pass over <= cap_max codes]
+int64_t vqhip_cvq_forward_ws_bytes(int64_t N, int64_t K, int D, int64_t cap_max) {
+    if (N <= 0 || K <= 0 || D <= 0 || cap_max < 0 || cap_max > K) return 0;
+    return vq_align1k(vqhip_workspace_bytes(N, K, D)) + vq_align1k(K * 8) + (cap_max > 0 ? vqhip_col_rows_workspace_bytes(N, cap_max, D) : 0);
+}
+
+int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
+    if (!a || a->struct_bytes != (int64_t)sizeof(vqhip_cvq_forward_t)) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: struct_bytes != sizeof(vqhip_cvq_forward_t)");
+    const int64_t N = a->N, K = a->K;
+    const int D = a->D, metric = a->metric;
+    if (N <= 0 || K <= 0 || D <= 0 || N >= (1ll << 31) || K >= (1ll << 31) || !vq_coarse_supported(D))
+        return fail(VQHIP_EINVAL, "vqhip_cvq_forward: needs N, K > 0 and D <= 1024, D % 8 == 0");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: metric");
+    if (a->x_dtype != VQHIP_DTYPE_F32 && a->x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: x_dtype");
+    if (a->phases < 1 || a->phases > VQHIP_STEP_ALL) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: phases");
+    if (!a->x || !a->w_in || !a->p_in || !a->w_out || !a->p_out || !a->rows || !a->slot || !a->count || !a->cb || !a->idx || !a->hist || !a->ws)
+        return fail(VQHIP_EINVAL, "vqhip_cvq_forward: null pointer");
+    const bool cos = VQ_IS_COS(metric);
+    if (cos && !a->xq) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: the cosine metric needs the xq buffer");
+    if ((a->z_ste || a->mse) && (!a->mse || !a->scratch16)) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: the decode tail needs mse and scratch16");
+    if (a->exchange) {
+        if (!a->packed) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: exchange without a packed buffer");
+        if (a->world < 1 || a->world > VQ_PACK_MAX_WORLD) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: world must be in [1, 256]");
+        if (a->phases == VQHIP_STEP_ALL && !a->comm && a->world > 1)
+            return fail(VQHIP_EINVAL, "vqhip_cvq_forward: VQHIP_STEP_ALL over more than one rank needs a communicator (or issue the collective between the two phases)");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t enc_bytes = vq_align1k(vqhip_workspace_bytes(N, K, D));
+    VQ_NEED("vqhip_cvq_forward: ws too small", a->ws_bytes, enc_bytes + vq_align1k(K * 8));
+    char *w = (char *)a->ws;
+    int64_t *col_idx = (int64_t *)(w + enc_bytes);
+    char *col_ws = w + enc_bytes + vq_align1k(K * 8);
+    const int64_t col_ws_have = a->ws_bytes - enc_bytes - vq_align1k(K * 8);
+    if (a->phases & VQHIP_STEP_BEFORE_EXCHANGE) {
+        if (int rc = vqhip_encode_ex(a->x, a->x_dtype, a->w_in, N, K, D, metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws,
+                                     enc_bytes, VQHIP_ENCODE_ZERO_HIST, stream)) return rc;
+        if (!a->list_ready)
+            if (int rc = vqhip_cvq_rows(a->p_in, K, a->ema_decay, a->eps, a->rows, a->slot, a->count, stream)) return rc;
+        int64_t cap = a->cap;
+        if (cap < 0) {                   // the count the previous call's prefetch copied out: queued a whole step ago
+            if (!a->count_host) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap < 0 needs count_host");
+            if (a->count_event) VQ_HIP(hipEventSynchronize((hipEvent_t)a->count_event));
+            cap = (int64_t)*(volatile const int32_t *)a->count_host;
+        }
+        if (cap < 0 || cap > K) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: capacity outside [0, K]");
+        a->cap_used = cap;
+        a->exchange_floats = a->exchange ? vqhip_pack_floats(K, cap, D) : 0;
+        if (a->exchange) VQ_NEED("vqhip_cvq_forward: packed buffer too small (floats)", a->packed_floats, a->exchange_floats);
+        if (cap > 0) {
+            VQ_NEED("vqhip_cvq_forward: ws too small for the column pass", col_ws_have, vqhip_col_rows_workspace_bytes(N, cap, D));
+            const VqCbLayout L = vq_cb_layout(K, D);
+            const void *rows_x = cos ? (const void *)a->xq : a->x;
+            const float *codes = cos ? (const float *)((const char *)a->cb + L.off_eexact) : a->w_in;
+            if (int rc = vqhip_col_argmin_rows(rows_x, cos ? VQHIP_DTYPE_F32 : a->x_dtype, codes, a->rows, a->count, cap, N, K, D, metric,
+                                               col_idx, col_ws, col_ws_have, stream)) return rc;
+        }
+        if (a->exchange)
+            if (int rc = vqhip_cvq_pack(a->hist, N, a->x, a->x_dtype, col_idx, a->count, cap, K, D, a->packed, stream)) return rc;
+    }
+    if (a->phases == VQHIP_STEP_ALL && a->exchange && a->comm)
+        if (int rc = vqhip_allreduce_packed(a->packed, a->exchange_floats, a->comm, stream)) return rc;
+    if (a->phases & VQHIP_STEP_AFTER_EXCHANGE) {
+        if (a->cap_used < 0 || a->cap_used > K) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap_used (the BEFORE phase writes it)");
+        if (int rc = vqhip_cvq_apply(a->w_in, a->w_out, a->p_in, a->p_out, a->hist, N, a->x, a->x_dtype, col_idx, a->exchange ? a->packed : nullptr,
+                                     a->world, a->slot, K, D, a->ema_decay, a->eps, stream)) return rc;
+        if (a->prefetch) {
+            if (int rc = vqhip_cvq_rows(a->p_out, K, a->ema_decay, a->eps, a->rows, a->slot, a->count, stream)) return rc;
+            if (a->count_host) {
+                VQ_HIP(hipMemcpyAsync(a->count_host, a->count, 4, hipMemcpyDeviceToHost, s));
+                if (a->count_event) VQ_HIP(hipEventRecord((hipEvent_t)a->count_event, s));
+            }
+        }
+        if (a->mse)
+            if (int rc = vqhip_gather_ste_mse(a->x, a->x_dtype, a->w_out, a->idx, N, D, nullptr, a->z_ste, a->mse, a->beta, a->scratch16, stream)) return rc;
+    }
+    return VQHIP_OK;
+}
+
+// workspace of vqhip_vqkd_forward: [encode: vqhip_workspace_bytes(N, K, D)][ordered sums: counts K, offsets K + 1, order N int32,
+// vqhip_order_workspace_bytes, vqhip_segsum_workspace_bytes]
+static inline void vqkd_ws_offsets(int64_t N, int64_t K, int D, int64_t *o_counts, int64_t *o_offsets, int64_t *o_order, int64_t *o_ows,
+                                   int64_t *o_sws, int64_t *o_x2, int64_t *total) {
+    int64_t p = vq_align1k(vq_ws_layout(N, K, D).total);
+    *o_x2 = p; p += vq_align1k(N * (int64_t)D * 4);        // F.normalize(xn) for the ordered sums under the bf16-autocast metric (xq is rounded there)
+    *o_counts = p; p += vq_align1k(K * 4);
+    *o_offsets = p; p += vq_align1k((K + 1) * 4);
+    *o_order = p; p += vq_align1k(N * 4);
+    *o_ows = p; p += vq_align1k(vqhip_order_workspace_bytes(N, K));
+    *o_sws = p; p += vq_align1k(vqhip_segsum_workspace_bytes(N, D));
+    *total = p;
+}
+
+int64_t vqhip_vqkd_forward_ws_bytes(int64_t N, int64_t K, int D) {
+    if (N <= 0 || K <= 0 || D <= 0) return 0;
+    int64_t a, b, c, d, e, f, total;
+    vqkd_ws_offsets(N, K, D, &a, &b, &c, &d, &e, &f, &total);
+    return total;
+}
+
+int vqhip_vqkd_forward(vqhip_vqkd_forward_t *a, void *stream) {
+    if (!a || a->struct_bytes != (int64_t)sizeof(vqhip_vqkd_forward_t)) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: struct_bytes != sizeof(vqhip_vqkd_forward_t)");
+    const int64_t N = a->N, K = a->K;
+    const int D = a->D;
+    if (N <= 0 || K <= 0 || D <= 0 || N >= (1ll << 31) || K >= (1ll << 31) || !vq_coarse_supported(D))
+        return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: needs N, K > 0 and D <= 1024, D % 8 == 0");
+    if (a->metric != VQHIP_METRIC_COS && a->metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: metric (cosine only)");
+    if (a->x_dtype != VQHIP_DTYPE_F32 && a->x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: x_dtype");
+    if (a->phases < 1 || a->phases > VQHIP_STEP_ALL) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: phases");
+    if (!a->x || !a->w_in || !a->w_mid || !a->w_out || !a->xn || !a->xq || !a->cb || !a->idx || !a->hist || !a->packed || !a->ws)
+        return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: null pointer");
+    if (a->tail && (!a->mse || !a->scratch16)) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: the tail needs mse and scratch16");
+    if (a->world < 1 || a->world > VQ_PACK_MAX_WORLD) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: world must be in [1, 256]");
+    if (a->phases == VQHIP_STEP_ALL && a->exchange && !a->comm && a->world > 1)
+        return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: VQHIP_STEP_ALL over more than one rank needs a communicator (or issue the collective between the two phases)");
+    if (a->ordered && (K > 32768 || (D % 4) != 0)) return fail(VQHIP_EINVAL, "vqhip_vqkd_forward: ordered sums need K <= 32768 and D % 4 == 0");
+    const int64_t floats = vqhip_pack_floats(K, K, D);
+    VQ_NEED("vqhip_vqkd_forward: packed buffer too small (floats)", a->packed_floats, floats);
+    int64_t o_counts, o_offsets, o_order, o_ows, o_sws, o_x2, total;
+    vqkd_ws_offsets(N, K, D, &o_counts, &o_offsets, &o_order, &o_ows, &o_sws, &o_x2, &total);
+    VQ_NEED("vqhip_vqkd_forward: ws too small", a->ws_bytes, total);
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)a->ws;
+    float *payload = a->packed + VQ_PACK_HEADER(K);
+    if (a->phases & VQHIP_STEP_BEFORE_EXCHANGE) {
+        a->exchange_floats = floats;
+        // front: codebook normalised twice, latents normalised, payload zeroed (the atomic sums need it; the ordered sums write every row)
+        int64_t nzero = a->ordered ? 0 : K * (int64_t)D;
+        if (nzero && ((K & 1) || (nzero % 4))) {            // a payload that is not 16-byte aligned / sized: plain memset
+            VQ_HIP(hipMemsetAsync(payload, 0, (size_t)nzero * 4, s));
+            nzero = 0;
+        }
+        const int kblocks = (int)((K + 3) / 4), xblocks = (int)((N + 3) / 4);
+        if (a->x_dtype == VQHIP_DTYPE_F32) vqkd_front_kernel<0><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_mid, K, a->x, a->xn, N, D, 1e-12f, kblocks, payload, nzero);
+        else vqkd_front_kernel<1><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_mid, K, a->x, a->xn, N, D, 1e-12f, kblocks, payload, nzero);
+        VQ_CHECK_LAUNCH("vqkd_front_kernel");
+        if (int rc = vqhip_encode_ex(a->xn, VQHIP_DTYPE_F32, a->w_mid, N, K, D, a->metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws,
+                                     vq_align1k(vq_ws_layout(N, K, D).total), VQHIP_ENCODE_ZERO_HIST, stream)) return rc;
+        const int hb = (int)((K + 255) / 256);
+        if (a->ordered) {
+            int32_t *counts = (int32_t *)(w + o_counts), *offsets = (int32_t *)(w + o_offsets), *order = (int32_t *)(w + o_order);
+            if (int rc = vqhip_token_order(a->idx, N, K, counts, offsets, order, w + o_ows, vqhip_order_workspace_bytes(N, K), stream)) return rc;
+            const float *x2 = a->xq;                      // F.normalize(xn): the encode's by-product — except under the bf16-autocast
+            if (VQ_IS_BF16(a->metric)) {                  // metric, where xq holds the ROUNDED rows (the operand of that metric)
+                if (int rc = vqhip_normalize_rows(a->xn, VQHIP_DTYPE_F32, N, D, 1e-12f, (float *)(w + o_x2), stream)) return rc;
+                x2 = (const float *)(w + o_x2);
+            }
+            if (int rc = vqhip_segsum_rows(x2, a->idx, order, offsets, N, K, D, payload, w + o_sws, vqhip_segsum_workspace_bytes(N, D), stream)) return rc;
+            vqkd_scatter_pack_kernel<<<hb, 256, 0, s>>>(a->hist, N, a->xn, a->idx, N, K, D, 1e-12f, a->packed, hb, 0);
+        } else {
+            vqkd_scatter_pack_kernel<<<hb + xblocks, 256, 0, s>>>(a->hist, N, a->xn, a->idx, N, K, D, 1e-12f, a->packed, hb, 1);
+        }
+        VQ_CHECK_LAUNCH("vqkd_scatter_pack_kernel");
+    }
+    if (a->phases == VQHIP_STEP_ALL && a->exchange && a->comm)
+        if (int rc = vqhip_allreduce_packed(a->packed, floats, a->comm, stream)) return rc;
+    if (a->phases & VQHIP_STEP_AFTER_EXCHANGE) {
+        vqkd_update_packed_kernel<<<waves_grid(K, 4), 256, 0, s>>>(a->w_mid, a->w_out, a->packed, K, D, a->ema_decay);
+        VQ_CHECK_LAUNCH("vqkd_update_packed_kernel");
+        if (a->tail) {
+            int grid = (int)((N + 3) / 4); grid = grid > 1024 ? 1024 : grid;
+            vqkd_tail_kernel<<<grid, 256, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse);
+            VQ_CHECK_LAUNCH("vqkd_tail_kernel");
+        }
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_vqkd_backward(const void *x, int x_dtype, const float *xn, const float *w, const int64_t *idx, int64_t N, int D,
+                        const float *g_zste, const float *g_loss, float *grad_x, void *stream) {
+    if (!x || !xn || !w || !idx || !grad_x || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: bad argument");
+    if (N == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)((N + 3) / 4); grid = grid > 2048 ? 2048 : grid;
+    if (x_dtype == VQHIP_DTYPE_F32) vqkd_backward_kernel<0><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x);
+    else if (x_dtype == VQHIP_DTYPE_BF16) vqkd_backward_kernel<1><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x);
+    else return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: x_dtype");
+    VQ_CHECK_LAUNCH("vqkd_backward_kernel");
+    return VQHIP_OK;
+}
+
 int vqhip_argmin_stats(const void *ws, int32_t *out, void *stream) {
     if (!ws || !out) return fail(VQHIP_EINVAL, "vqhip_argmin_stats: bad argument");
     VQ_HIP(hipMemcpyAsync(out, ws, 16, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -265,3 +265,4 @@ __device__ __forceinline__ void cb_stats_publish(const VqCbStats *st) {
 #include "vqhip_sort_kernels.h"
 #include "vqhip_aux_kernels.h"
 #include "vqhip_exchange_kernels.h"
+#include "vqhip_step_kernels.h"

@@ -166,3 +166,68 @@ class _FusedMapDecodeLoss(Function):
 def fused_map_decode_loss(x_map: torch.Tensor, x_rows: torch.Tensor, weight: torch.Tensor, idx: torch.Tensor, beta: float = 0.0):
     """Returns (z_map [B, D, H, W], m_cb, m_cm, m_cb + beta*m_cm)."""
     return _FusedMapDecodeLoss.apply(x_map, x_rows, weight, idx, beta)
+
+
+class _Computed:
+    """Tensors a one-call training forward (train_step.py) has already produced, handed to the autograd wrappers below
+    without becoming graph inputs."""
+
+    def __init__(self, **tensors) -> None:
+        self.__dict__.update(tensors)
+
+
+class _PrecomputedDecodeLoss(Function):
+    """``_FusedDecodeLoss`` whose forward values were computed by vqhip_cvq_forward in the same library call as the encode and
+    the codebook update: the node only ties them into the graph.  Backward is the same fused kernel."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, done: _Computed, beta: float):
+        ctx.set_materialize_grads(False)
+        ctx.beta = float(beta)
+        ctx.save_for_backward(x, weight, done.idx)
+        mse = done.mse
+        return done.z_ste.view(x.shape), mse[0], mse[1], mse[2]
+
+    @staticmethod
+    def backward(ctx, g_zste, g_cb, g_cm, g_comb):
+        x, weight, idx = ctx.saved_tensors
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx, gw = ops.vq_backward(x, weight, idx, g_zste, g_cb, g_cm, need_x, need_w, g_comb=g_comb, beta=ctx.beta)
+        if gx is not None:
+            gx = gx.view(x.shape).to(x.dtype)
+        return gx, gw, None, None
+
+
+def precomputed_decode_loss(x: torch.Tensor, weight: torch.Tensor, done: _Computed, beta: float = 0.0):
+    """(z_ste, m_cb, m_cm, m_cb + beta*m_cm) of ``fused_decode_loss`` from values a one-call forward already holds."""
+    return _PrecomputedDecodeLoss.apply(x, weight, done, beta)
+
+
+class _VqkdStep(Function):
+    """Autograd node of the VQ-KD one-call forward: outputs xn = F.normalize(x) (what memo['x'] holds), the straight-through
+    output xn + sg(z - xn) and the commitment loss mean((F.normalize(sg z) - F.normalize(xn))^2) (CommitmentLoss with
+    mse norm=True); backward is ONE kernel (vqhip_vqkd_backward).  The codebook receives no gradient: the commitment term
+    detaches z and the straight-through output detaches (z - xn)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, done: _Computed):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, done.xn, weight, done.idx)
+        return done.xn.view(x.shape), done.z_ste.view(x.shape), done.mse[0]
+
+    @staticmethod
+    def backward(ctx, g_xn, g_zste, g_loss):
+        from . import train_step
+        x, xn, weight, idx = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        g = g_zste
+        if g_xn is not None:                                    # a consumer of memo['x'] other than the straight-through output
+            g = g_xn if g is None else g + g_xn
+        gx = train_step.vqkd_backward(_as2d(x), xn, weight, idx, None if g is None else _as2d(g), g_loss)
+        return gx.view(x.shape).to(x.dtype), None, None
+
+
+def vqkd_step(x: torch.Tensor, weight: torch.Tensor, done: _Computed):
+    """(xn, z_ste, commitment loss) tied into the autograd graph."""
+    return _VqkdStep.apply(x, weight, done)

@@ -79,7 +79,10 @@ class GraphedQuantizer(nn.Module):
         with ops.owned_mse_scratch(self._mse_scratch):
             if self._train:
                 sample = sample_x.detach().clone().requires_grad_(True)
-                self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup)
+                # (allow_unused_input: a VQ-KD step gives the codebook no gradient — the commitment term and the straight-through
+                #  output both detach z, configs/vqkd/model.py:76-82 freezes the quantizer anyway — and the one-call forward's
+                #  autograd node says so with None instead of a zero-filled [K, D] tensor)
+                self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup, allow_unused_input=True)
             else:
                 self._x = sample_x.detach().clone()
                 side = torch.cuda.Stream()

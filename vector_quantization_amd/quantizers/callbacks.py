@@ -16,11 +16,11 @@ import torch.distributed as dist
 from .. import exchange, ops
 from ..config import BuildPreHookMixin, Config, Item, RegistryMeta
 from ..registries import AnchorRegistry, VQITQuantizerCallbackRegistry
-from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, exchanging, gather_to_rank0, get_rank,
-                     get_world_size, is_sync)
+from ..utils import (EMA, PriorityQueue, Store, all_reduce_statistics, broadcast_, exchange_log, exchanging, gather_to_rank0,
+                     get_rank, get_world_size, is_sync)
 from .anchors import NearestAnchor
 from .distances import LazyDistance
-from .memo import Memo
+from .memo import Memo, get_memo
 from .quantizer_api import BaseQuantizer
 from .statistics import QuantStatistics
 
@@ -269,6 +269,62 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
             broadcast_(e, 0)
         self._update_embedding(e)
 
+    # ---- the whole training forward as ONE library call (train_step.py, include/vqhip.h: vqhip_vqkd_forward) ------------
+    def fused_forward_ok(self, x: torch.Tensor) -> bool:
+        """True when this step can be enqueued by one call: train mode, the lazy init done, device latents with a proposal
+        image, cosine distance with the library's fused encode, an EMA, a world the packed exchange covers."""
+        from .distances import CosineDistance
+        q = self.vector_quantizer
+        if not (q.training and self.with_ema and x.dim() == 2 and x.is_cuda and x.shape[0] > 0 and x.shape[0] < (1 << 31)):
+            return False
+        if type(q.distance) is not CosineDistance or not ops.coarse_supported(q.embedding_dim) or q._cache_codebook:
+            return False
+        if len(q._forward_pre_hooks) > 0 or get_world_size() > exchange.MAX_WORLD:
+            return False
+        w = q.embedding.weight
+        return w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+
+    def fused_forward(self, x: torch.Tensor, memo: Memo):
+        """NormalizeCallback.before_encode + _encode + after_encode + decode + CommitmentLoss(norm=True) + STE of one training
+        step (normalize.py:22-29, vqkd callbacks.py:114-129, quantizers.py:92-117) from one host call.  Returns
+        (xn, quant, z_ste, loss) with the reference's memo side effects; weight.data is rebound (or overwritten in place)
+        exactly as the two ``_update_embedding`` calls of the unfused flow leave it."""
+        from .. import functional as VF, train_step
+        from ..utils import all_reduce_sum
+        q = self.vector_quantizer
+        weight = q.embedding.weight
+        K, D = weight.shape
+        if getattr(self, '_step_state', None) is None:
+            self._step_state = train_step.VqkdStepState()
+        inplace = q.inplace_updates
+        w_in = weight.detach()
+        w_mid = w_in if inplace else torch.empty_like(w_in)
+        w_out = w_in if inplace else torch.empty_like(w_in)
+        xd = x.detach()
+        exch = exchanging()
+        comm = None
+        if exch and not exchange_log.enabled:
+            from .. import rccl
+            comm = rccl.communicator(w_in)
+        metric = q.distance.metric_for(D)
+        ordered = ops.use_ordered(K, D, None, xd.shape[0])
+        out = train_step.vqkd_forward(xd, w_in, w_mid, w_out, metric, self._ema.decay, self._step_state, exchange=exch,
+                                      world=get_world_size(), comm=comm, all_reduce=all_reduce_sum if exch else None,
+                                      ordered=ordered, tail=True)
+        if Store.DRY_RUN:
+            assert is_sync(w_out)
+        if not inplace:
+            weight.data = w_out                                  # callbacks/update.py:56 (after the EMA update: callbacks.py:128)
+        q.invalidate_codebook()
+        done = VF._Computed(xn=out['xn'], z_ste=out['z_ste'], mse=out['mse'], idx=out['idx'])
+        xn, z_ste, loss = VF.vqkd_step(x, weight, done)
+        enc = get_memo(memo, 'encode')
+        prepared = out['prepared']
+        enc['distance'] = LazyDistance(q.distance, xn, w_mid, xq=out['xq'], eq=prepared.exact_rows(), metric=ops.metric_name(prepared.metric))
+        enc['hist'] = out['hist']
+        memo['encode'] = enc
+        return xn, out['idx'], z_ste, loss
+
     def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
         quant = super().after_encode(x, quant, memo)
         if not self.quantizer.training:
@@ -301,6 +357,8 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         self._sparse_anchors = sparse_anchors
         self._listed = None               # (p tensor, its _version, rows, slot, count, pinned host count, copy event)
         self._pinned_count = None
+        self._step_state = None           # train_step.CvqStepState of the one-call forward (lazily, on the codebook's device)
+        self.capture_cap = None           # capacity of the listed-code launches under HIP-graph capture (None = K; graphs.py)
         self.last_exchange_rows = None    # M of the last training step (diagnostics: bench.py, tests)
 
     @classmethod
@@ -322,6 +380,8 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
 
     def _update_probability(self, value: torch.Tensor) -> None:
         self._listed = None               # a list prefetched for the old probabilities is void (`_prefetch_listed` re-arms it)
+        if self._step_state is not None:
+            self._step_state.invalidate()
         if self.quantizer.inplace_updates and '_probability' in self.quantizer._buffers \
                 and self.quantizer._buffers['_probability'].shape == value.shape \
                 and self.quantizer._buffers['_probability'].device == value.device:
@@ -398,8 +458,108 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         else:
             self._update_probability(p_out)
             self._update_embedding(w_out)
+        if self._step_state is not None:                         # the one-call forward's list described the old probabilities
+            self._step_state.invalidate()
         if not capturing:
             self._prefetch_listed(self.probability, K)
+
+    # ---- the whole training forward as ONE library call (train_step.py, include/vqhip.h: vqhip_cvq_forward) --------------
+    def fused_forward_ok(self, x: torch.Tensor) -> bool:
+        """True when this step can be enqueued by one call: the conditions of the sparse-anchor flow (`_sparse_ok`) that can
+        be known before the encode, a distance whose encode is the library's fused one, device latents."""
+        from .distances import CosineDistance, L2Distance
+        q = self.vector_quantizer
+        if not (q.training and self.with_ema and x.dim() == 2 and x.is_cuda and x.shape[0] > 0 and x.shape[0] < (1 << 31)):
+            return False
+        if self._sparse_anchors is False or type(self._anchor) is not NearestAnchor:
+            return False
+        if (self._anchor._sync and get_world_size() > 1) or get_world_size() > exchange.MAX_WORLD:
+            return False
+        if type(q.distance) not in (L2Distance, CosineDistance) or not ops.coarse_supported(q.embedding_dim) or q._cache_codebook:
+            return False
+        if '_probability' not in q._buffers:
+            return False
+        p, w = self.probability, q.embedding.weight
+        return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.device == x.device
+                and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous())
+
+    def refresh_list(self) -> None:
+        """(Re)build the device-side list of codes for the CURRENT probabilities and note its length on the host — what a
+        first step, a loaded checkpoint or a probability buffer replaced from outside needs (one synchronisation)."""
+        from .. import train_step
+        p = self.probability
+        K = self.quantizer.codebook_size
+        if self._step_state is None or self._step_state.device != p.device or self._step_state.K != K:
+            self._step_state = train_step.CvqStepState(K, p.device)
+        st = self._step_state
+        ops.cvq_rows(p, K, self._ema.decay, self._eps, out=(st.rows, st.slot, st.count))
+        st.count_host[0] = int(st.count.item())
+        st.mark_list(p)
+
+    def fused_forward(self, x: torch.Tensor, memo: Memo, beta: float):
+        """_encode + after_encode (sparse-anchor flow of `_sparse_step`) + decode + MSE losses + STE of one training step from
+        one host call.  Returns (quant, z_ste, m_cb, m_cm, m_vqgan) with the reference's memo side effects."""
+        from .. import functional as VF, train_step
+        from ..utils import all_reduce_sum
+        q = self.vector_quantizer
+        weight = q.embedding.weight
+        K, D = weight.shape
+        capturing = torch.cuda.is_current_stream_capturing()
+        p_in = self.probability
+        if self._step_state is None or self._step_state.device != p_in.device or self._step_state.K != K:
+            self._step_state = train_step.CvqStepState(K, p_in.device)
+        st = self._step_state
+        if capturing:                     # the launches are sized for a fixed capacity, the device-side count decides
+            list_ready, cap, prefetch = False, (K if self.capture_cap is None else int(self.capture_cap)), False
+        else:
+            if not st.list_valid_for(p_in):
+                self.refresh_list()       # first step / probabilities replaced from outside: counted on the spot
+                st = self._step_state
+                list_ready, cap = True, int(st.count_host[0])
+            else:
+                list_ready, cap = True, -1          # the library reads the count the previous step's prefetch copied out
+            prefetch = True
+        inplace = q.inplace_updates
+        w_in = weight.detach()
+        w_out = w_in if inplace else torch.empty_like(w_in)
+        p_out = p_in if inplace else torch.empty_like(p_in)
+        exch = exchanging()
+        comm = None
+        if exch and not exchange_log.enabled:
+            from .. import rccl
+            comm = rccl.communicator(w_in)
+        metric = q.distance.metric_for(D)
+        xd = x.detach()
+        # the codebook operand of memo['distance'] aliases the storage the encode ran against (quantizers.py:97 clones it)
+        e_alias = weight.view_as(weight) if (torch.is_grad_enabled() and weight.requires_grad) else w_in
+        out = train_step.cvq_forward(xd, w_in, p_in, w_out, p_out, metric, self._ema.decay, self._eps, beta, st, cap=cap,
+                                     list_ready=list_ready, prefetch=prefetch, exchange=exch, world=get_world_size(), comm=comm,
+                                     all_reduce=all_reduce_sum if exch else None, tail=True)
+        self.last_exchange_rows = out['cap_used']
+        self._listed = None                                      # (the hook-by-hook flow's prefetched list is void now)
+        if Store.DRY_RUN:
+            assert is_sync(w_out)
+        if inplace:
+            q.invalidate_codebook()
+            p_new = p_in
+        else:
+            self._update_probability(p_out)
+            weight.data = w_out                                  # callbacks/update.py:56
+            q.invalidate_codebook()
+            p_new = p_out
+        if prefetch:
+            st.mark_list(p_new)                                  # rows / slot / count now describe p_new (the call's last but one launch)
+        enc = get_memo(memo, 'encode')
+        prepared = out['prepared']
+        cos = out['xq'] is not None
+        x_op = x if (torch.is_grad_enabled() and x.requires_grad) else out['x']
+        enc['distance'] = LazyDistance(q.distance, x_op, e_alias, xq=out['xq'] if cos else out['x'],
+                                       eq=prepared.exact_rows() if cos else w_in, metric=ops.metric_name(prepared.metric))
+        enc['hist'] = out['hist']
+        memo['encode'] = enc
+        done = VF._Computed(z_ste=out['z_ste'], mse=out['mse'], idx=out['idx'])
+        z_ste, m_cb, m_cm, m_vqgan = VF.precomputed_decode_loss(x, weight, done, beta)
+        return out['idx'], z_ste, m_cb, m_cm, m_vqgan
 
     def after_encode(self, x: torch.Tensor, quant: torch.Tensor, memo: Memo) -> torch.Tensor:
         quant = super().after_encode(x, quant, memo)

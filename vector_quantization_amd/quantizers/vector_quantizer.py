@@ -2,6 +2,7 @@
 vq/algorithms/vqgan/quantizer.py:11-21 and vq/algorithms/vqkd/quantizers/base.py:11-15."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -29,6 +30,9 @@ def _normal_init(mean: float = 0.0, std: float = 1.0):
 
 @VQITQuantizerRegistry.register_()
 class VectorQuantizer(BaseQuantizer):
+    # False (or VQHIP_ONE_CALL=0 in the environment): the callback-driven training forwards run hook by hook, one library call
+    # per piece, instead of as ONE call (train_step.py) — the same values either way (tests/test_gpu_one_call.py)
+    one_call_steps = os.environ.get('VQHIP_ONE_CALL', '1') != '0'
 
     def __init__(self, *args, embedding: nn.Embedding, distance: BaseDistance, fused: bool = True,
                  cache_codebook: bool = False, **kwargs) -> None:
@@ -153,18 +157,9 @@ class VectorQuantizer(BaseQuantizer):
                 return False
         return True
 
-    def forward(self, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:
-        """quantizers.py:110-117 (BaseQuantizer.forward, then ste(z, memo['x'])).  When nothing customises
-        decode/loss the gather, the STE expression and the MSE sums are one kernel with one fused backward."""
-        if not self._fusable() or x.dim() != 2:
-            z, loss, memo = super().forward(x, memo)
-            z = VF.ste(z, memo['x'])
-            return z, loss, memo
-        x, quant, memo = self.encode(x, memo)
-        memo.update(x=x, quant=quant)
-        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
-        z_ste, m_cb, m_cm, m_vqgan = VF.fused_decode_loss(x, self._embedding.weight, quant, betas[0] if betas else 0.0)
-        memo['decode'] = get_memo(memo, 'decode')
+    def _loss_values(self, memo: Memo, m_cb, m_cm, m_vqgan, betas, like: torch.Tensor) -> torch.Tensor:
+        """memo['loss'][name] of every configured (plain MSE) loss from the three values the fused kernel finished, and
+        their fp32 sum (base.py:151-171)."""
         losses = {}
         for name, loss in self._losses.items():
             if isinstance(loss, VQGANLoss):
@@ -180,10 +175,65 @@ class VectorQuantizer(BaseQuantizer):
         memo['loss'] = loss_memo
         values = list(losses.values())
         if len(values) == 1:                  # 0 + v == v: skip the zero-fill and the add of the general form below
-            loss = values[0]
-        else:
-            loss = sum(values, x.new_zeros([], dtype=torch.float32))
-        return z_ste, loss, memo
+            return values[0]
+        return sum(values, like.new_zeros([], dtype=torch.float32))
+
+    def _one_call_step(self, x: torch.Tensor):
+        """The training forwards that ONE library call enqueues (train_step.py): a VQGAN-style quantizer whose only callback
+        is a CVQVAECallback in its sparse-anchor flow, or a VQ-KD quantizer (VQKDCallback + CommitmentLoss with norm=True:
+        configs/vqkd/model.py:20-26).  None: the step runs hook by hook as below."""
+        if not (self.one_call_steps and self.training and self._fused and x.dim() == 2):
+            return None
+        cbs = self._callbacks.callbacks
+        if len(cbs) != 1 or type(self)._encode is not VectorQuantizer._encode or type(self)._decode is not VectorQuantizer._decode \
+                or type(self)._loss is not BaseQuantizer._loss or type(self).encode is not BaseQuantizer.encode:
+            return None
+        from .callbacks import CVQVAECallback, VQKDCallback
+        cb = cbs[0]
+        if type(cb) is CVQVAECallback:
+            return self._forward_cvq if (self._fusable() and cb.fused_forward_ok(x)) else None
+        if type(cb) is VQKDCallback:
+            losses = list(self._losses.values())
+            ok = (len(losses) == 1 and type(losses[0]) is CommitmentLoss and losses[0]._mse.norm
+                  and losses[0]._mse._weight._value == 1.0 and losses[0]._weight._value == 1.0)
+            return self._forward_vqkd if (ok and cb.fused_forward_ok(x)) else None
+        return None
+
+    def _forward_cvq(self, x: torch.Tensor, memo: Memo):
+        cb = self._callbacks.callbacks[0]
+        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
+        quant, z_ste, m_cb, m_cm, m_vqgan = cb.fused_forward(x, memo, betas[0] if betas else 0.0)
+        memo.update(x=x, quant=quant)
+        memo['decode'] = get_memo(memo, 'decode')
+        return z_ste, self._loss_values(memo, m_cb, m_cm, m_vqgan, betas, x), memo
+
+    def _forward_vqkd(self, x: torch.Tensor, memo: Memo):
+        cb = self._callbacks.callbacks[0]
+        xn, quant, z_ste, value = cb.fused_forward(x, memo)
+        memo.update(x=xn, quant=quant)
+        memo['decode'] = get_memo(memo, 'decode')
+        loss_memo = get_memo(memo, 'loss')
+        loss_memo.update({next(iter(self._losses.keys())): value})
+        memo['loss'] = loss_memo
+        return z_ste, value, memo
+
+    def forward(self, x: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, torch.Tensor, Memo]:
+        """quantizers.py:110-117 (BaseQuantizer.forward, then ste(z, memo['x'])).  When nothing customises
+        decode/loss the gather, the STE expression and the MSE sums are one kernel with one fused backward; the two
+        callback-driven training configs (CVQ-VAE, VQ-KD) are one library call for the whole forward."""
+        step = self._one_call_step(x)
+        if step is not None:
+            return step(x, memo)
+        if not self._fusable() or x.dim() != 2:
+            z, loss, memo = super().forward(x, memo)
+            z = VF.ste(z, memo['x'])
+            return z, loss, memo
+        x, quant, memo = self.encode(x, memo)
+        memo.update(x=x, quant=quant)
+        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
+        z_ste, m_cb, m_cm, m_vqgan = VF.fused_decode_loss(x, self._embedding.weight, quant, betas[0] if betas else 0.0)
+        memo['decode'] = get_memo(memo, 'decode')
+        return z_ste, self._loss_values(memo, m_cb, m_cm, m_vqgan, betas, x), memo
 
 
     # ---- the same three entry points on the NCHW feature map (SURVEY.md §8f row 3; models/base.py:116-146) --------------------
@@ -230,19 +280,7 @@ class VectorQuantizer(BaseQuantizer):
         betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
         z_map, m_cb, m_cm, m_vqgan = VF.fused_map_decode_loss(x_map, x_rows, self._embedding.weight, quant, betas[0] if betas else 0.0)
         memo['decode'] = get_memo(memo, 'decode')
-        losses = {}
-        for name, loss in self._losses.items():
-            if isinstance(loss, VQGANLoss):
-                losses[name] = m_vqgan if loss.beta == betas[0] else torch.add(m_cb, m_cm, alpha=loss.beta)
-            elif isinstance(loss, CodebookLoss):
-                losses[name] = m_cb
-            else:
-                losses[name] = m_cm
-        loss_memo = get_memo(memo, 'loss')
-        loss_memo.update(losses)
-        memo['loss'] = loss_memo
-        values = list(losses.values())
-        loss = values[0] if len(values) == 1 else sum(values, x_map.new_zeros([], dtype=torch.float32))
+        loss = self._loss_values(memo, m_cb, m_cm, m_vqgan, betas, x_map)
         return z_map, loss, memo
 
     def decode_map(self, quant: torch.Tensor, memo: Memo) -> tuple[torch.Tensor, Memo]:

@@ -12,16 +12,21 @@ this library's own, created once per process group —
 stays capturable into a HIP graph (the collective is one more node of the captured stream).
 
 Two communicators on one device (torch's and this one) must never have collectives in flight in different orders on
-different ranks.  They do not: the packed exchange runs inside the quantizer's forward, in program order on every rank, and
-nothing of torch's is in flight there (DDP's gradient buckets of the previous step were waited for by the optimizer step).
+different ranks.  Under DDP they do not: the packed exchange runs inside the quantizer's forward, in program order on every
+rank, and nothing of torch's is in flight there (DDP's gradient buckets of the previous step were waited for by the optimizer
+step; tests/test_gpu_two_ranks.py wraps the quantizer in DistributedDataParallel, tests/rccl_ws1_child.py does so on the nccl
+backend with both communicators alive in one process).  Under FSDP they can: its forward-prefetched all-gathers run on torch's
+communicator on a side stream while this one would run on the compute stream — the documented multi-communicator hazard.
 
 What a captured call costs (measured at world size 1, profiles/r04_rccl_ws1.json): a HIP graph that contains the RCCL call
 replays ~21 us slower than the same graph without it — a non-kernel node — whichever stream it was captured on.
 
-``VQHIP_ALLREDUCE`` selects the route: ``direct`` (this module; an error if it cannot be set up), ``torch``
-(``dist.all_reduce``), or ``auto`` (default): direct when the process group's backend is RCCL ("nccl") and the set-up —
-agreed across the ranks, with a probe all-reduce checked on every rank — succeeds, ``dist.all_reduce`` otherwise.  gloo
-groups (CPU tests, the shared-GPU plumbing runs) always take ``dist.all_reduce``."""
+``VQHIP_ALLREDUCE`` selects the route: ``direct`` (this module; an error if it cannot be set up) or ``torch``
+(``dist.all_reduce``, the reference's own route).  ``auto`` (the default) resolves to ``torch``: the direct route has
+executed at world size 1 only (one-GPU builder boxes; RCCL refuses two ranks on one device), its bootstrap catches failures
+but cannot catch a rank that hangs inside ``ncclCommInitRank``, and FSDP is unsafe next to it (above) — it stays opt-in until
+a run with two or more ranks on the nccl backend has been recorded.  gloo groups (CPU tests, the shared-GPU plumbing runs)
+always take ``dist.all_reduce``."""
 from __future__ import annotations
 
 import ctypes
@@ -109,7 +114,7 @@ def _bootstrap(device: torch.device) -> int:
 def communicator(t: torch.Tensor) -> Optional[int]:
     """The ncclComm_t for ``t``'s exchange, or None when ``dist.all_reduce`` is to be used (see the module docstring)."""
     m = mode()
-    if m == 'torch' or not (dist.is_available() and dist.is_initialized()):
+    if m != 'direct' or not (dist.is_available() and dist.is_initialized()):      # 'auto' resolves to 'torch' (module docstring)
         return None
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         return None
