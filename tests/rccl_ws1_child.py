@@ -125,6 +125,68 @@ def main():
                 rec[f'{kind}_{route}_graphed_bit_identical'] = None
                 rec[f'{kind}_{route}_graphed_error'] = f'{type(exc).__name__}: {exc}'[:500]
                 torch.cuda.synchronize()
+    # ---- the quantizer inside DDP / FSDP on the nccl backend (configs/strategies/ddp.py:5-6, fsdp.py:5-8): torch's communicator
+    # and the library's own alive in ONE process, the packed exchange on the compute stream between DDP's bucket all-reduces
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from toy_model import build_toy, train_steps
+    C, B, HW = 8, 6, 8
+    w32 = torch.from_numpy(synth.unit_rows(gen.standard_normal((1024, 32), dtype=np.float32)))
+    # two optimizer steps: the second sees the first one's codebook update and SGD step.  (More steps compare a chaotic system:
+    # the convolutions' weight gradients use float atomics, a 1e-8 difference in a latent flips a NearestAnchor near-tie a few
+    # steps later, and the re-anchored code moves by O(1) — the bare model differs from ITSELF that way, tools/debug/ddp_graphed.py)
+    images = [torch.from_numpy(gen.standard_normal((B, C, HW, HW), dtype=np.float32)).to(dev) for _ in range(2)]
+
+    def params_of(model):
+        return {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    for route in ('direct', 'torch'):
+        os.environ['VQHIP_ALLREDUCE'] = route
+        for kind in ('cvq', 'vqkd'):
+            bare = build_toy(kind, 1024, 32, w32, dev)
+            r_bare = train_steps(bare, images, autocast=True)
+            wrapped = build_toy(kind, 1024, 32, w32, dev)
+            ddp = DDP(wrapped, device_ids=[local], find_unused_parameters=True)
+            r_ddp = train_steps(ddp, images, autocast=True)
+            # (identical up to the arrival order of the float atomics in the convolutions' weight gradients)
+            ok = all(torch.equal(a[1], b[1]) and abs(float(a[0]) - float(b[0])) <= 1e-6 for a, b in zip(r_bare, r_ddp))
+            pa, pb = params_of(bare), params_of(wrapped)
+            rec[f'ddp_{kind}_{route}_bit_identical'] = bool(ok and all(float((pa[n] - pb[n]).abs().max()) <= 1e-6 for n in pa))
+        rec[f'ddp_status_{route}'] = rccl.status()
+    # the graphed quantizer inside the DDP-wrapped model (forward + backward replayed, the collective inside the capture)
+    os.environ['VQHIP_ALLREDUCE'] = 'direct'
+    try:
+        bare = build_toy('cvq', 1024, 32, w32, dev)
+        r_bare = train_steps(bare, images)
+        wrapped = build_toy('cvq', 1024, 32, w32, dev)
+        sample = torch.zeros(B * HW * HW, 32, device=dev)
+        gq = GraphedQuantizer(wrapped._quantizer, sample)
+        wrapped.quant_call = gq
+        ddp = DDP(wrapped, device_ids=[local], find_unused_parameters=True)
+        r_ddp = train_steps(ddp, images)
+        rec['ddp_graphed_tokens_identical'] = all(torch.equal(a[1].reshape(-1), b[1].reshape(-1)) for a, b in zip(r_bare, r_ddp))
+        pa, pb = params_of(bare), params_of(wrapped)
+        rec['ddp_graphed_max_param_diff'] = max(float((pa[n] - pb[n]).abs().max()) for n in pa)
+        rec['ddp_graphed_error'] = None
+    except Exception as exc:        # noqa: BLE001
+        rec['ddp_graphed_error'] = f'{type(exc).__name__}: {exc}'[:500]
+        torch.cuda.synchronize()
+    # FSDP (use_orig_params=True, as configs/strategies/fsdp.py:5-8): construction + one optimizer step; the codebook update
+    # must survive FSDP's next unshard (the callbacks write FSDP-managed parameters in place)
+    try:
+        from torch.distributed.fsdp import FullyShardedDataParallel as FSDP
+        os.environ['VQHIP_ALLREDUCE'] = 'torch'
+        bare = build_toy('cvq', 1024, 32, w32, dev)
+        r_bare = train_steps(bare, images)
+        inner = build_toy('cvq', 1024, 32, w32, dev)
+        fs = FSDP(inner, use_orig_params=True, device_id=dev)
+        r_fs = train_steps(fs, images)
+        rec['fsdp_tokens_identical'] = all(torch.equal(a[1].reshape(-1), b[1].reshape(-1)) for a, b in zip(r_bare, r_fs))
+        rec['fsdp_loss_diff'] = max(abs(float(a[0]) - float(b[0])) for a, b in zip(r_bare, r_fs))
+        rec['fsdp_error'] = None
+    except Exception as exc:        # noqa: BLE001
+        rec['fsdp_error'] = f'{type(exc).__name__}: {exc}'[:500]
+        torch.cuda.synchronize()
     with open(args.out, 'w') as fh:
         json.dump(rec, fh, indent=1)
     print(json.dumps(rec))

@@ -58,3 +58,25 @@ def test_graph_replay_with_the_collective_captured(ws1, kind):
     # the direct route puts the collective on the captured stream itself; the torch route is reported alongside
     assert ws1[f'{kind}_direct_graphed_error'] is None, ws1[f'{kind}_direct_graphed_error']
     assert ws1[f'{kind}_direct_graphed_bit_identical'] is True
+
+
+@pytest.mark.parametrize('kind', ['cvq', 'vqkd'])
+@pytest.mark.parametrize('route', ['torch', 'direct'])
+def test_quantizer_inside_ddp_on_the_nccl_backend(ws1, kind, route):
+    """DistributedDataParallel on the nccl backend with the exchange forced: torch's communicator (DDP's bucket all-reduces)
+    and — on the direct route — the library's own alive in one process, under bf16 autocast; bit-identical to the bare module."""
+    assert ws1[f'ddp_{kind}_{route}_bit_identical'] is True
+    if route == 'direct':
+        assert ws1['ddp_status_direct']['direct'] is True
+
+
+def test_graphed_quantizer_inside_ddp(ws1):
+    assert ws1['ddp_graphed_error'] is None, ws1['ddp_graphed_error']
+    assert ws1['ddp_graphed_tokens_identical'] is True and ws1['ddp_graphed_max_param_diff'] <= 1e-6
+
+
+def test_fsdp_use_orig_params_smoke(ws1):
+    """FullyShardedDataParallel(use_orig_params=True) around the toy model: construction and two optimizer steps, the second
+    of which only sees the first one's codebook update if it landed in FSDP's flat parameter."""
+    assert ws1['fsdp_error'] is None, ws1['fsdp_error']
+    assert ws1['fsdp_tokens_identical'] is True and ws1['fsdp_loss_diff'] <= 1e-5

@@ -185,11 +185,20 @@ class UpdateMixin(BuildPreHookMixin, BaseCallback):
     def with_ema(self) -> bool:
         return hasattr(self, '_ema')
 
+    def _writes_in_place(self, weight: torch.Tensor) -> bool:
+        """True when the codebook update must land in the parameter's existing storage: graph replay (``inplace_updates``),
+        or a parameter that FSDP manages (``use_orig_params=True``, configs/strategies/fsdp.py:5-8: the parameter is a view
+        into FSDP's flat parameter, and a rebound ``.data`` would be dropped at the next unshard — measured: the CVQ-VAE update
+        of every step was lost, tools/debug/fsdp_diff.py)."""
+        # (inside an FSDP forward the module attribute is not even the Parameter but a temporary view of the flat parameter —
+        #  a non-leaf tensor: rebinding ITS .data, as callbacks/update.py:56 does, changes nothing that outlives the forward)
+        return bool(self.quantizer.inplace_updates or getattr(weight, '_fsdp_flattened', False) or not weight.is_leaf or weight._is_view())
+
     def _update_embedding(self, e: torch.Tensor) -> None:
         if Store.DRY_RUN:
             assert is_sync(e)
         weight = self.vector_quantizer.embedding.weight
-        if self.quantizer.inplace_updates:                   # same values into the existing storage (graph replay)
+        if self._writes_in_place(weight):                    # same values into the existing storage (graph replay, FSDP)
             weight.data.copy_(e)
         else:
             weight.data = e                                  # rebinds the storage, like callbacks/update.py:56
@@ -296,7 +305,7 @@ class VQKDCallback(LazyInitWeightsMixin, NormalizeCallback):
         K, D = weight.shape
         if getattr(self, '_step_state', None) is None:
             self._step_state = train_step.VqkdStepState()
-        inplace = q.inplace_updates
+        inplace = self._writes_in_place(weight)
         w_in = weight.detach()
         w_mid = w_in if inplace else torch.empty_like(w_in)
         w_out = w_in if inplace else torch.empty_like(w_in)
@@ -520,8 +529,9 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
                 list_ready, cap = True, -1          # the library reads the count the previous step's prefetch copied out
             prefetch = True
         inplace = q.inplace_updates
+        w_inplace = self._writes_in_place(weight)
         w_in = weight.detach()
-        w_out = w_in if inplace else torch.empty_like(w_in)
+        w_out = w_in if w_inplace else torch.empty_like(w_in)
         p_out = p_in if inplace else torch.empty_like(p_in)
         exch = exchanging()
         comm = None
@@ -539,14 +549,13 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         self._listed = None                                      # (the hook-by-hook flow's prefetched list is void now)
         if Store.DRY_RUN:
             assert is_sync(w_out)
-        if inplace:
-            q.invalidate_codebook()
-            p_new = p_in
-        else:
+        p_new = p_in
+        if not inplace:
             self._update_probability(p_out)
-            weight.data = w_out                                  # callbacks/update.py:56
-            q.invalidate_codebook()
             p_new = p_out
+        if not w_inplace:
+            weight.data = w_out                                  # callbacks/update.py:56
+        q.invalidate_codebook()
         if prefetch:
             st.mark_list(p_new)                                  # rows / slot / count now describe p_new (the call's last but one launch)
         enc = get_memo(memo, 'encode')
