@@ -218,3 +218,59 @@ def test_forced_exchange_takes_the_two_phase_route(monkeypatch):
     assert len(calls) == len(xs) and calls[0] == 2 * K + 4 + K * 32
     assert_same(base_k, forced_k, exact_w=False)
     del train_step
+
+
+def test_graphed_cvq_capacity_buckets_follow_the_list():
+    """graphs.GraphedQuantizer captures the CVQ-VAE step at several capacities of the listed-code launches and chains the
+    replays through the pinned count word: every step runs the smallest captured capacity that holds its list, and the
+    results stay those of the eager module, through a change of bucket and through probabilities replaced from outside."""
+    from vector_quantization_amd.graphs import GraphedQuantizer
+    N, K, D = 3000, 2048, 64
+    w0 = synth.unit_rows(synth.rng(5).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 8, 36)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) / (N * D)
+
+    def steps(call, q, xs_):
+        out = []
+        for x in xs_:
+            xin = x.clone().requires_grad_(True)
+            q.zero_grad(set_to_none=True)
+            z, loss, quant = call(xin)
+            torch.autograd.backward([loss, z], [None, gz])
+            out.append((quant.clone(), z.detach().clone(), float(loss), q.embedding.weight.detach().clone(),
+                        q.get_buffer('_probability').clone()))
+        return out
+
+    q1 = build(cvq_cfg(K, D, 'Cosine'), w0)
+    counts = []
+
+    def eager(xin):
+        z, loss, memo = q1(xin, {})
+        counts.append(q1._callbacks.callbacks[0].last_exchange_rows)
+        return z, loss, memo['quant']
+
+    ref = steps(eager, q1, xs[:6])
+    with torch.no_grad():                                         # probabilities replaced from outside, then two more steps
+        q1.get_buffer('_probability').mul_(0.25)
+    ref += steps(eager, q1, xs[6:])
+    assert counts[0] == K and min(counts) < K
+    caps = tuple(sorted({min(counts), sorted(counts)[len(counts) // 2]} - {K}))
+    q2 = build(cvq_cfg(K, D, 'Cosine'), w0)
+    gq = GraphedQuantizer(q2, xs[0], bucket_caps=caps)
+    used = []
+
+    def graphed(xin):
+        out = gq(xin)
+        used.append(gq.last_capacity)
+        return out
+
+    got = steps(graphed, q2, xs[:6])
+    with torch.no_grad():
+        q2.get_buffer('_probability').mul_(0.25)
+    got += steps(graphed, q2, xs[6:])
+    all_caps = list(caps) + [K]
+    assert used == [min(c for c in all_caps if c >= n) for n in counts], (used, counts, caps)
+    assert len(set(used)) >= 2, used
+    for (qa, za, la, wa, pa), (qb, zb, lb, wb, pb) in zip(ref, got):
+        assert torch.equal(qa, qb) and torch.equal(za, zb) and torch.equal(wa, wb) and torch.equal(pa, pb)
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))

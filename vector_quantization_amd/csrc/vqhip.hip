@@ -1158,11 +1158,11 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
         if (int rc = vqhip_cvq_apply(a->w_in, a->w_out, a->p_in, a->p_out, a->hist, N, a->x, a->x_dtype, col_idx, a->exchange ? a->packed : nullptr,
                                      a->world, a->slot, K, D, a->ema_decay, a->eps, stream)) return rc;
         if (a->prefetch) {
-            if (int rc = vqhip_cvq_rows(a->p_out, K, a->ema_decay, a->eps, a->rows, a->slot, a->count, stream)) return rc;
-            if (a->count_host) {
-                VQ_HIP(hipMemcpyAsync(a->count_host, a->count, 4, hipMemcpyDeviceToHost, s));
-                if (a->count_event) VQ_HIP(hipEventRecord((hipEvent_t)a->count_event, s));
-            }
+            // the list of the NEXT step; its length also goes straight to the caller's pinned host word (a store of the kernel
+            // itself — pinned host memory is device-visible at its own address — instead of a 4-byte copy launch behind it)
+            cvq_rows_kernel<<<1, 1024, 0, s>>>(a->p_out, K, a->ema_decay, a->eps, a->rows, a->slot, a->count, a->count_host);
+            VQ_CHECK_LAUNCH("cvq_rows_kernel");
+            if (a->count_host && a->count_event) VQ_HIP(hipEventRecord((hipEvent_t)a->count_event, s));
         }
         if (a->mse)
             if (int rc = vqhip_gather_ste_mse(a->x, a->x_dtype, a->w_out, a->idx, N, D, nullptr, a->z_ste, a->mse, a->beta, a->scratch16, stream)) return rc;
@@ -1251,8 +1251,8 @@ int vqhip_vqkd_forward(vqhip_vqkd_forward_t *a, void *stream) {
         vqkd_update_packed_kernel<<<waves_grid(K, 4), 256, 0, s>>>(a->w_mid, a->w_out, a->packed, K, D, a->ema_decay);
         VQ_CHECK_LAUNCH("vqkd_update_packed_kernel");
         if (a->tail) {
-            int grid = (int)((N + 3) / 4); grid = grid > 1024 ? 1024 : grid;
-            vqkd_tail_kernel<<<grid, 256, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse);
+            int grid = (int)((N + 15) / 16); grid = grid > 256 ? 256 : grid;
+            vqkd_tail_kernel<<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse);
             VQ_CHECK_LAUNCH("vqkd_tail_kernel");
         }
     }

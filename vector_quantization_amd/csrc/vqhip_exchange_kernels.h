@@ -69,9 +69,11 @@ __device__ __forceinline__ bool cvq_may_need_anchor(float p_old, int64_t K, floa
 // One 1024-thread workgroup; thread t owns the consecutive codes [t*per, (t+1)*per), per = ceil(K / 1024): flags in a
 // register, a wave scan of the per-thread counts, a 16-entry scan of the wave totals — two barriers in all (3 us at
 // K = 16 384; a round-per-1024-codes form with three barriers per round took 14).
+// count_host (nullable): a pinned HOST word that receives the count as well (system-scope store; the host reads it behind an
+// event recorded after this launch).
 __global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict__ p, int64_t K, float ema_decay, float eps,
                                                         int32_t *__restrict__ rows, int32_t *__restrict__ slot,
-                                                        int32_t *__restrict__ count) {
+                                                        int32_t *__restrict__ count, int32_t *count_host = nullptr) {
     __shared__ int wtot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t per = (K + 1023) / 1024;
@@ -121,7 +123,10 @@ __global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict_
             }
             *(int4 *)(slot + k0 + i) = make_int4(sv[0], sv[1], sv[2], sv[3]);
         }
-        if (threadIdx.x == 0) count[0] = total;
+        if (threadIdx.x == 0) {
+            count[0] = total;
+            if (count_host != nullptr) __hip_atomic_store(count_host, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     for (int64_t k = k0; k < k0 + per && k < K; ++k) {
@@ -129,7 +134,10 @@ __global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict_
         if (f) { rows[pos] = (int32_t)k; slot[k] = pos; ++pos; }
         else slot[k] = -1;
     }
-    if (threadIdx.x == 0) count[0] = total;
+    if (threadIdx.x == 0) {
+        count[0] = total;
+        if (count_host != nullptr) __hip_atomic_store(count_host, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // out[i] = e[rows[i]] for i < count, zeros up to cap (the role-swapped pipeline reads whole 32-row blocks)

@@ -96,7 +96,9 @@ struct VqWsLayout {
 // the D <= 32 group path: the stream kernel files one identification request per (token, slice, lane half) under the code
 // tile of the lane's best group; identify32_kernel serves them bucket by bucket.  Up to VQ_GROUP_MAX_SLICES slices and
 // VQ_GROUP_MAX_TILES code tiles (K <= 131 072): beyond, the per-element kernels are used.
+#ifndef VQ_GROUP_MAX_SLICES
 #define VQ_GROUP_MAX_SLICES 2
+#endif
 #define VQ_GROUP_MAX_TILES 4096
 // A group's requests are spread over R buckets (by the token block that files them; R = the largest power of two <= 128 with
 // groups * R <= VQ_GROUP_MAX_BUCKETS): 100 352 returning atomics on the 256 counters of BASELINE configs[2] — eight cache

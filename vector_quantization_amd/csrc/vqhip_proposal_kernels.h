@@ -62,9 +62,12 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 //
 // GROUPS (with FILTER; D <= 32, where the per-element update of the tiles that fail the skip test was the larger half of
 // the VALU work): see "group record" in the loop and "group records -> code records" after it.
+#ifndef VQ_D32_PLAIN_OCC
+#define VQ_D32_PLAIN_OCC 4      // waves per SIMD the D <= 32 filtered forms WITHOUT group records are compiled for (A/B: 2)
+#endif
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false,
           bool GROUPS = false>
-__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? 4 : WAVES / 4) void coarse_kernel(
+__global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : VQ_D32_PLAIN_OCC) : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
     const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {

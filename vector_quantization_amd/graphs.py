@@ -18,6 +18,12 @@ What capture needs from the step, and how the quantizer provides it:
     ``inplace_updates`` its codebook operand is the live storage, i.e. a consumer that materialises the matrix AFTER the
     update callback sees the updated codebook (the reference clones: quantizers.py:97) — no shipped config does.
 Collectives: captured as issued; RCCL ("nccl") supports capture, gloo does not — use the graph at world size 1 or on RCCL.
+
+CVQ-VAE (the sparse-anchor flow): a captured step cannot size its listed-code launches from a count the host reads, so the
+train-mode step is captured at SEVERAL capacities (256, 4096 and K listed codes) and chained: every replay ends by writing the
+next step's list and, to a pinned host word, its length; before the next replay the host waits for the event it recorded
+behind the previous one, reads the length and picks the smallest captured capacity that fits (round 4 captured K only: at
+65 536 tokens per rank the replayed step was slower than the eager one, 1.08 against 0.79 ms, profiles/r04_cvq256.json).
 """
 from __future__ import annotations
 
@@ -53,7 +59,7 @@ class GraphedQuantizer(nn.Module):
     codebook is exactly what it was before the constructor ran.  (A VQ-KD quantizer's lazy k-means init, which needs host
     logic, must already have happened: call the quantizer once eagerly first.)"""
 
-    def __init__(self, quantizer: nn.Module, sample_x: torch.Tensor, warmup: int = 3) -> None:
+    def __init__(self, quantizer: nn.Module, sample_x: torch.Tensor, warmup: int = 3, bucket_caps=(256, 4096)) -> None:
         super().__init__()
         if not sample_x.is_cuda:
             raise ValueError('GraphedQuantizer needs a device tensor (no CPU path)')
@@ -75,9 +81,25 @@ class GraphedQuantizer(nn.Module):
         saved = {k: v.detach().clone() for k, v in quantizer.state_dict().items()}
         step = self._step = _Step(quantizer)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._caps, self._calls, self._steps = [], [], []
+        self._cvq = self._chained_cvq_callback(quantizer, sample_x) if self._train else None
         from . import ops
         with ops.owned_mse_scratch(self._mse_scratch):
-            if self._train:
+            if self._cvq is not None:
+                K = quantizer.codebook_size
+                self._caps = [c for c in bucket_caps if c < K] + [K]
+                try:
+                    for cap in self._caps:
+                        self._cvq.capture_plan = dict(cap=cap, chained=True)
+                        st = _Step(quantizer)
+                        sample = sample_x.detach().clone().requires_grad_(True)
+                        self._calls.append(torch.cuda.make_graphed_callables(st, (sample,), num_warmup_iters=warmup, allow_unused_input=True))
+                        self._steps.append(st)
+                finally:
+                    self._cvq.capture_plan = None
+                self._event = torch.cuda.Event()
+                self._list_version = None            # the chained list is (re)built before the first replay
+            elif self._train:
                 sample = sample_x.detach().clone().requires_grad_(True)
                 # (allow_unused_input: a VQ-KD step gives the codebook no gradient — the commitment term and the straight-through
                 #  output both detach z, configs/vqkd/model.py:76-82 freezes the quantizer anyway — and the one-call forward's
@@ -99,9 +121,39 @@ class GraphedQuantizer(nn.Module):
             for k, v in quantizer.state_dict().items():
                 v.copy_(saved[k])
 
+    @staticmethod
+    def _chained_cvq_callback(quantizer: nn.Module, sample_x: torch.Tensor):
+        """The CVQVAECallback of a quantizer whose train step is the one-call CVQ-VAE forward (capacity buckets), else None."""
+        step = getattr(quantizer, '_one_call_step', None)
+        if step is None or sample_x.dim() != 2:
+            return None
+        bound = step(sample_x)
+        if bound is None or getattr(bound, '__name__', '') != '_forward_cvq':
+            return None
+        return quantizer._callbacks.callbacks[0]
+
+    def _replay_chained(self, x: torch.Tensor):
+        cb = self._cvq
+        p = cb.probability
+        st = cb._step_state
+        if st is None or self._list_version != (p._version, p.data_ptr()):
+            cb.refresh_list()                                     # first replay, or probabilities changed from outside
+            st = cb._step_state
+            self._list_version = (p._version, p.data_ptr())
+        else:
+            self._event.synchronize()                             # recorded behind the previous replay's forward
+        count = int(st.count_host[0])
+        which = next(i for i, cap in enumerate(self._caps) if cap >= count)
+        self.last_capacity = self._caps[which]
+        z, loss = self._calls[which](x)
+        self._event.record()
+        return z, loss, self._steps[which].last_quant
+
     def forward(self, x: torch.Tensor):
         if tuple(x.shape) != self._shape or x.dtype != self._dtype:
             raise ValueError(f'graph captured for {self._shape} {self._dtype}, got {tuple(x.shape)} {x.dtype}')
+        if self._cvq is not None:
+            return self._replay_chained(x)
         if self._train:
             z, loss = self._call(x)
             return z, loss, self._step.last_quant

@@ -367,7 +367,12 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         self._listed = None               # (p tensor, its _version, rows, slot, count, pinned host count, copy event)
         self._pinned_count = None
         self._step_state = None           # train_step.CvqStepState of the one-call forward (lazily, on the codebook's device)
-        self.capture_cap = None           # capacity of the listed-code launches under HIP-graph capture (None = K; graphs.py)
+        # How a HIP-graph capture of the one-call forward sizes and chains itself (graphs.GraphedQuantizer sets it around its
+        # captures; None = launches sized for K, the list rebuilt inside the graph): dict(cap=<capacity of the listed-code
+        # launches>, chained=True: the graph trusts rows / slot / count to describe the probabilities it starts from — every
+        # replay ends by writing the NEXT step's list there and its length to the pinned host word — so the host can pick, per
+        # step, the smallest captured capacity that fits)
+        self.capture_plan = None
         self.last_exchange_rows = None    # M of the last training step (diagnostics: bench.py, tests)
 
     @classmethod
@@ -519,7 +524,9 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
             self._step_state = train_step.CvqStepState(K, p_in.device)
         st = self._step_state
         if capturing:                     # the launches are sized for a fixed capacity, the device-side count decides
-            list_ready, cap, prefetch = False, (K if self.capture_cap is None else int(self.capture_cap)), False
+            plan = self.capture_plan or {}
+            list_ready = prefetch = bool(plan.get('chained', False))
+            cap = int(plan.get('cap', K))
         else:
             if not st.list_valid_for(p_in):
                 self.refresh_list()       # first step / probabilities replaced from outside: counted on the spot

@@ -115,9 +115,11 @@ def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: 
     a.cap = int(cap)
     a.x, a.w_in, a.p_in, a.w_out, a.p_out = x.data_ptr(), w_in.data_ptr(), p_in.data_ptr(), w_out.data_ptr(), p_out.data_ptr()
     a.rows, a.slot, a.count = state.rows.data_ptr(), state.slot.data_ptr(), state.count.data_ptr()
-    use_host_word = not capturing and (prefetch or cap < 0)
+    # the pinned count word: written by the prefetch (a store of the list kernel itself, capturable), read by the call when cap < 0;
+    # the event around it belongs to eager steps only (a captured step's replay is followed by the caller's own event)
+    use_host_word = prefetch or cap < 0
     a.count_host = state.count_host.data_ptr() if use_host_word else None
-    a.count_event = (state.event_handle or None) if use_host_word else None
+    a.count_event = (state.event_handle or None) if (use_host_word and not capturing) else None
     a.comm = comm
     a.cb, a.cb_bytes = image.data_ptr(), image.numel()
     a.idx, a.hist, a.xq = idx.data_ptr(), hist.data_ptr(), _p(xq)
@@ -140,7 +142,7 @@ def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: 
         all_reduce(packed[:a.exchange_floats])
         a.phases = STEP_AFTER_EXCHANGE
         check(L.vqhip_cvq_forward(ctypes.byref(a), stream), 'vqhip_cvq_forward')
-    if use_host_word and prefetch and not state.event_handle:
+    if use_host_word and prefetch and not capturing and not state.event_handle:
         state.event.record()
     return dict(idx=idx, hist=hist, xq=xq, prepared=ops.PreparedCodebook(image, w_in, K, D, m), z_ste=z_ste, mse=mse,
                 cap_used=int(a.cap_used), exchange_floats=int(a.exchange_floats), x=x)
