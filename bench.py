@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — quantized tokens/s of the VQ codebook-lookup hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--workload vqgan|cvq|tokenize]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--images B] [--workload vqgan|cvq|vqkd|tokenize]
 
 `--gpus N` with N > 1 from a bare invocation (no WORLD_SIZE in the environment) starts the N ranks itself: the parent —
 which makes NO GPU call — checks that N devices exist, runs `python -m torch.distributed.run --nproc-per-node N bench.py
@@ -22,6 +22,10 @@ Workloads (BASELINE.json configs; each "step" is one pass of the hot path over o
            per-rank batch 12 images = 3072 tokens (configs/vqgan/interface.py:8 over 8 ranks); forward (encode, sparse
            anchor list, column argmin over the listed codes, ONE packed all-reduce of histogram ‖ token count ‖ anchors,
            EMA update, decode, loss) + backward from a given upstream gradient.  Weak scaling.
+  vqkd     (configs[2] as a TRAINING step) VQ-KD: VQKDQuantizer + VQKDCallback(ema) + CommitmentLoss(norm=True), cosine,
+           K=8192 D=32, per-rank batch 64 images = 12 544 tokens (configs/vqkd/interface.py:8: 512 images over 8 ranks, 14x14
+           tokens each; configs/vqkd/model.py:20-26); forward (normalise, encode, histogram + centroid sums, ONE packed
+           all-reduce, EMA update, decode, normalised commitment loss — one library call) + backward.  Weak scaling.
   tokenize (configs[4]) LlamaGen bulk tokenization: 2048 images per step IN TOTAL, sharded over the ranks
            (`encode` only, D=8 + NormalizeCallback + L2: configs/llamagen/vqgan.py:10-20).  Strong scaling, no collective.
 
@@ -66,9 +70,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--images', type=int, default=None,
-                    help='images per GPU per step (256 tokens each); default 2048 (vqgan), 12 (cvq); '
+                    help='images per GPU per step (256 tokens each; vqkd: 196); default 2048 (vqgan), 12 (cvq), 64 (vqkd); '
                          'tokenize: images per step over ALL ranks, default 2048')
-    ap.add_argument('--workload', choices=('vqgan', 'cvq', 'tokenize'), default='vqgan')
+    ap.add_argument('--workload', choices=('vqgan', 'cvq', 'vqkd', 'tokenize'), default='vqgan')
     ap.add_argument('--min-seconds', type=float, default=8.0,
                     help='repeat the K-step block until this much timed GPU work has accumulated (0: one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -284,12 +288,42 @@ def _median_block(blocks):
     return s[(len(s) - 1) // 2]             # an actual block (lower median), not an interpolation
 
 
-def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, graphs: bool = True, settle: int = 150):
-    """The CVQ-VAE training step at `tokens` per rank (module + callbacks, forward + backward from a given upstream
-    gradient), eager and replayed from HIP graphs; exchange accounting; codebook-in-sync check."""
+def train_cfg(kind):
+    """(K, D, quantizer config, callback config list) of the two callback-driven training workloads."""
+    if kind == 'vqkd':         # configs/vqkd/model.py:20-26
+        cb_cfg = [dict(type='VQKDCallback', ema=dict())]
+        K, D = 8192, 32
+        cfg = dict(type='VQKDQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D), distance=dict(type='CosineDistance'),
+                   losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True))), callbacks=cb_cfg)
+        return K, D, cfg
+    cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
+    return K_CODES, DIM, quantizer_cfg(K_CODES, DIM, 'Cosine', cb_cfg)
+
+
+def build_train_module(kind, cfg, dev, w):
+    import torch
+
+    from vector_quantization_amd import Config, build_quantizer
+    q = build_quantizer(cfg)
+    q.train(True)
+    q.init_weights(Config(type='vqgan') if kind == 'cvq' else Config())
+    q = q.to(dev)
+    q._forward_pre_hooks.clear()          # VQ-KD: the k-means lazy init is not part of a steady-state step
+    with torch.no_grad():
+        q.embedding.weight.copy_(w)
+    if kind == 'vqkd':                    # configs/vqkd/model.py:76-82: no_grad on the quantizer's parameters
+        for p_ in q.parameters():
+            p_.requires_grad_(False)
+    return q
+
+
+def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, graphs: bool = True, settle: int = 150, kind: str = 'cvq'):
+    """The CVQ-VAE (or, kind='vqkd', the VQ-KD) training step at `tokens` per rank (module + callbacks, forward + backward
+    from a given upstream gradient), eager and replayed from HIP graphs; exchange accounting; codebook-in-sync check."""
     torch, dist = B.torch, B.dist
     from vector_quantization_amd.utils import exchange_log
-    K, D, dev = K_CODES, DIM, B.dev
+    K, D, cfg = train_cfg(kind)
+    dev = B.dev
     w = torch.nn.functional.normalize(torch.randn(K, D, device=dev, generator=torch.Generator(device=dev).manual_seed(3407)))
     g = torch.Generator(device=dev).manual_seed(3407 + B.rank)
     # codebook identical on all ranks, latents per rank.  A pool of up to 128 batches drawn around the rows of the initial
@@ -302,9 +336,8 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     x = pool[0]
     gz = torch.randn(tokens, D, device=dev, generator=g) / (tokens * D)          # what the decoder's backward would hand back
     turn = [0]
-    cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
-    q = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
-    q_params = list(q.parameters())
+    q = build_train_module(kind, cfg, dev, w)
+    q_params = [p_ for p_ in q.parameters() if p_.requires_grad]
     cvq_cb = q._callbacks.callbacks[0]
 
     def make_step(module_call, params):
@@ -326,12 +359,13 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     for i in range(settle):
         step()
         if i == 0:
-            rows_first = cvq_cb.last_exchange_rows
+            rows_first = getattr(cvq_cb, 'last_exchange_rows', None)
     blocks, out, prof = B.timed_blocks(step, steps, warmup, min_seconds)
     el = _median_block(blocks)
     rec = {'tokens_per_rank': tokens, 'ms_per_step': el / steps * 1e3, 'tokens_per_s': tokens * B.world * steps / el,
            'blocks': len(blocks), 'ms_per_step_min': min(blocks) / steps * 1e3, 'ms_per_step_max': max(blocks) / steps * 1e3,
-           'settle_steps': settle, 'exchange_rows_first_step': rows_first, 'exchange_rows': cvq_cb.last_exchange_rows}
+           'settle_steps': settle, 'exchange_rows_first_step': rows_first, 'exchange_rows': getattr(cvq_cb, 'last_exchange_rows', None),
+           'one_call_forward': bool(q._one_call_step(x) is not None)}
     # exchange accounting on a few extra steps (events around the collective: not part of the timed blocks)
     exchange_log.start(timing=B.distributed and not B.share_gpu)
     n_acc = 10
@@ -354,7 +388,7 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     # graphs contain the collective
     if graphs and (not B.distributed or B.backend == 'nccl'):
         from vector_quantization_amd.graphs import GraphedQuantizer
-        qg = build_module(quantizer_cfg(K, D, 'Cosine', cb_cfg), dev, w, train=True)
+        qg = build_train_module(kind, cfg, dev, w)
         qg.load_state_dict(q.state_dict())
         err = None
         try:
@@ -362,13 +396,14 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
         except Exception as exc:                          # reported, never silently dropped
             gq, err = None, f'{type(exc).__name__}: {exc}'
         if B.all_ranks(gq is not None):
-            gstep = make_step(lambda xin: gq(xin), list(qg.parameters()))
+            gstep = make_step(lambda xin: gq(xin), [p_ for p_ in qg.parameters() if p_.requires_grad])
             gblocks, _, _ = B.timed_blocks(gstep, steps, 3, min_seconds)
             ge = _median_block(gblocks)
             rec['ms_per_step_graphed'] = ge / steps * 1e3
             rec['tokens_per_s_graphed'] = tokens * B.world * steps / ge
             rec['graphed_note'] = ('GraphedQuantizer: forward (with the in-place codebook update and the packed all-reduce) and '
-                                   'backward replayed from HIP graphs; launches sized for K listed codes, the device-side count decides')
+                                   'backward replayed from HIP graphs; CVQ-VAE: captured at 256 / 4096 / K listed codes, chained through '
+                                   'the pinned count word (the replay waits for the previous forward: the eager one-call step is the faster one)')
         else:
             rec['graphed_error'] = err or 'graph capture failed on another rank'
     wsum = q.embedding.weight.detach().double().sum().reshape(1).to(B.coll_dev)
@@ -494,15 +529,15 @@ def main():
         if world > 1 and not args.no_cvq:
             # the communicating workload of the path, so that a scaling run is interpretable
             extra['cvq'] = {}
-            # HIP-graph replay of a step that CONTAINS an RCCL collective has never been executed for this repo (one-GPU
-            # builder boxes): a capture that goes wrong can hang a process group, which would cost the whole scaling run.
-            # The eager step — which no longer waits for the host anywhere — is timed by default; VQ_BENCH_CVQ_GRAPHS=1 adds
-            # the graphed one.
+            # The eager step is ONE library call per forward (vqhip_cvq_forward) and GPU-bound at both sizes; it is what is
+            # timed by default.  VQ_BENCH_CVQ_GRAPHS=1 adds the graph-replayed step: capture and replay of a step that contains
+            # the collective have executed at world size 1 on RCCL, both routes (tests/test_gpu_rccl.py), never with more ranks
+            # (one-GPU builder boxes) — a capture that goes wrong there would cost the whole scaling run.
             cvq_graphs = os.environ.get('VQ_BENCH_CVQ_GRAPHS') == '1'
             for toks in (12 * TOK_PER_IMAGE, 256 * TOK_PER_IMAGE):
                 rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), graphs=cvq_graphs, settle=120)
                 if not cvq_graphs:
-                    rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph capture of an RCCL collective is untested here)' 
+                    rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph replay of an RCCL collective has run at world size 1 only)'
                 extra['cvq'][str(toks)] = rec
         tokens_per_step_global = N * world
         scaling = 'weak'
@@ -510,6 +545,23 @@ def main():
                     'drop-in nn.Module, eval mode (prepare+argmin+gather+STE+loss)')
         parallelism = f'dp{world} (independent shards, no data-path collective)'
         metric = 'quantized tokens/sec, VQGAN quantizer forward K=16384 D=256'
+    elif wl == 'vqkd':
+        images = args.images or 64
+        K, D, _ = train_cfg('vqkd')
+        N = images * 196
+        rec, prof = run_cvq(B, N, args.steps, args.warmup, args.min_seconds,
+                            graphs=(world == 1 or os.environ.get('VQ_BENCH_CVQ_GRAPHS') == '1'), kind='vqkd')
+        blocks = [rec['ms_per_step'] * args.steps / 1e3]
+        extra['vqkd'] = rec
+        loss, used_codes = rec['loss'], rec['used_codes']
+        tokens_per_step_global = N * world
+        scaling = 'weak'
+        workload = ('VQ-KD training step K=8192 D=32 cosine, VQKDQuantizer + VQKDCallback(ema) + CommitmentLoss(norm=True), 64 images x '
+                    '14x14 tokens per rank: forward (normalise, encode, histogram + centroid sums, ONE packed all-reduce, EMA update, '
+                    'decode, loss: one library call) + backward from a given upstream gradient')
+        parallelism = (f'dp{world} (rows sharded, codebook replicated; one fp32 all-reduce of 2K+4+K*D floats per step over '
+                       f'{B.backend or "no backend"})')
+        metric = 'quantized tokens/sec, VQ-KD quantizer training step K=8192 D=32'
     elif wl == 'cvq':
         images = args.images or 12
         N, K, D = images * TOK_PER_IMAGE, K_CODES, DIM
@@ -580,13 +632,28 @@ def main():
                                       'with this very libvqhip.so, gfx950-corrected; NOT measured in this run): ' + str(rec.get('source')))
             except Exception:
                 traffic = None
+        # the proposal kernel's OWN algorithmic bytes (what `traffic` is to be compared with): the fp16 token image read once,
+        # the fp16 codebook image once, the records written (5 floats per token and codebook slice; two slices at this size)
+        dp = 32
+        while dp < D:
+            dp *= 2
+        dp = D if D > 512 else dp
+        rec_slices = 2
+        kernel_alg_bytes = N * dp * 2 + K * dp * 2 + rec_slices * 5 * 4 * N
+        step_ms = elapsed / args.steps * 1e3
+        step_tf = flops / (step_ms * 1e-3) / 1e12
         roofline = {'bound': 'mfma', 'kernel': 'coarse_kernel (fp16 MFMA distance+argmin proposals)',
                     'achieved': achieved_tf, 'peak': MFMA_F16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved_tf / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': traffic,
                     'traffic_source': traffic_source,
+                    'kernel_algorithmic_bytes': kernel_alg_bytes,
+                    'traffic_over_kernel_algorithmic': (traffic / kernel_alg_bytes) if traffic else None,
                     'kernel_ms': kern_ms, 'launches_timed': prof[1], 'launches_per_step': launches_per_step,
+                    'step_frac': step_tf / MFMA_F16_DENSE_PEAK_TFLOPS,
+                    'step_frac_note': 'the same flops over the WHOLE step (ms_per_step: what `value` is), against the same peak',
+                    'step_algorithmic_bytes': alg_bytes,
                     'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
-        if wl == 'cvq':
+        if wl in ('cvq', 'vqkd'):
             roofline['kernel_ms_note'] = ('average over the proposal launches of a step: the row pass (N x K) and, when codes are listed, '
                                           'the role-swapped column pass (listed codes x N) — `achieved` prices the row pass only')
         per_step = sorted(b / args.steps * 1e3 for b in blocks)

@@ -233,8 +233,8 @@ int vqhip_unpack_counts(const float *packed, int64_t K, int64_t *out, void *stre
  * HIP graph with the rest of the step.  libvqhip does not link RCCL: the symbols are resolved at run time from the
  * librccl.so the process already has (PyTorch-ROCm ships one; two RCCL copies in one process must be avoided) or from
  * `path`.  These four are HOST-side set-up calls and the only entry points that block or allocate (inside RCCL):
- *   vqhip_rccl_load(path)            path NULL or "": the librccl.so already mapped into the process, else the loader's
- *                                    default librccl.so; idempotent.
+ *   vqhip_rccl_load(path)            path NULL or "": the librccl.so already mapped into the process (never a fresh copy from the
+ *                                    loader's search path: VQHIP_ERCCL if none is mapped under that name); idempotent.
  *   vqhip_rccl_unique_id(id)         HOST buffer of VQHIP_RCCL_ID_BYTES; called on ONE rank, the bytes are handed to the
  *                                    others by whatever the application has (torch.distributed's store here).
  *   vqhip_rccl_comm_init(&comm, nranks, id, rank)   collective over the ranks; binds the CURRENT HIP device.
@@ -302,7 +302,7 @@ int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p
  *   rows / slot / count: K, K, 1 int32, caller-owned and persistent across steps.  cap_used / exchange_floats: written by the
  *   BEFORE phase (host fields).  ws: vqhip_cvq_forward_ws_bytes(N, K, D, cap_max) with cap_max >= cap; packed: at least
  *   vqhip_pack_floats(K, cap, D) floats (exchange != 0).  xq: cosine only (as vqhip_encode).  z_ste / mse nullable together
- *   (no decode tail).  w_out / p_out may alias w_in / p_in.
+ *   (no decode tail).  w_out / p_out may alias w_in / p_in.  early_word_host / early_seq_dev: see the struct.
  *
  * vqhip_vqkd_forward — VQKDQuantizer + VQKDCallback in train mode (vq/algorithms/vq/callbacks/normalize.py:22-29,
  *   vq/algorithms/vqkd/quantizers/callbacks.py:44-75,114-129, vq/algorithms/vq/losses.py:53-62 with mse norm=True):
@@ -338,6 +338,12 @@ typedef struct vqhip_cvq_forward_t {
     float *z_ste, *mse; void *scratch16;
     void *ws; int64_t ws_bytes;
     int64_t cap_used, exchange_floats;      /* OUT (host), written by the BEFORE phase */
+    /* early count (nullable pair): as soon as this step's histogram is final (behind the encode at one rank, behind the exchange
+     * otherwise) one small launch writes {sequence number << 32 | length of the NEXT step's list} to the pinned HOST word
+     * early_word_host and advances the DEVICE counter early_seq_dev by one — for a caller that replays this call from a HIP graph
+     * and must choose the next replay's capacity without an event in the middle of the graph (it polls the word) */
+    unsigned long long *early_word_host;
+    int32_t *early_seq_dev;
 } vqhip_cvq_forward_t;
 int64_t vqhip_cvq_forward_ws_bytes(int64_t N, int64_t K, int D, int64_t cap_max);
 int vqhip_cvq_forward(vqhip_cvq_forward_t *args, void *stream);

@@ -341,6 +341,14 @@ def two_rank_reference():
         return [dict(np.load(os.path.join(d, f'rank{r}.npz'))) for r in range(2)]
 
 
+def eight_rank_reference():
+    """The reference's callbacks at the world size its shipped configs train at (8 ranks: configs/strategies, batch_size_in_total)."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rank_worker, args=(8, 29741, d), nprocs=8, join=True)
+        return [dict(np.load(os.path.join(d, f'rank{r}.npz'))) for r in range(8)]
+
+
 def update_cases():
     x, w = update_inputs()
     xt, wt = torch.from_numpy(x), torch.from_numpy(w)
@@ -387,6 +395,20 @@ def update_cases():
                                  two_rank='two gloo processes running the reference callbacks on rows r::2; '
                                           '"avg" = NearestAnchor(sync=False) (anchors.py:64-67), '
                                           '"sync" = NearestAnchor(sync=True) (anchors.py:50-57)')))
+    # --- the same at eight ranks (rows r::8): codebooks, probabilities, per-rank tokens and column argmins ---
+    r8 = eight_rank_reference()
+    for k in r8[0]:
+        if k.endswith('w_new') or k.endswith('_p') or k == 'lazy_w':
+            assert all(r8[0][k].tobytes() == r[k].tobytes() for r in r8[1:]), f'reference ranks disagree on {k} at world size 8'
+    rec8 = {k: r8[0][k] for k in r8[0] if k.endswith('w_new') or k.endswith('_p') or k == 'lazy_w'}
+    rec8['vqkd_quant'] = np.stack([r['vqkd_quant'] for r in r8]).astype(np.int32)
+    for tag in ('cvq_l2_avg', 'cvq_cosine_avg', 'cvq_l2_sync', 'cvq_cosine_sync'):
+        rec8[f'{tag}_quant'] = np.stack([r[f'{tag}_quant'] for r in r8]).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, 'update_8rank.npz'), x_sha=synth.sha(x), w_sha=synth.sha(w), **rec8,
+                        spec=json.dumps(dict(UPD, world=8, source='reference-import', reference=CITE_VQKD + CITE_CVQ,
+                                             eight_rank='eight gloo processes running the reference callbacks on rows r::8 '
+                                                        '(VQ-KD step; CVQ-VAE step with NearestAnchor sync False / True, L2 and cosine; '
+                                                        'k-means lazy init from 256 rows per rank, K = 64)')))
     np.savez_compressed(os.path.join(OUT, 'lazy_init_2rank.npz'), w=ranks[0]['lazy_w'],
                         spec=json.dumps(dict(K=64, D=UPD['D'], N_per_rank=256, seed=1234, source='reference-import',
                                              reference=['vq/algorithms/vqkd/quantizers/callbacks.py:26-35,77-112'])))

@@ -32,7 +32,8 @@ class CvqForwardArgs(ctypes.Structure):
                 ('packed', _vp), ('packed_floats', _i64),
                 ('z_ste', _vp), ('mse', _vp), ('scratch16', _vp),
                 ('ws', _vp), ('ws_bytes', _i64),
-                ('cap_used', _i64), ('exchange_floats', _i64)]
+                ('cap_used', _i64), ('exchange_floats', _i64),
+                ('early_word_host', _vp), ('early_seq_dev', _vp)]
 
 
 class VqkdForwardArgs(ctypes.Structure):

@@ -171,9 +171,6 @@ static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages
 #define VQ_D32_SMALL_TT 2      // token tiles per wave / waves per workgroup of the D <= 32 kernels below 262 144 tokens
 #define VQ_D32_SMALL_W 8
 #endif
-#ifndef VQ_GROUPS_MIN_N
-#define VQ_GROUPS_MIN_N 16384
-#endif
 #ifndef VQ_MIN_SLICES_FILTER
 #define VQ_MIN_SLICES_FILTER 1
 #endif
@@ -251,7 +248,7 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
         // D <= 16 always; 16 < D <= 32 (two instructions per tile) only without aux reads — measured (tools/ab_w32.py,
         // profiles/r03_w32_ab.txt): D = 32 cosine +2.5..5 %, D = 32 L2 -4..-14 % (the form is LDS-bound once the four 16-byte aux
         // reads per lane and tile come on top of 2 KiB of fragments)
-        case 2: if ((L.D <= 16 || (L.D <= VQ_W32_MAX_D && noaux)) && N >= VQ_GROUPS_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load() &&
+        case 2: if ((L.D <= 16 || (L.D <= VQ_W32_MAX_D && noaux)) && N >= VQ_W32_MIN_N && g_tune_w32.load() && g_tune_filter.load() && g_tune_groups.load() &&
                     grp.bcnt != nullptr && grun != nullptr) {
                     // one 32x32x16 instruction covers the whole inner dimension: a quarter of the MFMA issue, group update per
                     // 16 scores.  Wide token tiles of 32 tokens: 1 (below 262 144 tokens) or 2 per wave.
@@ -1130,6 +1127,10 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
                                      enc_bytes, VQHIP_ENCODE_ZERO_HIST, stream)) return rc;
         if (!a->list_ready)
             if (int rc = vqhip_cvq_rows(a->p_in, K, a->ema_decay, a->eps, a->rows, a->slot, a->count, stream)) return rc;
+        if (!a->exchange && a->early_word_host && a->early_seq_dev) {     // one rank: the histogram is final behind the encode
+            cvq_count_next_kernel<false><<<1, 1024, 0, s>>>(a->p_in, a->hist, N, nullptr, K, a->ema_decay, a->eps, a->early_seq_dev, a->early_word_host);
+            VQ_CHECK_LAUNCH("cvq_count_next_kernel");
+        }
         int64_t cap = a->cap;
         if (cap < 0) {                   // the count the previous call's prefetch copied out: queued a whole step ago
             if (!a->count_host) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap < 0 needs count_host");
@@ -1155,6 +1156,10 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
         if (int rc = vqhip_allreduce_packed(a->packed, a->exchange_floats, a->comm, stream)) return rc;
     if (a->phases & VQHIP_STEP_AFTER_EXCHANGE) {
         if (a->cap_used < 0 || a->cap_used > K) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap_used (the BEFORE phase writes it)");
+        if (a->exchange && a->early_word_host && a->early_seq_dev) {      // the next list's length, right behind the reduced histogram
+            cvq_count_next_kernel<true><<<1, 1024, 0, s>>>(a->p_in, nullptr, 0, a->packed, K, a->ema_decay, a->eps, a->early_seq_dev, a->early_word_host);
+            VQ_CHECK_LAUNCH("cvq_count_next_kernel");
+        }
         if (int rc = vqhip_cvq_apply(a->w_in, a->w_out, a->p_in, a->p_out, a->hist, N, a->x, a->x_dtype, col_idx, a->exchange ? a->packed : nullptr,
                                      a->world, a->slot, K, D, a->ema_decay, a->eps, stream)) return rc;
         if (a->prefetch) {
@@ -1491,14 +1496,16 @@ int vqhip_rccl_load(const char *path) {
     void *h = nullptr;
     if (path && path[0]) {
         h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return fail(VQHIP_ERCCL, "vqhip_rccl_load: librccl.so not loadable", dlerror());
     } else {
+        // without a path: ONLY the copy the process already has (RTLD_NOLOAD).  Falling back to the loader's search path could map
+        // a second RCCL (say /opt/rocm's next to PyTorch's) into the process — two copies must never coexist; a caller whose
+        // copy was loaded under another name passes its path
         const char *names[] = {"librccl.so", "librccl.so.1"};
         for (const char *n : names)
-            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already has
-        for (const char *n : names)
-            if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (!h) return fail(VQHIP_ERCCL, "vqhip_rccl_load: no librccl.so is mapped into this process under that name; pass the path of the copy the application uses");
     }
-    if (!h) return fail(VQHIP_ERCCL, "vqhip_rccl_load: librccl.so not loadable", dlerror());
     RcclApi api;
     api.handle = h;
     api.get_unique_id = (decltype(api.get_unique_id))dlsym(h, "ncclGetUniqueId");

@@ -140,6 +140,41 @@ __global__ __launch_bounds__(1024) void cvq_rows_kernel(const float *__restrict_
     }
 }
 
+// The LENGTH of the next step's list as soon as this step's histogram is final — long before cvq_rows_kernel can build the list
+// itself from the updated probabilities (that needs the column pass and the update first).  p' is the update's own expression
+// (cvq_apply_kernel: bit-identical), the test is the list's own.  One workgroup.  The count goes to a pinned HOST word together
+// with a sequence number the kernel advances on the device ({seq, count} as ONE 64-bit system-scope store): a host that replays
+// this step from a HIP graph — where no event can be recorded in the middle — polls the word for the sequence number it expects
+// and picks the next replay's capacity while the rest of this one is still running (graphs.GraphedQuantizer).
+template <bool PACKED>
+__global__ __launch_bounds__(1024) void cvq_count_next_kernel(const float *__restrict__ p_in, const int32_t *__restrict__ hist,
+                                                              int64_t numel, const float *__restrict__ packed, int64_t K,
+                                                              float ema_decay, float eps, int32_t *seq_dev,
+                                                              unsigned long long *word_host) {
+    __shared__ int wtot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float fn = PACKED ? (float)unpack_numel(packed, K) : (float)numel;
+    int mine = 0;
+    for (int64_t k = threadIdx.x; k < K; k += 1024) {
+        const float freq = (PACKED ? (float)unpack_count(packed, K, k) : (float)hist[k]) / fn;
+        const float pk = p_in[k] * ema_decay + freq * (1.0f - ema_decay);
+        mine += cvq_may_need_anchor(pk, K, ema_decay, eps) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if (lane == 0) wtot[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) total += wtot[i];
+        const int seq = seq_dev[0] + 1;
+        seq_dev[0] = seq;
+        __hip_atomic_store(word_host, ((unsigned long long)(uint32_t)seq << 32) | (unsigned long long)(uint32_t)total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // out[i] = e[rows[i]] for i < count, zeros up to cap (the role-swapped pipeline reads whole 32-row blocks)
 __global__ void gather_listed_rows_kernel(const float *__restrict__ e, const int32_t *__restrict__ rows,
                                           const int32_t *__restrict__ count, int64_t cap, int D, float *__restrict__ out) {

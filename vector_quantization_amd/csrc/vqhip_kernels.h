@@ -196,6 +196,17 @@ __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r 
 
 // The statistics header as the margin consumes it: header words + the maxima of the VQ_CB_SLOTS slots cb_image_kernel raised
 // (lanes 0..15 load one slot each, a 16-lane shuffle tree folds them).  Wave-level: every lane of the wave must call it.
+// `folded` of a published header: a checksum of the four words it vouches for (never 0).  A reader that caught the header in the
+// middle of a publication by ANOTHER wave — of the same launch, or of a launch on another stream that shares a frozen codebook
+// image — sees a flag that does not match the words it loaded, and folds the partials itself as if nothing had been published:
+// no acquire fence (an L1 / K-cache invalidate in front of every consumer wave's first instruction) is needed for that.
+__device__ __forceinline__ uint32_t cb_folded_mark(uint32_t r2, uint32_t eh2, uint32_t e2, uint32_t nonfinite) {
+    uint32_t h = r2 * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + eh2 * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + e2 * 0xC2B2AE3Du;
+    h = (h ^ (h >> 16)) + nonfinite * 0x27D4EB2Fu;
+    return h | 0x80000000u;
+}
 __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
     VqCbStats v = *st;
     const int lane = threadIdx.x & 63;
@@ -206,7 +217,8 @@ __device__ __forceinline__ VqCbStats cb_stats_view(const VqCbStats *st) {
         const uint32_t r2 = __shfl_xor(r, off, 64), h2 = __shfl_xor(h, off, 64), b2 = __shfl_xor(bad, off, 64);
         r = r > r2 ? r : r2; h = h > h2 ? h : h2; bad |= b2;
     }
-    if (v.folded != 0u) return v;   // cosine, already folded into the header by an earlier launch (cb_stats_publish)
+    // cosine, already folded into the header by an earlier launch (cb_stats_publish) — and seen whole (see cb_folded_mark)
+    if (v.folded != 0u && v.folded == cb_folded_mark(v.r2max_bits, v.eh2max_bits, v.e2max_bits, v.nonfinite)) return v;
     if (v.part2_n != 0u) {      // cosine image made in one launch: per-tile partials instead of the slots (wave-uniform)
         const f32x4 *part = (const f32x4 *)((const char *)st + v.part2_off);
         float pr = 0.0f, ph = 0.0f, pb = 0.0f, pe = 0.0f;
@@ -248,10 +260,10 @@ __device__ __forceinline__ void cb_stats_publish(const VqCbStats *st) {
         VqCbStats *w = const_cast<VqCbStats *>(st);
         w->r2max_bits = v.r2max_bits; w->eh2max_bits = v.eh2max_bits; w->e2max_bits = v.e2max_bits; w->nonfinite = v.nonfinite;
         // the four words have reached L2 before the flag is stored (no agent-scope release: its L2 write-back put 3-4 us on this
-        // workgroup, i.e. on the kernel; launches that follow see everything anyway, a concurrent launch on another stream sees
-        // the flag only behind the words)
+        // workgroup, i.e. on the kernel).  Launches that follow on the stream see everything; a reader that overlaps this
+        // publication validates the flag against the words it loaded (cb_folded_mark) and otherwise folds for itself
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        w->folded = 1u;
+        w->folded = cb_folded_mark(v.r2max_bits, v.eh2max_bits, v.e2max_bits, v.nonfinite);
     }
 }
 

@@ -96,8 +96,10 @@ struct VqWsLayout {
 // the D <= 32 group path: the stream kernel files one identification request per (token, slice, lane half) under the code
 // tile of the lane's best group; identify32_kernel serves them bucket by bucket.  Up to VQ_GROUP_MAX_SLICES slices and
 // VQ_GROUP_MAX_TILES code tiles (K <= 131 072): beyond, the per-element kernels are used.
+// (four slices since round 5: 16 384 rows x 16 384 codes x 8 dims -12 %, nothing lost from 32 768 rows on, where fewer are picked
+//  anyway: profiles/r05_ab_small_d.txt)
 #ifndef VQ_GROUP_MAX_SLICES
-#define VQ_GROUP_MAX_SLICES 2
+#define VQ_GROUP_MAX_SLICES 4
 #endif
 #define VQ_GROUP_MAX_TILES 4096
 // A group's requests are spread over R buckets (by the token block that files them; R = the largest power of two <= 128 with
@@ -107,6 +109,16 @@ struct VqWsLayout {
 #define VQ_GROUP_CNT_STRIDE 32         // ints between two bucket counters (128 bytes)
 #ifndef VQ_GROUP_TILES
 #define VQ_GROUP_TILES 4               // code tiles per group record of coarse32_kernel (a divisor of VQ_TPS_D32; 1, 2, 4, 8 measured: profiles/r04_group_tiles.txt)
+#endif
+#ifndef VQ_GROUPS_MIN_N
+#define VQ_GROUPS_MIN_N 16384          // group records on the 16x16x32 form (in-kernel replay) from this many rows on
+#endif
+// ... and on the 32x32x16 form (coarse32_kernel + identify32_kernel, the request lists of this workspace) from this many: measured
+// against the per-element form it replaces below 16 384 rows (profiles/r05_ab_small_d.txt, one-call encodes): 8192 x 8192 x 32
+// cosine 0.066 -> 0.061 ms, 12 544 x 8192 x 32 (the VQ-KD per-rank batch) 0.077 -> 0.065, 8192 x 16384 x 8 0.077 -> 0.069; at 4096
+// rows the per-element form — compiled for two waves per SIMD there, which ended its register spills — stays ahead
+#ifndef VQ_W32_MIN_N
+#define VQ_W32_MIN_N 8192
 #endif
 VQ_HD int vq_group_replicas(int64_t ngroups) { int r = 128; while (r > 1 && ngroups * r > VQ_GROUP_MAX_BUCKETS) r >>= 1; return r; }
 VQ_HD bool vq_group_path_possible(int64_t K, int D) {
@@ -134,8 +146,15 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     W.off_en = W.off_keys + Mp * 8;          // K floats: oracle |e_k|^2 for the fp32-only entry points
     W.off_xn = W.off_en + (K + 63) / 64 * 64 * 4;   // oracle-order |x_n|^2 of every row (x_prep_kernel)
     W.off_arrive = W.off_xn + Np * 4;          // arrival counters of the proposal kernel's token blocks (>= 128 tokens each)
-    const bool grp = vq_group_path_possible(K, D);
-    W.nbkt = grp ? (int64_t)VQ_GROUP_MAX_BUCKETS * VQ_GROUP_CNT_STRIDE : 0;      // one counter per bucket, each on a 128-byte line of its own
+    // the request lists exist only where the proposal pass can take the group path: enough rows (launch_coarse), and then one
+    // counter per bucket the codebook really has — not 4096 x 128 bytes zeroed by every call's first launch whatever the shape
+    const bool grp = vq_group_path_possible(K, D) && N >= VQ_W32_MIN_N;
+    int64_t nbuckets = 0;
+    if (grp) {
+        const int64_t ngroups = ((K + (int64_t)VQ_TPS_D32 * VQ_TILE_CODES - 1) / ((int64_t)VQ_TPS_D32 * VQ_TILE_CODES)) * VQ_TPS_D32 / VQ_GROUP_TILES;
+        nbuckets = ngroups * vq_group_replicas(ngroups);
+    }
+    W.nbkt = nbuckets * VQ_GROUP_CNT_STRIDE;                                    // one counter per bucket, each on a 128-byte line of its own
     W.off_bcnt = (W.off_arrive + (Np / 128 + 8) * 4 + 127) / 128 * 128;
     W.narrive = (W.off_bcnt - W.off_arrive) / 4 + W.nbkt;
     // second-best value inside an identified group, per (slice, lane half, token): the consumer folds it into the bound v3
@@ -144,7 +163,7 @@ VQ_HD VqWsLayout vq_ws_layout(int64_t N, int64_t K, int D) {
     // an entry is the token word and, in a second array, the token's B fragment as the requesting lanes hold it (32 bytes
     // per 16 dims: identify32_kernel reads a batch's 32 fragments as 1-2 KiB of contiguous bytes instead of gathering 64
     // scattered 16-byte pieces from the token image — 35 -> 9 us at 524 288 requests)
-    W.blist_entries = grp ? 4 * Np + 64 * (int64_t)VQ_GROUP_MAX_BUCKETS : 0;
+    W.blist_entries = grp ? 4 * Np + 64 * nbuckets : 0;
     W.off_blist = W.off_rece2 + (grp ? (int64_t)VQ_GROUP_MAX_SLICES * 2 * Np * 4 : 0);
     W.off_bfrag = (W.off_blist + W.blist_entries * 4 + 255) / 256 * 256;
     const int64_t frag_bytes = W.blist_entries * (D <= 16 ? 32 : 64);

@@ -62,8 +62,13 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 //
 // GROUPS (with FILTER; D <= 32, where the per-element update of the tiles that fail the skip test was the larger half of
 // the VALU work): see "group record" in the loop and "group records -> code records" after it.
+// Waves per SIMD the D <= 32 filtered forms WITHOUT group records are compiled for — the forms small batches take (below
+// VQ_W32_MIN_N / VQ_GROUPS_MIN_N rows).  Four (128 registers) left them with 57-83 spilled registers and scratch traffic in the
+// stream loop; two (256 registers) compile without a spill, and at these sizes there are at most two workgroups per CU to
+// co-schedule anyway: 4096 x 8192 x 32 cosine 0.0705 -> 0.0538 ms per encode, 4096 x 16384 x 8 0.0768 -> 0.0592
+// (profiles/r05_ab_small_d.txt; 12 544 rows: level).
 #ifndef VQ_D32_PLAIN_OCC
-#define VQ_D32_PLAIN_OCC 4      // waves per SIMD the D <= 32 filtered forms WITHOUT group records are compiled for (A/B: 2)
+#define VQ_D32_PLAIN_OCC 2
 #endif
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false,
           bool GROUPS = false>

@@ -21,8 +21,10 @@ Collectives: captured as issued; RCCL ("nccl") supports capture, gloo does not â
 
 CVQ-VAE (the sparse-anchor flow): a captured step cannot size its listed-code launches from a count the host reads, so the
 train-mode step is captured at SEVERAL capacities (256, 4096 and K listed codes) and chained: every replay ends by writing the
-next step's list and, to a pinned host word, its length; before the next replay the host waits for the event it recorded
-behind the previous one, reads the length and picks the smallest captured capacity that fits (round 4 captured K only: at
+next step's list, and publishes that list's LENGTH â€” with a sequence number, to a pinned host word â€” as soon as the step's
+histogram is final (one small launch behind the encode / the exchange: the probabilities' update needs nothing else); before the
+next replay the host polls the word for the number it expects and picks the smallest captured capacity that fits, while the
+GPU is still busy with the rest of the previous replay (round 4 captured K only: at
 65 536 tokens per rank the replayed step was slower than the eager one, 1.08 against 0.79 ms, profiles/r04_cvq256.json).
 """
 from __future__ import annotations
@@ -97,8 +99,8 @@ class GraphedQuantizer(nn.Module):
                         self._steps.append(st)
                 finally:
                     self._cvq.capture_plan = None
-                self._event = torch.cuda.Event()
                 self._list_version = None            # the chained list is (re)built before the first replay
+                self._seq = None                     # sequence number the last launched replay will publish (set at the first one)
             elif self._train:
                 sample = sample_x.detach().clone().requires_grad_(True)
                 # (allow_unused_input: a VQ-KD step gives the codebook no gradient â€” the commitment term and the straight-through
@@ -136,17 +138,26 @@ class GraphedQuantizer(nn.Module):
         cb = self._cvq
         p = cb.probability
         st = cb._step_state
-        if st is None or self._list_version != (p._version, p.data_ptr()):
-            cb.refresh_list()                                     # first replay, or probabilities changed from outside
+        if st is None or self._seq is None or self._list_version != (p._version, p.data_ptr()):
+            cb.refresh_list()                                     # first replay, or probabilities changed from outside (synchronises)
             st = cb._step_state
             self._list_version = (p._version, p.data_ptr())
+            self._seq = int(st.seq_dev.item())
+            count = int(st.count_host[0])
         else:
-            self._event.synchronize()                             # recorded behind the previous replay's forward
-        count = int(st.count_host[0])
+            # the previous replay publishes {its sequence number, the length of THIS step's list} as soon as its histogram is final:
+            # usually long since there â€” the rest of that replay (column pass, update, decode, backward) is what the GPU is running now
+            word, spins = int(st.early_host[0]), 0
+            while (word >> 32) != self._seq:
+                spins += 1
+                if spins > 50_000_000:
+                    raise RuntimeError('GraphedQuantizer: the previous replay never published its list length')
+                word = int(st.early_host[0])
+            count = word & 0xFFFFFFFF
         which = next(i for i, cap in enumerate(self._caps) if cap >= count)
         self.last_capacity = self._caps[which]
         z, loss = self._calls[which](x)
-        self._event.record()
+        self._seq += 1                                            # every replay advances the device counter by one
         return z, loss, self._steps[which].last_quant
 
     def forward(self, x: torch.Tensor):

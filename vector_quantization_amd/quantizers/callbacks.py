@@ -370,8 +370,8 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         # How a HIP-graph capture of the one-call forward sizes and chains itself (graphs.GraphedQuantizer sets it around its
         # captures; None = launches sized for K, the list rebuilt inside the graph): dict(cap=<capacity of the listed-code
         # launches>, chained=True: the graph trusts rows / slot / count to describe the probabilities it starts from — every
-        # replay ends by writing the NEXT step's list there and its length to the pinned host word — so the host can pick, per
-        # step, the smallest captured capacity that fits)
+        # replay ends by writing the NEXT step's list there, and publishes its length to a pinned host word as soon as the step's
+        # histogram is final — so the host can pick, per step, the smallest captured capacity that fits)
         self.capture_plan = None
         self.last_exchange_rows = None    # M of the last training step (diagnostics: bench.py, tests)
 
@@ -525,7 +525,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         st = self._step_state
         if capturing:                     # the launches are sized for a fixed capacity, the device-side count decides
             plan = self.capture_plan or {}
-            list_ready = prefetch = bool(plan.get('chained', False))
+            list_ready = prefetch = early = bool(plan.get('chained', False))
             cap = int(plan.get('cap', K))
         else:
             if not st.list_valid_for(p_in):
@@ -534,7 +534,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
                 list_ready, cap = True, int(st.count_host[0])
             else:
                 list_ready, cap = True, -1          # the library reads the count the previous step's prefetch copied out
-            prefetch = True
+            prefetch, early = True, False
         inplace = q.inplace_updates
         w_inplace = self._writes_in_place(weight)
         w_in = weight.detach()
@@ -551,7 +551,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         e_alias = weight.view_as(weight) if (torch.is_grad_enabled() and weight.requires_grad) else w_in
         out = train_step.cvq_forward(xd, w_in, p_in, w_out, p_out, metric, self._ema.decay, self._eps, beta, st, cap=cap,
                                      list_ready=list_ready, prefetch=prefetch, exchange=exch, world=get_world_size(), comm=comm,
-                                     all_reduce=all_reduce_sum if exch else None, tail=True)
+                                     all_reduce=all_reduce_sum if exch else None, tail=True, early_count=early)
         self.last_exchange_rows = out['cap_used']
         self._listed = None                                      # (the hook-by-hook flow's prefetched list is void now)
         if Store.DRY_RUN:

@@ -124,7 +124,13 @@ def communicator(t: torch.Tensor) -> Optional[int]:
         return None
     group = dist.distributed_c10d._get_default_group()
     if _state['group'] is not group:                          # first exchange of this process group (never inside a capture:
-        _state.update(group=group, comm=None, error=None)     # a captured step has run eagerly at least once before)
+        if _state['comm'] is not None:                        # a captured step has run eagerly at least once before)
+            try:                                              # the process group was re-created without shutdown(): the old
+                torch.cuda.synchronize()                      # communicator is destroyed, not leaked
+                _lib.lib().vqhip_rccl_comm_destroy(_state['comm'])
+            except Exception:                                 # noqa: BLE001
+                pass
+        _state.update(group=group, comm=None, error=None)
         try:
             _state['comm'] = _bootstrap(t.device)
         except Exception as exc:                              # noqa: BLE001 — reported through `status()`, or raised in direct mode

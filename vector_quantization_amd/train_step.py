@@ -65,6 +65,9 @@ class CvqStepState:
         with torch.cuda.device(device):
             self.event.record()                                   # created now: the library records / waits on its handle
         self.event_handle = int(getattr(self.event, 'cuda_event', 0) or 0)
+        # early count (include/vqhip.h, vqhip_cvq_forward_t.early_word_host): {sequence number << 32 | count}, and the device counter
+        self.early_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.seq_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.list_of = None
         self.arena = _Arena()
 
@@ -82,7 +85,7 @@ class CvqStepState:
 @_on_tensor_device
 def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: torch.Tensor, p_out: torch.Tensor, metric,
                 ema_decay: float, eps: float, beta: float, state: CvqStepState, *, cap: int, list_ready: bool, prefetch: bool,
-                exchange: bool, world: int, comm: Optional[int], all_reduce=None, tail: bool = True):
+                exchange: bool, world: int, comm: Optional[int], all_reduce=None, tail: bool = True, early_count: bool = False):
     """The CVQ-VAE training forward as one library call (two around a caller-issued collective when ``comm`` is None and the
     exchange has more than one rank: ``all_reduce(packed_view)`` is then called between the halves).
 
@@ -128,6 +131,8 @@ def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: 
     a.scratch16 = _mse_scratch(dev).data_ptr() if tail else None
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.cap_used, a.exchange_floats = -1, 0
+    a.early_word_host = state.early_host.data_ptr() if early_count else None
+    a.early_seq_dev = state.seq_dev.data_ptr() if early_count else None
     stream = _stream()
     if cap < 0 and not state.event_handle:           # no raw handle on this torch build: the wait happens here instead
         state.event.synchronize()
