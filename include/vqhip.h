@@ -396,6 +396,17 @@ int vqhip_vq_backward(const void *x, int x_dtype, const float *e, const int64_t 
 int vqhip_vq_backward_ex(const void *x, int x_dtype, const float *e, const int64_t *idx, int64_t N, int D,
                          const float *g_zste, const float *g_cb, const float *g_cm, const float *g_comb, float beta,
                          float *grad_x, float *grad_w, void *stream);
+/* grad_x of vqhip_vq_backward_ex for a quantizer call on the NCHW feature map (vq/tasks/image_tokenization/models/base.py:116-128),
+ * with both rearrangements folded in: g_map [B, D, HW] fp32 is the upstream gradient of the straight-through output AS the map it
+ * arrives in (nullable = 0), grad_map [B, D, HW] receives the gradient of the latents as the map the encoder's backward consumes,
+ * in grad_dtype (VQHIP_DTYPE_F32 / _BF16: the map's own dtype; bf16 rounds to nearest even):
+ *   grad_map[b, d, p] = g_map[b, d, p] + (g_cm + beta*g_comb) * 2/(N D) * (x_rows[n][d] - e[idx[n]][d]),  n = b*HW + p.
+ * No transpose launch and no cast around it.  HW % 256 == 0 and D % 32 == 0 (16 x 16 and larger power-of-two maps; other shapes:
+ * vqhip_transpose + vqhip_vq_backward_ex).  The codebook gradient is formed by vqhip_vq_backward_ex with grad_x = NULL (or the
+ * ordered route). */
+int vqhip_vq_backward_map(const void *x_rows, int x_dtype, const float *e, const int64_t *idx, int64_t B, int64_t HW, int D,
+                          const float *g_map, const float *g_cm, const float *g_comb, float beta, void *grad_map, int grad_dtype,
+                          void *stream);
 int vqhip_ste(const void *x, int x_dtype, const float *z, int64_t n, float *out, void *stream);
 int vqhip_normalize_rows_bwd(const void *v, int dtype, const float *g, int64_t R, int D, float eps, float *gv,
                              void *stream);

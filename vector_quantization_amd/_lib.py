@@ -81,6 +81,7 @@ SIGNATURES = {
     'vqhip_diff': (_i32, [_vp, _i32, _vp, _i32, _i64, _f32, _vp, _vp, _vp, _vp]),
     'vqhip_vq_backward': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vqhip_vq_backward_ex': (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
+    'vqhip_vq_backward_map': (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _f32, _vp, _i32, _vp]),
     'vqhip_ste': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     'vqhip_normalize_rows_bwd': (_i32, [_vp, _i32, _vp, _i64, _i32, _f32, _vp, _vp]),
     'vqhip_transpose': (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),

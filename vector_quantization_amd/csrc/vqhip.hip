@@ -1319,6 +1319,32 @@ int vqhip_vq_backward_ex(const void *x, int x_dtype, const float *e, const int64
     return VQHIP_OK;
 }
 
+int vqhip_vq_backward_map(const void *x_rows, int x_dtype, const float *e, const int64_t *idx, int64_t B, int64_t HW, int D,
+                          const float *g_map, const float *g_cm, const float *g_comb, float beta, void *grad_map, int grad_dtype,
+                          void *stream) {
+    if (!x_rows || !e || !idx || !grad_map || B <= 0 || HW <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vq_backward_map: bad argument");
+    if ((HW % 256) != 0 || (D % 32) != 0) return fail(VQHIP_EINVAL, "vqhip_vq_backward_map: needs HW % 256 == 0 and D % 32 == 0 (transpose and use vqhip_vq_backward_ex)");
+    if ((x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) || (grad_dtype != VQHIP_DTYPE_F32 && grad_dtype != VQHIP_DTYPE_BF16))
+        return fail(VQHIP_EINVAL, "vqhip_vq_backward_map: dtype");
+    const int64_t N = B * HW, nt = N / 256;
+    int csplit = 1;
+    while (nt * csplit < 512 && (D / 32) % (csplit * 2) == 0) csplit *= 2;
+    const int64_t items = nt * csplit;
+    const int grid = (int)(items < 1024 ? items : 1024);
+    constexpr int LDS = 2 * 32 * 256 * 4;
+    static LdsCache sets[4];
+    const int v = (x_dtype == VQHIP_DTYPE_BF16 ? 1 : 0) + (grad_dtype == VQHIP_DTYPE_BF16 ? 2 : 0);
+    const void *kerns[4] = {(const void *)vq_backward_map256_kernel<0, 0>, (const void *)vq_backward_map256_kernel<1, 0>,
+                            (const void *)vq_backward_map256_kernel<0, 1>, (const void *)vq_backward_map256_kernel<1, 1>};
+    if (int rc = ensure_dyn_lds(kerns[v], LDS, sets[v])) return rc;
+    hipStream_t s = (hipStream_t)stream;
+#define VQ_BMAP(DT, ODT) vq_backward_map256_kernel<DT, ODT><<<grid, 512, LDS, s>>>(x_rows, e, idx, N, D, HW, csplit, g_map, g_cm, g_comb, beta, grad_map)
+    if (v == 0) VQ_BMAP(0, 0); else if (v == 1) VQ_BMAP(1, 0); else if (v == 2) VQ_BMAP(0, 1); else VQ_BMAP(1, 1);
+#undef VQ_BMAP
+    VQ_CHECK_LAUNCH("vq_backward_map256_kernel");
+    return VQHIP_OK;
+}
+
 // ---- deterministic (ordered) codebook-side sums -----------------------------------------------------------------
 int64_t vqhip_order_workspace_bytes(int64_t N, int64_t K) {
     if (N < 0 || K <= 0) return 0;

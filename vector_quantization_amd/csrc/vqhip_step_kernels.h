@@ -221,3 +221,102 @@ __global__ __launch_bounds__(256) void vqkd_backward_kernel(const void *__restri
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the quantizer call on the NCHW feature map, gradient of the latents written AS the map (round 5):
+//   grad_map[b, d, p] = g_map[b, d, p] - kx * (e[idx[n]][d] - x_rows[n][d]),   n = b*hw + p,   kx = (g_cm + beta*g_comb) * 2/(N D)
+// — vq_backward_kernel's grad_x with both rearrangements of vq/tasks/image_tokenization/models/base.py:124,126 folded in: the
+// upstream gradient is read as the map it arrives in and the result is stored as the map the encoder's backward consumes, in the
+// map's own dtype; round 4 transposed both through global memory (two vqhip_transpose launches and a cast around the kernel).
+// Geometry of gather_ste_map256_kernel: a work item = (256 consecutive positions of one image, a share of the channels), 512
+// threads, chunks of 32 channels turned through a swizzled LDS tile (two buffers, one barrier per chunk), codebook rows and
+// latents requested one chunk ahead; every wave-load of g_map and wave-store of grad_map is one whole 1 KiB (fp32) channel row.
+// Needs hw % 256 == 0 and D % 32 == 0.  The codebook gradient is not formed here (vqhip_vq_backward_ex with grad_x = NULL, or
+// the ordered route).  ODT: 0 = fp32 map, 1 = bf16 map (round to nearest even).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float v) {
+    uint32_t b = __float_as_uint(v);
+    if ((b & 0x7F800000u) == 0x7F800000u) return b >> 16;        // Inf / NaN: truncate (a NaN keeps a set mantissa bit or becomes Inf-safe)
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return b >> 16;
+}
+
+template <int DT, int ODT>
+__global__ __launch_bounds__(512) void vq_backward_map256_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                                 const int64_t *__restrict__ idx, int64_t N, int D, int64_t hw,
+                                                                 int csplit, const float *__restrict__ g_map,
+                                                                 const float *__restrict__ g_cm, const float *__restrict__ g_comb,
+                                                                 float beta, void *__restrict__ grad_map) {
+    extern __shared__ __attribute__((aligned(16))) char bmap_lds[];
+    float *tile = (float *)bmap_lds;                              // [2][32][256]
+    __shared__ int64_t code_s[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ntiles = N / 256;
+    const int nchunk = D / 32 / csplit;
+    const float kx = ((g_cm ? *g_cm : 0.0f) + beta * (g_comb ? *g_comb : 0.0f)) * (2.0f / ((float)N * (float)D));
+    for (int64_t item = blockIdx.x; item < ntiles * csplit; item += gridDim.x) {
+        const int64_t tb = item / csplit;
+        const int cbase = (int)(item % csplit) * nchunk * 32;
+        const int64_t n0 = tb * 256;
+        const int64_t obase = (n0 / hw) * (int64_t)D * hw + (n0 % hw);
+        __syncthreads();
+        if (threadIdx.x < 256) code_s[threadIdx.x] = idx[n0 + threadIdx.x];
+        __syncthreads();
+        float4 zc[4], zn[4];
+        typename std::conditional<DT == 0, float4, uint2>::type xc[4], xnx[4];
+        auto load_chunk = [&](int c0, float4 (&zr)[4], decltype(xc) &xr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = threadIdx.x + 512 * i, tl = q >> 3, cp = q & 7;
+                zr[i] = *(const float4 *)(e + code_s[tl] * D + c0 + 4 * cp);
+                if constexpr (DT == 0) xr[i] = *(const float4 *)((const float *)x + (n0 + tl) * D + c0 + 4 * cp);
+                else xr[i] = *(const uint2 *)((const uint16_t *)x + (n0 + tl) * D + c0 + 4 * cp);
+            }
+        };
+        load_chunk(cbase, zc, xc);
+        for (int c = 0; c < nchunk; ++c) {
+            const int c0 = cbase + 32 * c;
+            float *tb_lds = tile + (c & 1) * (32 * 256);
+            // the upstream gradient of this chunk: requested before the barrier, consumed behind it
+            float4 gv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave + 8 * i;
+                gv[i] = g_map ? *(const float4 *)(g_map + obase + (int64_t)(c0 + r) * hw + 4 * lane) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (c + 1 < nchunk) load_chunk(c0 + 32, zn, xnx);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = threadIdx.x + 512 * i, tl = q >> 3, cp = q & 7;
+                const float4 zv = zc[i];
+                float xv[4];
+                if constexpr (DT == 0) { xv[0] = xc[i].x; xv[1] = xc[i].y; xv[2] = xc[i].z; xv[3] = xc[i].w; }
+                else {
+                    xv[0] = __uint_as_float(xc[i].x << 16); xv[1] = __uint_as_float(xc[i].x & 0xFFFF0000u);
+                    xv[2] = __uint_as_float(xc[i].y << 16); xv[3] = __uint_as_float(xc[i].y & 0xFFFF0000u);
+                }
+                const float o[4] = {kx * (zv.x - xv[0]), kx * (zv.y - xv[1]), kx * (zv.z - xv[2]), kx * (zv.w - xv[3])};
+                const int col = tl ^ (cp << 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tb_lds[(4 * cp + j) * 256 + col] = o[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave + 8 * i;
+                const float4 v = *(const float4 *)(tb_lds + r * 256 + 4 * (lane ^ ((r >> 2) & 7)));
+                const float4 out = make_float4(gv[i].x - v.x, gv[i].y - v.y, gv[i].z - v.z, gv[i].w - v.w);
+                const int64_t off = obase + (int64_t)(c0 + r) * hw + 4 * lane;
+                if constexpr (ODT == 0) *(float4 *)((float *)grad_map + off) = out;
+                else {
+                    uint2 pk;
+                    pk.x = f32_to_bf16_bits(out.x) | (f32_to_bf16_bits(out.y) << 16);
+                    pk.y = f32_to_bf16_bits(out.z) | (f32_to_bf16_bits(out.w) << 16);
+                    *(uint2 *)((uint16_t *)grad_map + off) = pk;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { zc[i] = zn[i]; xc[i] = xnx[i]; }
+        }
+    }
+}

@@ -563,30 +563,37 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const void *x, const f
     const float gc = g_comb ? *g_comb : 0.0f;
     const float kx = ((g_cm ? *g_cm : 0.0f) + beta * gc) * s, kw = ((g_cb ? *g_cb : 0.0f) + gc) * s;
     const bool do_w = grad_w && kw != 0.0f;
-    // float atomics want the 64 lanes on 256 contiguous bytes (measured: 4 consecutive floats per lane is 3.5x slower),
-    // so the vector path is for the atomic-free case (grad_x only: the ordered route computes grad_w elsewhere)
-    const bool vec = (D % 4) == 0 && !do_w;
+    // grad_x: 16-byte accesses (4 consecutive floats per lane).  grad_w: float atomics want the 64 lanes of an instruction on 256
+    // contiguous bytes (measured: 4 consecutive floats per lane is 3.5x slower), so the atomics run as a second sweep over the row
+    // with one float per lane — its operands were loaded a moment ago and come from L1 / L2.  (Round 4 dropped to the one-float
+    // form for BOTH outputs whenever the codebook gradient was wanted: quantize() forward + backward on a channels-last map
+    // 0.674 -> see profiles/r05_shapes.txt.)
+    const bool vec = (D % 4) == 0;
     for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
         const int64_t k = idx[n];
         if (vec) {
-            for (int d = 4 * lane; d < D; d += 256) {
-                const float4 zv = *(const float4 *)(e + k * D + d);
-                float xv[4];
-                if (DT == 0) {
-                    const float4 t = *(const float4 *)((const float *)x + n * D + d);
-                    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-                } else {
-                    const uint2 t = *(const uint2 *)((const uint16_t *)x + n * D + d);
-                    xv[0] = __uint_as_float(t.x << 16); xv[1] = __uint_as_float(t.x & 0xFFFF0000u);
-                    xv[2] = __uint_as_float(t.y << 16); xv[3] = __uint_as_float(t.y & 0xFFFF0000u);
-                }
-                const float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
-                if (grad_x) {
+            if (grad_x)
+                for (int d = 4 * lane; d < D; d += 256) {
+                    const float4 zv = *(const float4 *)(e + k * D + d);
+                    float xv[4];
+                    if (DT == 0) {
+                        const float4 t = *(const float4 *)((const float *)x + n * D + d);
+                        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                    } else {
+                        const uint2 t = *(const uint2 *)((const uint16_t *)x + n * D + d);
+                        xv[0] = __uint_as_float(t.x << 16); xv[1] = __uint_as_float(t.x & 0xFFFF0000u);
+                        xv[2] = __uint_as_float(t.y << 16); xv[3] = __uint_as_float(t.y & 0xFFFF0000u);
+                    }
+                    const float d0 = zv.x - xv[0], d1 = zv.y - xv[1], d2 = zv.z - xv[2], d3 = zv.w - xv[3];
                     float4 gz = make_float4(0, 0, 0, 0);
                     if (g_zste) gz = *(const float4 *)(g_zste + n * D + d);
                     *(float4 *)(grad_x + n * D + d) = make_float4(gz.x - kx * d0, gz.y - kx * d1, gz.z - kx * d2, gz.w - kx * d3);
                 }
-            }
+            if (do_w)
+                for (int d = lane; d < D; d += 64) {
+                    const float df = e[k * D + d] - load_elem<DT>(x, n * D + d);
+                    atomicAdd(&grad_w[k * D + d], kw * df);
+                }
         } else {
             for (int d = lane; d < D; d += 64) {
                 float xv = load_elem<DT>(x, n * D + d), zv = e[k * D + d];

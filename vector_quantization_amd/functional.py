@@ -154,6 +154,12 @@ class _FusedMapDecodeLoss(Function):
         x_rows, weight, idx = ctx.saved_tensors
         b, d, h, w = ctx.map_shape
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        if ops.backward_map_supported(d, h * w) and ctx.map_dtype in (torch.float32, torch.bfloat16):
+            # both rearrangements folded into the kernel: the upstream gradient is read as the map, the latents' gradient written
+            # as the map in the map's dtype (vqhip_vq_backward_map); the codebook gradient from the token-major rows as before
+            gx = ops.vq_backward_map(x_rows, weight, idx, (b, d, h, w), g_map, g_cm, g_comb, ctx.beta, ctx.map_dtype) if need_x else None
+            gw = ops.vq_backward(x_rows, weight, idx, None, g_cb, g_cm, False, True, g_comb=g_comb, beta=ctx.beta)[1] if need_w else None
+            return gx, None, gw, None, None
         g_tok = None
         if g_map is not None:                                    # 'b c h w -> (b h w) c' of the incoming gradient
             g_tok = ops.transpose_last2(g_map.float().contiguous().reshape(b, d, h * w)).reshape(b * h * w, d)

@@ -756,6 +756,34 @@ def vq_backward(x: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, g_zste: Opt
     return gx, gw
 
 
+def backward_map_supported(D: int, hw: int) -> bool:
+    """Shapes ``vq_backward_map`` takes (whole 1 KiB channel rows per wave-instruction): HW % 256 == 0, D % 32 == 0."""
+    return hw % 256 == 0 and D % 32 == 0
+
+
+@_on_tensor_device
+def vq_backward_map(x_rows: torch.Tensor, e: torch.Tensor, idx: torch.Tensor, shape, g_map: Optional[torch.Tensor],
+                    g_cm: Optional[torch.Tensor], g_comb: Optional[torch.Tensor], beta: float, out_dtype: torch.dtype) -> torch.Tensor:
+    """Gradient of the latents of a quantizer call on the NCHW map [B, D, H, W], written as that map in ``out_dtype`` (fp32 or
+    bf16) from the upstream gradient ``g_map`` of the straight-through output given as the map too (include/vqhip.h:
+    vqhip_vq_backward_map — no transposes, no cast)."""
+    _require_cuda(x_rows, e, idx)
+    b, d, h, w = shape
+    x_rows, dt = _latents(x_rows)
+    e = _codebook(e)
+    idx = idx.reshape(-1).contiguous()
+    assert tuple(x_rows.shape) == (b * h * w, d) and out_dtype in (torch.float32, torch.bfloat16)
+    if g_map is not None:
+        g_map = g_map.float().contiguous()
+        assert tuple(g_map.shape) == (b, d, h, w)
+    scal = [None if g is None else g.detach().float().reshape(1).contiguous() for g in (g_cm, g_comb)]
+    out = torch.empty(b, d, h, w, dtype=out_dtype, device=x_rows.device)
+    check(_lib.lib().vqhip_vq_backward_map(_ptr(x_rows), dt, _ptr(e), _ptr(idx), b, h * w, d, _ptr(g_map), _ptr(scal[0]), _ptr(scal[1]),
+                                           float(beta), _ptr(out), _lib.DTYPE_F32 if out_dtype == torch.float32 else _lib.DTYPE_BF16,
+                                           _stream()), 'vqhip_vq_backward_map')
+    return out
+
+
 @_on_tensor_device
 def transpose_last2(t: torch.Tensor) -> torch.Tensor:
     """[B, R, C] -> [B, C, R] for fp32 / bf16 / fp16 tensors (the BCHW <-> (BHW)C rearrangement)."""
