@@ -290,7 +290,13 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
                 if (small) VQ_CFG(4, 2, 8, 4, 4, true) else VQ_CFG(4, 4, 8, 4, 4, true)
         case 8: if (!g_tune_filter.load()) { if (small) VQ_CFG(8, 2, 8, 4, 4) else VQ_CFG(8, 4, 8, 4, 4) }
                 if (small) VQ_CFG(8, 2, 8, 4, 4, true) else VQ_CFG(8, 4, 8, 4, 4, true)
+#if defined(VQ_D256_GROUPS)
+        case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4, true, false, true)
+#elif defined(VQ_D256_FILTER)
+        case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4, true) else VQ_CFG(16, 4, 8, VQ_TPS16, 4, true)
+#else
         case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
+#endif
         // large D: the token fragments of a wave must stay in registers for the whole stream
 #ifndef VQ_CFG_D512
 #define VQ_CFG_D512 VQ_CFG(32, 2, 8, 2)
@@ -1476,6 +1482,17 @@ int vqhip_debug_proposal_scores(const void *x, int x_dtype, const void *cb, int6
     VQ_CHECK_LAUNCH("debug_margin_kernel");
     return VQHIP_OK;
 }
+
+#ifdef VQ_CLOCK_STAMPS
+// diagnostic builds only (not declared in include/vqhip.h): the (delta s_memtime, delta s_memrealtime) pairs the proposal kernel's
+// waves stamped around their stage loop, copied to the HOST buffer out[2 * n], n <= VQ_CLOCK_SLOTS
+int vqhip_debug_clock_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n <= 0 || n > VQ_CLOCK_SLOTS) return fail(VQHIP_EINVAL, "vqhip_debug_clock_stamps: bad argument");
+    VQ_HIP(hipDeviceSynchronize());
+    VQ_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vq_clock_dbg), (size_t)n * 16, 0, hipMemcpyDeviceToHost));
+    return VQHIP_OK;
+}
+#endif
 
 int vqhip_set_tuning(int key, int value) {
     if (key == 2) g_tune_slices = (value == 1 || value == 2 || value == 4 || value == 8 || value == 16) ? value : 0;

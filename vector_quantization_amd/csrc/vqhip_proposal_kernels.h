@@ -67,6 +67,10 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 // stream loop; two (256 registers) compile without a spill, and at these sizes there are at most two workgroups per CU to
 // co-schedule anyway: 4096 x 8192 x 32 cosine 0.0705 -> 0.0538 ms per encode, 4096 x 16384 x 8 0.0768 -> 0.0592
 // (profiles/r05_ab_small_d.txt; 12 544 rows: level).
+#ifdef VQ_CLOCK_STAMPS
+#define VQ_CLOCK_SLOTS 16384
+__device__ unsigned long long vq_clock_dbg[2 * VQ_CLOCK_SLOTS];
+#endif
 #ifndef VQ_D32_PLAIN_OCC
 #define VQ_D32_PLAIN_OCC 2
 #endif
@@ -196,6 +200,11 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         for (int t = 0; t < TT; ++t) accA[1][t] = f32x4{-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     }
 
+#ifdef VQ_CLOCK_STAMPS
+    // diagnostic build only (tools/inkernel_clock.py; MI355X guide, DVFS item 6): the shader clock this wave's stage loop ran at =
+    // delta s_memtime / delta s_memrealtime x 100 MHz.  The stamps go to a buffer of their own that nothing else reads.
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
         const int64_t st = it - lag;
@@ -267,8 +276,12 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
                 if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
 #pragma unroll
             for (int ch = 0; ch < NSTEP; ++ch) {
+#ifdef VQ_EXP_NO_LDS_READS      // timing-only diagnostic build: the A fragment of every chunk is the register set loaded first (opaque to the compiler)
+                if (ch + PF < NSTEP) { af[(ch + PF) % (PF + 1)] = af[0]; asm volatile("" : "+v"(af[(ch + PF) % (PF + 1)])); }
+#else
                 if (ch + PF < NSTEP)
                     af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+#endif
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     if constexpr (!WITH_AUX) {
@@ -317,8 +330,17 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
                 }
                 // retire NE*TT/NSTEP accumulator elements of the previous tile per chunk step
                 constexpr int TOTAL = NE * TT;
+#ifdef VQ_EXP_NO_EPILOGUE       // timing-only diagnostic build: the scores are never looked at.  Every accumulator of the previous tile is
+                constexpr bool RETIRE = false;      // named as an asm input once per tile, so that not one MFMA is dead code (a first form that
+                if (ch == 0) {                      // read ONE element per chunk let hipcc drop a quarter of the MFMAs: 96 of 128 per stage)
 #pragma unroll
-                for (int i = 0; PIPE && !FILTER && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
+                    for (int u = 0; u < TT; ++u) asm volatile("" :: "v"(prv[0][u]), "v"(prv[1][u]));
+                }
+#else
+                constexpr bool RETIRE = PIPE && !FILTER;
+#endif
+#pragma unroll
+                for (int i = 0; RETIRE && i < (TOTAL + NSTEP - 1) / NSTEP; ++i) {
                     constexpr int EVERY = (NSTEP / TOTAL) > 0 ? NSTEP / TOTAL : 1;   // TOTAL < NSTEP: one element every EVERY chunks
                     const int id = (TOTAL >= NSTEP) ? ch * (TOTAL / NSTEP) + i : ((ch % EVERY == 0) ? ch / EVERY : -1);
                     if (id >= 0 && id < TOTAL) {
@@ -361,6 +383,16 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
         __syncthreads();
     }
+#ifdef VQ_CLOCK_STAMPS
+    {
+        const unsigned long long clk_t1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && wave_active) {
+            const unsigned slot = ((unsigned)blockIdx.x * WAVES + (unsigned)wave) & (VQ_CLOCK_SLOTS - 1);
+            vq_clock_dbg[2 * slot] = clk_t1 - clk_t0;
+            vq_clock_dbg[2 * slot + 1] = clk_r1 - clk_r0;
+        }
+    }
+#endif
     if (PIPE_H && st1 > st0) {   // drain: second half of the last tile
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
