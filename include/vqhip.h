@@ -371,6 +371,28 @@ int vqhip_vqkd_forward(vqhip_vqkd_forward_t *args, void *stream);
 int vqhip_vqkd_backward(const void *x, int x_dtype, const float *xn, const float *w, const int64_t *idx, int64_t N, int D,
                         const float *g_zste, const float *g_loss, float *grad_x, void *stream);
 
+/* vqhip_vq_forward — the forward of a quantizer WITHOUT an update callback, or with NormalizeCallback alone (the LlamaGen
+ * tokenizer, configs/llamagen/vqgan.py:18-20), as one host call (vq/algorithms/vq/quantizers.py:92-117, callbacks/normalize.py:22-29,
+ * losses.py:41-127): [w_out = normalize(w_in) and xn = normalize(x): ONE launch] -> vqhip_encode_ex(xn | x, w_out | w_in) ->
+ * vqhip_gather_ste_mse on the same operands.  normalize != 0: both normalisations (w_out [K, D] and xn [N, D] fp32 are written; w_out
+ * may alias w_in); normalize == 0: w_out / xn unused.  hist nullable; xq: cosine only; z_ste / mse nullable together.
+ * ws: vqhip_workspace_bytes(N, K, D). */
+typedef struct vqhip_vq_forward_t {
+    int64_t struct_bytes;
+    int64_t N, K;
+    int32_t D, x_dtype, metric, normalize;
+    float beta;
+    int32_t reserved0;
+    const void *x;
+    const float *w_in;
+    float *w_out, *xn;
+    void *cb; int64_t cb_bytes;
+    int64_t *idx; int32_t *hist; float *xq;
+    float *z_ste, *mse; void *scratch16;
+    void *ws; int64_t ws_bytes;
+} vqhip_vq_forward_t;
+int vqhip_vq_forward(vqhip_vq_forward_t *args, void *stream);
+
 /* anchors[k] = x[col_idx[k]] (anchors.py:84) as fp32 */
 int vqhip_gather_rows(const void *x, int x_dtype, const int64_t *row_idx, int64_t K, int D, float *out,
                       void *stream);

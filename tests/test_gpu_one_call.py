@@ -274,3 +274,40 @@ def test_graphed_cvq_capacity_buckets_follow_the_list():
     for (qa, za, la, wa, pa), (qb, zb, lb, wb, pb) in zip(ref, got):
         assert torch.equal(qa, qb) and torch.equal(za, zb) and torch.equal(wa, wb) and torch.equal(pa, pb)
         assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
+
+
+@pytest.mark.parametrize('kind,dist,D,bf16,train', [('plain', 'L2', 256, True, True), ('plain', 'L2', 256, True, False), ('plain', 'Cosine', 32, False, True),
+                                                    ('normalize', 'L2', 8, False, True), ('normalize', 'L2', 8, True, False),
+                                                    ('normalize', 'Cosine', 64, False, True)])
+def test_plain_and_normalize_forward_one_call_equals_hook_by_hook(kind, dist, D, bf16, train):
+    """vqhip_vq_forward: a quantizer without an update callback (configs/vqgan/model.py:19-23) and one with NormalizeCallback
+    alone (configs/llamagen/vqgan.py:18-20), train and eval — tokens, outputs, codebooks bit for bit, gradients to 1e-5."""
+    N, K = 3000, 2048
+    w0 = synth.rng(11).standard_normal((K, D), dtype=np.float32)
+    xs = batches(N, K, D, synth.unit_rows(w0), 3, 37, bf16)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(6)) / (N * D)
+    cfg = dict(type='VQGANQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D), distance=dict(type=f'{dist}Distance'),
+               losses=dict(vqgan_loss=dict(type='VQGANLoss')), callbacks=[dict(type='NormalizeCallback')] if kind == 'normalize' else [])
+    recs = []
+    for one_call in (False, True):
+        q = build(cfg, w0)
+        q.train(train)
+        assert (q._one_call_step(xs[0]) is not None) == one_call or not one_call
+        q.one_call_steps = one_call
+        assert (q._one_call_step(xs[0]) is not None) == one_call
+        rec = []
+        for x in xs:
+            xin = x.clone().requires_grad_(train)
+            for p in q.parameters():
+                p.grad = None
+            z, loss, memo = q(xin, {})
+            if train:
+                torch.autograd.backward([loss, z], [None, gz])
+            wg = q.embedding.weight.grad
+            rec.append(dict(quant=memo['quant'].clone(), z=z.detach().clone(), loss=loss.detach().clone(),
+                            gx=xin.grad.clone() if train else torch.zeros(1), gw=None if wg is None else wg.clone(),
+                            w=q.embedding.weight.detach().clone(), hist=memo['encode'].get('hist', torch.zeros(1)).clone(),
+                            memo_x=memo['x'].detach().clone(), loss_memo={k: v.detach().clone() for k, v in memo['loss'].items()}))
+            assert memo['encode']['distance'].shape == (N, K)
+        recs.append(rec)
+    assert_same(recs[0], recs[1])

@@ -50,6 +50,17 @@ class VqkdForwardArgs(ctypes.Structure):
                 ('exchange_floats', _i64)]
 
 
+class VqForwardArgs(ctypes.Structure):
+    """vqhip_vq_forward_t of include/vqhip.h, field for field."""
+    _fields_ = [('struct_bytes', _i64), ('N', _i64), ('K', _i64),
+                ('D', _i32), ('x_dtype', _i32), ('metric', _i32), ('normalize', _i32),
+                ('beta', _f32), ('reserved0', _i32),
+                ('x', _vp), ('w_in', _vp), ('w_out', _vp), ('xn', _vp),
+                ('cb', _vp), ('cb_bytes', _i64), ('idx', _vp), ('hist', _vp), ('xq', _vp),
+                ('z_ste', _vp), ('mse', _vp), ('scratch16', _vp),
+                ('ws', _vp), ('ws_bytes', _i64)]
+
+
 STEP_BEFORE_EXCHANGE, STEP_AFTER_EXCHANGE, STEP_ALL = 1, 2, 3
 
 # name -> (restype, argtypes); mirrors include/vqhip.h one to one
@@ -101,6 +112,7 @@ SIGNATURES = {
     'vqhip_cvq_forward': (_i32, [ctypes.POINTER(CvqForwardArgs), _vp]),
     'vqhip_vqkd_forward_ws_bytes': (_i64, [_i64, _i64, _i32]),
     'vqhip_vqkd_forward': (_i32, [ctypes.POINTER(VqkdForwardArgs), _vp]),
+    'vqhip_vq_forward': (_i32, [ctypes.POINTER(VqForwardArgs), _vp]),
     'vqhip_vqkd_backward': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     'vqhip_cvq_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
     'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),

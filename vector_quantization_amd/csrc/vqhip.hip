@@ -1270,6 +1270,35 @@ int vqhip_vqkd_forward(vqhip_vqkd_forward_t *a, void *stream) {
     return VQHIP_OK;
 }
 
+int vqhip_vq_forward(vqhip_vq_forward_t *a, void *stream) {
+    if (!a || a->struct_bytes != (int64_t)sizeof(vqhip_vq_forward_t)) return fail(VQHIP_EINVAL, "vqhip_vq_forward: struct_bytes != sizeof(vqhip_vq_forward_t)");
+    const int64_t N = a->N, K = a->K;
+    const int D = a->D;
+    if (N <= 0 || K <= 0 || D <= 0 || N >= (1ll << 31) || K >= (1ll << 31)) return fail(VQHIP_EINVAL, "vqhip_vq_forward: N, K, D");
+    if (a->metric != VQHIP_METRIC_L2 && a->metric != VQHIP_METRIC_COS && a->metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_vq_forward: metric");
+    if (a->x_dtype != VQHIP_DTYPE_F32 && a->x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_vq_forward: x_dtype");
+    if (!a->x || !a->w_in || !a->cb || !a->idx || !a->ws || (a->normalize && (!a->w_out || !a->xn))) return fail(VQHIP_EINVAL, "vqhip_vq_forward: null pointer");
+    if (VQ_IS_COS(a->metric) && !a->xq) return fail(VQHIP_EINVAL, "vqhip_vq_forward: the cosine metric needs the xq buffer");
+    if ((a->z_ste || a->mse) && (!a->mse || !a->scratch16)) return fail(VQHIP_EINVAL, "vqhip_vq_forward: the decode tail needs mse and scratch16");
+    VQ_NEED("vqhip_vq_forward: ws too small", a->ws_bytes, vqhip_workspace_bytes(N, K, D));
+    hipStream_t s = (hipStream_t)stream;
+    const void *rows = a->x;
+    int rows_dtype = a->x_dtype;
+    const float *codes = a->w_in;
+    if (a->normalize) {
+        const int kblocks = (int)((K + 3) / 4), xblocks = (int)((N + 3) / 4);
+        if (a->x_dtype == VQHIP_DTYPE_F32) vqkd_front_kernel<0><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_out, K, a->x, a->xn, N, D, 1e-12f, kblocks, nullptr, 0, 1);
+        else vqkd_front_kernel<1><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_out, K, a->x, a->xn, N, D, 1e-12f, kblocks, nullptr, 0, 1);
+        VQ_CHECK_LAUNCH("vqkd_front_kernel");
+        rows = a->xn; rows_dtype = VQHIP_DTYPE_F32; codes = a->w_out;
+    }
+    if (int rc = vqhip_encode_ex(rows, rows_dtype, codes, N, K, D, a->metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws, a->ws_bytes,
+                                 a->hist ? VQHIP_ENCODE_ZERO_HIST : 0, stream)) return rc;
+    if (a->mse)
+        if (int rc = vqhip_gather_ste_mse(rows, rows_dtype, codes, a->idx, N, D, nullptr, a->z_ste, a->mse, a->beta, a->scratch16, stream)) return rc;
+    return VQHIP_OK;
+}
+
 int vqhip_vqkd_backward(const void *x, int x_dtype, const float *xn, const float *w, const int64_t *idx, int64_t N, int D,
                         const float *g_zste, const float *g_loss, float *grad_x, void *stream) {
     if (!x || !xn || !w || !idx || !grad_x || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: bad argument");

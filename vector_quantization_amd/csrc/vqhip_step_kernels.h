@@ -22,10 +22,13 @@ __device__ __forceinline__ float row_den(const void *v, int64_t r, int D, int la
 //   blocks after:         xn[n] = F.normalize(x[n])                       (callbacks/normalize.py:24)
 //   every block:          its share of `zero[0 .. nzero)` cleared (the payload of the packed exchange buffer)
 // Bit-identical to normalize_rows_kernel applied twice / once.
+// w_passes: 2 = the VQ-KD front above; 1 = NormalizeCallback alone (w_mid = F.normalize(w_in), callbacks/normalize.py:27: the
+// front of vqhip_vq_forward); kblocks == 0 / N == 0: that side is not wanted.
 template <int DT>
 __global__ __launch_bounds__(256) void vqkd_front_kernel(const float *__restrict__ w_in, float *__restrict__ w_mid, int64_t K,
                                                          const void *__restrict__ x, float *__restrict__ xn, int64_t N, int D,
-                                                         float eps, int kblocks, float *__restrict__ zero, int64_t nzero) {
+                                                         float eps, int kblocks, float *__restrict__ zero, int64_t nzero,
+                                                         int w_passes = 2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nzero; i += (int64_t)gridDim.x * 1024)
         *(float4 *)(zero + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // nzero % 4 == 0 (K * D with D % 8 == 0)
@@ -33,6 +36,10 @@ __global__ __launch_bounds__(256) void vqkd_front_kernel(const float *__restrict
         const int64_t k = (int64_t)blockIdx.x * 4 + wave;
         if (k >= K) return;
         const float den1 = row_den<0>(w_in, k, D, lane, eps);
+        if (w_passes == 1) {
+            for (int d = lane; d < D; d += 64) w_mid[k * D + d] = w_in[k * D + d] / den1;
+            return;
+        }
         float p = 0.0f;
         for (int d = lane; d < D; d += 64) { const float y = w_in[k * D + d] / den1; p = fmaf(y, y, p); }
         p = wave_sum_tree(p);

@@ -219,7 +219,10 @@ class _VqkdStep(Function):
     def forward(ctx, x: torch.Tensor, weight: torch.Tensor, done: _Computed):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, done.xn, weight, done.idx)
-        return done.xn.view(x.shape), done.z_ste.view(x.shape), done.mse[0]
+        xn = done.xn.view(x.shape)
+        if not ctx.needs_input_grad[0]:
+            ctx.mark_non_differentiable(xn)
+        return xn, done.z_ste.view(x.shape), done.mse[0]
 
     @staticmethod
     def backward(ctx, g_xn, g_zste, g_loss):
@@ -237,3 +240,51 @@ class _VqkdStep(Function):
 def vqkd_step(x: torch.Tensor, weight: torch.Tensor, done: _Computed):
     """(xn, z_ste, commitment loss) tied into the autograd graph."""
     return _VqkdStep.apply(x, weight, done)
+
+
+class _VqStep(Function):
+    """Autograd node of the one-call forward of a quantizer without an update callback, or with NormalizeCallback alone
+    (vqhip_vq_forward): outputs (xn = F.normalize(x) when normalised, else x itself is what memo['x'] holds), the straight-through
+    output, both MSE values and their VQGAN combination.  Backward: the fused kernel of ``_FusedDecodeLoss`` on the rows the
+    forward quantized, then F.normalize's backward when the rows were normalised."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, done: _Computed, beta: float):
+        ctx.set_materialize_grads(False)
+        ctx.beta = float(beta)
+        ctx.normalized = done.xn is not None
+        mse = done.mse
+        if ctx.normalized:
+            ctx.save_for_backward(x, done.xn, weight, done.idx)
+            xn = done.xn.view(x.shape)
+            if not ctx.needs_input_grad[0]:                      # F.normalize(x) of latents without a graph has none either
+                ctx.mark_non_differentiable(xn)
+            return xn, done.z_ste.view(x.shape), mse[0], mse[1], mse[2]
+        ctx.save_for_backward(x, weight, done.idx)
+        return None, done.z_ste.view(x.shape), mse[0], mse[1], mse[2]
+
+    @staticmethod
+    def backward(ctx, g_xn, g_zste, g_cb, g_cm, g_comb):
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if ctx.normalized:
+            x, xn, weight, idx = ctx.saved_tensors
+            rows = xn
+        else:
+            x, weight, idx = ctx.saved_tensors
+            rows = _as2d(x)
+        gr, gw = ops.vq_backward(rows, weight, idx, None if g_zste is None else _as2d(g_zste), g_cb, g_cm, need_x, need_w,
+                                 g_comb=g_comb, beta=ctx.beta)
+        gx = None
+        if need_x:
+            if ctx.normalized:
+                if g_xn is not None:                             # a consumer of memo['x'] other than the decode / loss tail
+                    gr = _as2d(g_xn).float() if gr is None else gr + _as2d(g_xn)
+                gx = ops.normalize_rows_bwd(_as2d(x), gr, 1e-12).view(x.shape).to(x.dtype)
+            else:
+                gx = gr.view(x.shape).to(x.dtype)
+        return gx, gw, None, None
+
+
+def vq_step(x: torch.Tensor, weight: torch.Tensor, done: _Computed, beta: float = 0.0):
+    """(xn or None, z_ste, m_cb, m_cm, m_cb + beta*m_cm) of a one-call forward, tied into the autograd graph."""
+    return _VqStep.apply(x, weight, done, beta)

@@ -182,13 +182,23 @@ class VectorQuantizer(BaseQuantizer):
         """The training forwards that ONE library call enqueues (train_step.py): a VQGAN-style quantizer whose only callback
         is a CVQVAECallback in its sparse-anchor flow, or a VQ-KD quantizer (VQKDCallback + CommitmentLoss with norm=True:
         configs/vqkd/model.py:20-26).  None: the step runs hook by hook as below."""
-        if not (self.one_call_steps and self.training and self._fused and x.dim() == 2):
+        if not (self.one_call_steps and self._fused and x.dim() == 2):
             return None
         cbs = self._callbacks.callbacks
-        if len(cbs) != 1 or type(self)._encode is not VectorQuantizer._encode or type(self)._decode is not VectorQuantizer._decode \
+        if len(cbs) > 1 or type(self)._encode is not VectorQuantizer._encode or type(self)._decode is not VectorQuantizer._decode \
                 or type(self)._loss is not BaseQuantizer._loss or type(self).encode is not BaseQuantizer.encode:
             return None
-        from .callbacks import CVQVAECallback, VQKDCallback
+        from .callbacks import CVQVAECallback, NormalizeCallback, VQKDCallback
+        from .distances import CosineDistance, L2Distance
+        if len(cbs) == 0 or type(cbs[0]) is NormalizeCallback:
+            # no update callback (VQGAN: configs/vqgan/model.py:19-23), or NormalizeCallback alone (LlamaGen: configs/llamagen/
+            # vqgan.py:18-20) — train and eval alike: vqhip_vq_forward
+            w = self._embedding.weight
+            ok = (self._fusable() and not self._cache_codebook and type(self._distance) in (L2Distance, CosineDistance)
+                  and x.is_cuda and 0 < x.shape[0] < (1 << 31) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous())
+            return self._forward_plain if ok else None
+        if not self.training:
+            return None
         cb = cbs[0]
         if type(cb) is CVQVAECallback:
             return self._forward_cvq if (self._fusable() and cb.fused_forward_ok(x)) else None
@@ -204,6 +214,46 @@ class VectorQuantizer(BaseQuantizer):
         betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
         quant, z_ste, m_cb, m_cm, m_vqgan = cb.fused_forward(x, memo, betas[0] if betas else 0.0)
         memo.update(x=x, quant=quant)
+        memo['decode'] = get_memo(memo, 'decode')
+        return z_ste, self._loss_values(memo, m_cb, m_cm, m_vqgan, betas, x), memo
+
+    def _forward_plain(self, x: torch.Tensor, memo: Memo):
+        """encode (+ NormalizeCallback.before_encode) + decode + MSE losses + STE from one library call (train_step.vq_forward)."""
+        from .. import train_step
+        cbs = self._callbacks.callbacks
+        weight = self._embedding.weight
+        D = weight.shape[1]
+        normalize = len(cbs) == 1
+        w_in = weight.detach()
+        w_out = None
+        if normalize:
+            w_out = w_in if cbs[0]._writes_in_place(weight) else torch.empty_like(w_in)
+        betas = [loss.beta for loss in self._losses.values() if isinstance(loss, VQGANLoss)]
+        beta = betas[0] if betas else 0.0
+        want_hist = self.training and len(cbs) > 0
+        out = train_step.vq_forward(x.detach(), w_in, w_out, self._distance.metric_for(D), beta, normalize=normalize, want_hist=want_hist)
+        if normalize:
+            from ..utils import Store, is_sync
+            if Store.DRY_RUN:
+                assert is_sync(w_out)
+            if w_out.data_ptr() != weight.data_ptr():
+                weight.data = w_out                              # callbacks/update.py:56
+            self.invalidate_codebook()
+        done = VF._Computed(xn=out['xn'], z_ste=out['z_ste'], mse=out['mse'], idx=out['idx'])
+        xn, z_ste, m_cb, m_cm, m_vqgan = VF.vq_step(x, weight, done, beta)
+        rows = xn if normalize else x
+        enc = get_memo(memo, 'encode')
+        prepared = out['prepared']
+        cos = out['xq'] is not None
+        grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        e_op = weight.view_as(weight) if (grad and weight.requires_grad) else prepared.weight
+        enc['distance'] = LazyDistance(self._distance, rows if grad else (out['xn'] if normalize else out['x']), e_op,
+                                       xq=out['xq'] if cos else (out['xn'] if normalize else out['x']),
+                                       eq=prepared.exact_rows() if cos else prepared.weight, metric=ops.metric_name(prepared.metric))
+        if out['hist'] is not None:
+            enc['hist'] = out['hist']
+        memo['encode'] = enc
+        memo.update(x=rows, quant=out['idx'])
         memo['decode'] = get_memo(memo, 'decode')
         return z_ste, self._loss_values(memo, m_cb, m_cm, m_vqgan, betas, x), memo
 

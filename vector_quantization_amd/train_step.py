@@ -212,6 +212,43 @@ def vqkd_forward(x: torch.Tensor, w_in: torch.Tensor, w_mid: torch.Tensor, w_out
 
 
 @_on_tensor_device
+def vq_forward(x: torch.Tensor, w_in: torch.Tensor, w_out: Optional[torch.Tensor], metric, beta: float, *, normalize: bool,
+               want_hist: bool, tail: bool = True):
+    """The forward of a quantizer without an update callback — or with NormalizeCallback alone (``normalize``) — as one library
+    call (include/vqhip.h: vqhip_vq_forward).  Returns a dict: xn (F.normalize(x), normalize only), idx, hist, xq (cosine),
+    prepared, z_ste, mse, x (the latents as the library read them)."""
+    ops._require_cuda(x, w_in)
+    x, dt = _latents(x)
+    N, D = x.shape
+    K = w_in.shape[0]
+    m = METRICS[metric]
+    L = _lib.lib()
+    dev = x.device
+    cos = m in (_lib.METRIC_COS, _lib.METRIC_COS_BF16)
+    ws = _bytes(L.vqhip_workspace_bytes(N, K, D), dev)
+    image = _bytes(L.vqhip_codebook_bytes(K, D), dev)
+    idx = torch.empty(N, dtype=torch.int64, device=dev)
+    hist = torch.empty(K, dtype=torch.int32, device=dev) if want_hist else None
+    xn = torch.empty(N, D, dtype=torch.float32, device=dev) if normalize else None
+    xq = torch.empty(N, D, dtype=torch.float32, device=dev) if cos else None
+    z_ste = torch.empty(N, D, dtype=torch.float32, device=dev) if tail else None
+    mse = torch.empty(4, dtype=torch.float32, device=dev) if tail else None
+    a = _lib.VqForwardArgs()
+    a.struct_bytes = ctypes.sizeof(_lib.VqForwardArgs)
+    a.N, a.K, a.D, a.x_dtype, a.metric, a.normalize = N, K, D, dt, m, int(bool(normalize))
+    a.beta = float(beta)
+    a.x, a.w_in, a.w_out, a.xn = x.data_ptr(), w_in.data_ptr(), _p(w_out), _p(xn)
+    a.cb, a.cb_bytes = image.data_ptr(), image.numel()
+    a.idx, a.hist, a.xq = idx.data_ptr(), _p(hist), _p(xq)
+    a.z_ste, a.mse = _p(z_ste), _p(mse)
+    a.scratch16 = _mse_scratch(dev).data_ptr() if tail else None
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    check(L.vqhip_vq_forward(ctypes.byref(a), _stream()), 'vqhip_vq_forward')
+    codes = w_out if normalize else w_in
+    return dict(xn=xn, idx=idx, hist=hist, xq=xq, prepared=ops.PreparedCodebook(image, codes, K, D, m), z_ste=z_ste, mse=mse, x=x)
+
+
+@_on_tensor_device
 def vqkd_backward(x: torch.Tensor, xn: torch.Tensor, w: torch.Tensor, idx: torch.Tensor, g_zste: Optional[torch.Tensor],
                   g_loss: Optional[torch.Tensor]) -> torch.Tensor:
     """grad_x of the VQ-KD tail (include/vqhip.h: vqhip_vqkd_backward) as fp32 [N, D]."""
