@@ -256,7 +256,10 @@ int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream)
  * depends only on the synchronised p, so every rank derives the same one before anything is exchanged.
  * vqhip_col_argmin_rows: col_idx[i] = nearest latent of code rows[i] for i < count — vqhip_col_argmin's pipeline and
  *   arithmetic on the listed codes; the launches are sized for `cap` (>= the count; the host need not know it: a HIP graph
- *   captures cap = K), rows past the count cost an early exit; ws = vqhip_col_rows_workspace_bytes(N, cap, D).
+ *   captures cap = K), rows past the count cost an early exit; ws = vqhip_col_rows_workspace_bytes(N, cap, D).  A SHORT list
+ *   (ceil(cap / 32) * ceil(N / 128) * D <= 2^18; fp32 latents or the cosine metric) skips the proposal pipeline: the whole-batch fp32 pass of the
+ *   definition itself over the listed codes, one launch behind a tiny one (two more for the L2 norms) instead of five — the
+ *   same indices (tuning key 15 = 0 sends short lists through the pipeline as well: A/B, tests).
  * vqhip_cvq_pack: this rank's packed buffer — header from the int32 epilogue histogram, payload row i = x[col_idx[i]]
  *   for i < count, zeros up to cap.  All-reduce the first vqhip_pack_floats(K, cap, D) floats.
  * vqhip_cvq_apply: p_out = p_in*g + (hist/numel)*(1-g); decay as above; w_out[k] = w_in[k]*decay + a*(1-decay) for listed
@@ -486,7 +489,7 @@ int vqhip_profile_enable(int on);
  * stage inside the proposal kernel (0 never, 1 always, 2 = where one slice covers the codebook: default); key 8 = no aux reads
  * for cosine / dot codebooks at D <= 32 (1); key 9 = group records at D <= 32, identified by identify32_kernel (32x32x16 form: K <= 131 072, N < 2^30) or by an in-kernel replay (16x16x32 form) (1); key 10 = balanced
  * tiles per workgroup (1); key 11 = the 32x32x16 proposal kernel at D <= 16 (1); key 13 = whole-image tiles in vqhip_gather_ste_map
- * for maps of 256-position images (1).
+ * for maps of 256-position images (1); key 15 = the direct fp32 form of vqhip_col_argmin_rows for short lists (1).
  * Key 12 is a verification aid, not an A/B knob: value V > 0 sends rows 0 .. min(V, N, 1024) - 1 of every vqhip_argmin batch
  * through the last-resort whole-codebook fp32 pass as well (its indices replace the ones the earlier stages wrote — the same
  * ones; a histogram requested from the call counts those rows twice); 0 = off (default).  Any other key: VQHIP_EINVAL. */

@@ -311,3 +311,40 @@ def test_plain_and_normalize_forward_one_call_equals_hook_by_hook(kind, dist, D,
             assert memo['encode']['distance'].shape == (N, K)
         recs.append(rec)
     assert_same(recs[0], recs[1])
+
+
+@pytest.mark.parametrize('metric,D,dtype', [('Cosine', 256, torch.float32), ('L2', 256, torch.float32), ('CosineBF16', 64, torch.float32),
+                                            ('L2', 8, torch.float32), ('Cosine', 768, torch.float32), ('L2', 64, torch.bfloat16)])
+def test_column_pass_over_a_short_list_direct_form_equals_the_pipeline(metric, D, dtype):
+    """vqhip_col_argmin_rows on a short list runs the definition's own fp32 pass over the listed codes instead of the
+    role-swapped proposal pipeline (tuning key 15): identical indices, also against a brute-force float64 column argmin;
+    bf16 latents under L2 keep the pipeline (the pass reads fp32 rows)."""
+    from vector_quantization_amd import _lib, ops
+    N, K = 3072, 4096
+    g = torch.Generator(device='cuda').manual_seed(D)
+    w = torch.randn(K, D, device='cuda', generator=g)
+    x = (w[torch.randint(0, K, (N,), device='cuda', generator=g)] + 0.3 * torch.randn(N, D, device='cuda', generator=g)).to(dtype)
+    p = torch.full((K,), 1.0 / K, device='cuda')
+    listed = torch.randperm(K, device='cuda', generator=g)[:57].sort().values
+    p[listed] = 0.0
+    rows, slot, count = ops.cvq_rows(p, K, 0.99, 1e-3)
+    assert int(count) == 57 and torch.equal(rows[:57].long(), listed)
+    if metric.startswith('Cosine'):
+        xq, eq = ops.normalize_rows(x), ops.normalize_rows(w)
+        if metric == 'CosineBF16':
+            xq, eq = xq.bfloat16().float(), eq.bfloat16().float()
+    else:
+        xq, eq = x, w
+    L = _lib.lib()
+    outs = []
+    for direct in (1, 0):
+        L.vqhip_set_tuning(15, direct)
+        outs.append(ops.col_argmin_rows(xq, eq, rows, count, 64, metric)[:57].clone())
+    L.vqhip_set_tuning(15, 1)
+    assert torch.equal(outs[0], outs[1])
+    if metric != 'CosineBF16':
+        xe, ee = xq.double(), eq[listed].double()
+        d = torch.cdist(ee, xe) if metric == 'L2' else 1 - ee @ xe.t()
+        best = d.min(1).values
+        got = d.gather(1, outs[0].reshape(-1, 1)).reshape(-1)
+        assert bool(((got - best).abs() <= 1e-5 * best.abs().clamp_min(1e-3)).all())      # the definition's argmin up to fp32 near-ties

@@ -116,6 +116,9 @@ def run(name, bf16):
     for _ in range(settle):
         eager()
     timed(eager, 'eager')
+    cb0 = q._callbacks.callbacks[0] if len(q._callbacks.callbacks) else None
+    if getattr(cb0, 'last_exchange_rows', None) is not None:
+        print(f'{name:9s}          codes listed for an anchor in the last step: {cb0.last_exchange_rows} of {K}')
     if os.environ.get('VQ_TRAIN_NO_GRAPH') == '1':
         return
     from vector_quantization_amd.graphs import GraphedQuantizer

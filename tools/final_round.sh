@@ -10,6 +10,7 @@ bash tools/prof_bench.sh ${tag}_bench_profiled --no-cpu-baseline --min-seconds 0
 bash tools/pmc_passes.sh ${tag}_pmc > $o/${tag}_pmc.txt 2>&1; tail -3 $o/${tag}_pmc.txt | cut -c1-300
 python bench.py --workload cvq --no-cpu-baseline --min-seconds 3 > $o/${tag}_cvq.json 2>> $o/${tag}_bench.err; echo "cvq rc=$?"
 python bench.py --workload cvq --images 256 --no-cpu-baseline --min-seconds 3 > $o/${tag}_cvq256.json 2>> $o/${tag}_bench.err; echo "cvq256 rc=$?"
+python bench.py --workload vqkd --no-cpu-baseline --min-seconds 3 > $o/${tag}_vqkd.json 2>> $o/${tag}_bench.err; echo "vqkd rc=$?"
 python bench.py --workload tokenize --no-cpu-baseline > $o/${tag}_tokenize.json 2>> $o/${tag}_bench.err; echo "tokenize rc=$?"
 python bench.py --images 32 --no-cpu-baseline --min-seconds 3 > $o/${tag}_bench_32img.json 2>> $o/${tag}_bench.err; echo "32img rc=$?"
 python bench.py --images 256 --no-cpu-baseline --min-seconds 3 > $o/${tag}_bench_256img.json 2>> $o/${tag}_bench.err; echo "256img rc=$?"
@@ -27,3 +28,6 @@ bash tools/pmc_shape.sh ${tag}_tok_pmc 524288 16384 8 Cosine > $o/${tag}_tok_pmc
 # RCCL at world size 1: the test, then the A/B of the two all-reduce routes
 timeout 900 python -m pytest tests/test_gpu_rccl.py -q > $o/${tag}_rccl_test.log 2>&1; echo "rccl test rc=$?"
 bash tools/rccl_ws1_ab.sh ${tag}_rccl_ab 3 > $o/${tag}_rccl_ab.txt 2>&1; cat $o/${tag}_rccl_ab.txt
+# round 5: training steps at the per-rank shapes of the shipped configs (eager one-call and graph-replayed) and their per-launch timelines
+python tools/bench_train_shapes.py cvq vqkd cluster llamagen cvq64k 2>&1 | grep "ms per step" > $o/${tag}_train_shapes.txt; cat $o/${tag}_train_shapes.txt
+(bash tools/timeline_train.sh ${tag}_tl_cvq cvq vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_vqkd vqkd vqkd_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_cluster cluster vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_llamagen llamagen normalize_bwd_kernel) > $o/${tag}_train_timelines.txt 2>&1

@@ -104,6 +104,7 @@ static std::atomic<int> g_tune_fused_decide{2};
 // whatever the slice count (a launch less on a chain of ~5 us launches: 12 images -2.6 %, 32 images -0.5 %, tools/ab_small_batch.py;
 // at 256 images and more the last-arriving workgroup's merge is the longer tail)
 #define VQ_FUSED_DECIDE_MAX_N 16384
+static std::atomic<int> g_tune_col_direct{1};   // key 15: 0 = a short list of codes takes the proposal pipeline like a long one (A/B; results unchanged)
 static std::atomic<int> g_tune_map256{1};   // key 13: 0 = maps of 256-position images keep the 64-token tiles of gather_ste_map_kernel (A/B; results unchanged)
 static std::atomic<int> g_tune_force_exact{0};   // key 12 (verification aid): the first V rows of a batch also take the whole-codebook fp32 pass
 static std::atomic<int> g_tune_w32{1};      // key 11: 0 = D <= 16 keeps the 16x16x32 proposal kernel (A/B; results unchanged)
@@ -804,12 +805,63 @@ int vqhip_col_argmin(const void *x, int x_dtype, const float *e, int64_t N, int6
     return VQHIP_OK;
 }
 
+// ---- the column pass over a SHORT list, directly in fp32 ----------------------------------------------------------------
+// NearestAnchor over the listed codes is the proposal pipeline with the roles swapped: 5 launches, ~65 us at 3072 tokens x 256
+// dims (83 at 6272 x 768) however few codes are listed — and a CVQ-VAE run in its steady state lists a few dozen.  For such a
+// list the whole-codebook fp32 pass of the pipeline (exact_kernel: the oracle's k-ordered fma chains, the definition itself)
+// IS the cheaper way to the same indices: listed rows x all tokens, one launch behind a tiny one that arms the keys.
+// Limit: the pass's work items (32 listed rows x 128 tokens each, a chain of D/2 dependent fp32 MFMAs of 64 cycles) times D —
+// up to about one item per SIMD of the chip at D = 256 the pass is one chain long (4-12 us); beyond, the proposal pipeline wins.
+#ifndef VQ_COL_DIRECT_MAX_WORK
+#define VQ_COL_DIRECT_MAX_WORK (1ll << 18)
+#endif
+static inline int64_t col_direct_bytes(int64_t N, int64_t cap, int D, int64_t K) {
+    (void)cap; (void)D;
+    return (K * 8 + 1023) / 1024 * 1024 + 1024 + (N * 4 + 1023) / 1024 * 1024 + (K * 4 + 1023) / 1024 * 1024;
+}
+static bool col_direct_ok(int x_dtype, int metric, int64_t cap, int64_t N, int64_t K, int D, int64_t ws_bytes) {
+    if (!g_tune_col_direct.load() || cap <= 0 || (D % 4) != 0) return false;
+    if (metric == VQHIP_METRIC_L2 && x_dtype != VQHIP_DTYPE_F32) return false;        // the pass reads the tokens as fp32 rows
+    if (((cap + 31) / 32) * ((N + 127) / 128) * (int64_t)D > VQ_COL_DIRECT_MAX_WORK) return false;
+    return ws_bytes >= col_direct_bytes(N, cap, D, K);
+}
+// x: the tokens [N, D] as the exact definition consumes them (fp32), e: the codebook rows [K, D] likewise; tok_norm / row_norm:
+// oracle-order |x_n|^2 [N] / |e_k|^2 [K] where a caller has them already (L2 only; nullable: computed here)
+static int col_rows_direct(const void *x, const float *e, const int32_t *rows, const int32_t *count, int64_t cap, int64_t N,
+                           int64_t K, int D, int metric, int64_t *col_idx, char *ws, const float *tok_norm, const float *row_norm,
+                           hipStream_t s) {
+    u64 *keys = (u64 *)ws;
+    int *ticket = (int *)(ws + (K * 8 + 1023) / 1024 * 1024);
+    float *en = (float *)((char *)ticket + 1024);
+    float *xn = (float *)((char *)en + (N * 4 + 1023) / 1024 * 1024);
+    col_direct_init_kernel<<<(int)((cap + 255) / 256), 256, 0, s>>>(rows, count, cap, keys, ticket);
+    VQ_CHECK_LAUNCH("col_direct_init_kernel");
+    const int m = (metric == VQHIP_METRIC_L2) ? (VQHIP_METRIC_L2 | VQ_METRIC_SWAP) : (VQ_METRIC_DOT | (metric & VQ_METRIC_BF16));
+    if (metric == VQHIP_METRIC_L2) {
+        if (!tok_norm) { if (int rc = vqhip_row_sqnorm(x, VQHIP_DTYPE_F32, N, D, en, s)) return rc; tok_norm = en; }
+        if (!row_norm) { if (int rc = vqhip_row_sqnorm(e, VQHIP_DTYPE_F32, K, D, xn, s)) return rc; row_norm = xn; }
+    }
+    const int64_t ncb = (N + 63) / 64;
+    const int grid = (int)(ncb < 256 ? 256 : (ncb > 1024 ? 1024 : ncb));
+    const int few_max = D <= VQ_FEW_MAX_D ? VQ_EXACT_FEW_MAX : 0;
+    const int lds = few_max ? vq_few_lds_bytes(D) : 0;
+    static LdsCache lds_set;
+    if (int rc = ensure_dyn_lds((const void *)exact_kernel<0>, lds, lds_set)) return rc;
+    // roles swapped: the listed codebook rows are the "rows", the tokens the "codes"
+    exact_kernel<0><<<grid, 256, lds, s>>>(e, (const float *)x, tok_norm, row_norm, K, N, D, m, (const int *)rows, (const int *)count, keys, ticket,
+                                           col_idx, nullptr, few_max, 1);
+    VQ_CHECK_LAUNCH("exact_kernel (direct column pass)");
+    return VQHIP_OK;
+}
+
 int64_t vqhip_col_rows_workspace_bytes(int64_t N, int64_t cap, int D) {
     if (N <= 0 || cap <= 0 || D <= 0 || !vq_coarse_supported(D)) return 0;
     // [pipeline workspace for cap rows against N codes][image of the latents as codes][the listed codebook rows][fp32 copy of bf16 latents]
     const int64_t a = (vq_ws_layout(cap, N, D).total + 1023) / 1024 * 1024;
     const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
     const int64_t c = (cap * (int64_t)D * 4 + 1023) / 1024 * 1024;
+    // (the direct form of a short list, col_rows_direct, lives in the same buffer: 12 K + 4 N bytes — it is taken only where the
+    //  buffer it is handed is large enough for it, which the size below is unless K exceeds ~N D / 2)
     return a + b + c + N * (int64_t)D * 4;
 }
 
@@ -825,6 +877,8 @@ int vqhip_col_argmin_rows(const void *x, int x_dtype, const float *e, const int3
     VQ_NEED("vqhip_col_argmin_rows: ws too small", ws_bytes, vqhip_col_rows_workspace_bytes(N, cap, D));
     hipStream_t s = (hipStream_t)stream;
     char *w = (char *)ws;
+    if (col_direct_ok(x_dtype, metric, cap, N, K, D, ws_bytes))      // a short list: the fp32 pass itself, two launches (four for L2)
+        return col_rows_direct(x, e, rows, count, cap, N, K, D, metric, col_idx, w, nullptr, nullptr, s);
     const int64_t a = (vq_ws_layout(cap, N, D).total + 1023) / 1024 * 1024;
     const int64_t b = (vq_cb_layout(N, D).total + 1023) / 1024 * 1024;
     const int64_t c = (cap * (int64_t)D * 4 + 1023) / 1024 * 1024;
@@ -1534,6 +1588,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 10) g_tune_balance = value != 0;
     else if (key == 11) g_tune_w32 = value != 0;
     else if (key == 13) g_tune_map256 = value != 0;
+    else if (key == 15) g_tune_col_direct = value != 0;
     else if (key == 12) g_tune_force_exact = value > 0 ? (value < 1024 ? value : 1024) : 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

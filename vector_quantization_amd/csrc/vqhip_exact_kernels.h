@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                                                     int metric, const int *__restrict__ row_list,
                                                     const int *__restrict__ nrows_dev, u64 *__restrict__ keys,
                                                     int *__restrict__ ticket, int64_t *__restrict__ fin_idx,
-                                                    int32_t *__restrict__ fin_hist, int few_max) {
+                                                    int32_t *__restrict__ fin_hist, int few_max, int fin_pos = 0) {
     const int64_t nrows = (int64_t)(*nrows_dev);
     if (nrows <= 0) return;
     if (nrows <= few_max) exact_rows_few<DT>(x, e, en_in, xn_in, K, D, metric, row_list, nrows, keys);
@@ -399,12 +399,21 @@ __global__ __launch_bounds__(256) void exact_kernel(const void *__restrict__ x, 
                 const int64_t r = (int64_t)row_list[i];
                 const u64 key = __hip_atomic_load(&keys[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t kk = (uint32_t)(key & 0xFFFFFFFFull);
-                fin_idx[r] = (int64_t)kk;
+                fin_idx[fin_pos ? i : r] = (int64_t)kk;        // fin_pos: by position in the list (the direct column pass)
                 if (fin_hist) atomicAdd(&fin_hist[kk], 1);
             }
         }
         VQ_STAMP(7);
     }
+}
+
+// Front of the direct column pass (vqhip_col_argmin_rows on a short list): the keys of the listed rows start at "no code yet",
+// the arrival ticket at zero.
+__global__ void col_direct_init_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ count, int64_t cap,
+                                       u64 *__restrict__ keys, int *__restrict__ ticket) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) ticket[0] = 0;
+    if (i < cap && i < (int64_t)count[0]) keys[rows[i]] = ~0ull;
 }
 
 // vqhip_set_tuning key 12 (verification aid): rows 0 .. V-1 of the batch join the list of the last-resort pass whatever the

@@ -1,8 +1,10 @@
 """Registers this package's classes over the reference's registry entries (option A).
 
-Usable only where the reference (`vq`) and its framework dependency (`todd`) are importable — neither is in the
-build image, so this module is exercised by construction only: it touches nothing but `Registry.register_`, the
-mechanism the reference's own `custom_imports` modules use (configs/vqgan/custom_imports.py:1-3).
+Usable where the reference (`vq`) and its framework dependency (`todd`) are importable.  It touches nothing but
+`Registry.register_`, the mechanism the reference's own `custom_imports` modules use (configs/vqgan/custom_imports.py:1-3),
+and is executed against the reference's REAL registry classes in the build container
+(tests/test_reference_pin.py::test_register_into_reference_registries: the reference's files loaded by oracle/ref_import.py
+behind a structure-only stand-in for the un-vendored todd).
 """
 from __future__ import annotations
 
