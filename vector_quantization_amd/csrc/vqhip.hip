@@ -347,6 +347,23 @@ static int run_exact_tiled(const void *x, int x_dtype, const float *e, const flo
     return VQHIP_OK;
 }
 
+// The few-rows (VALU) form of exact_kernel stages its operands in dynamic LDS: a 64 KiB ring + 64 D bytes.  The request applies to
+// the LAUNCH, i.e. also when the device-side count picks the MFMA form: at D > 512 (96 KiB) that would leave the MFMA form one
+// workgroup per CU, and a part with less LDS per workgroup than asked for would refuse the launch — so the form is offered only
+// where the request stays within 96 KiB and within what the device grants a workgroup.
+static int exact_few_max(int D) {
+    if (D > 512 || D > VQ_FEW_MAX_D) return 0;
+    static std::atomic<int> lds_limit{-1};
+    int lim = lds_limit.load(std::memory_order_relaxed);
+    if (lim < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 65536;
+        lim = v;
+        lds_limit.store(lim);
+    }
+    return vq_few_lds_bytes(D) <= lim ? VQ_EXACT_FEW_MAX : 0;
+}
+
 static int run_exact_rows(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K, int D,
                           int metric, const int *row_list, const int *nrows_dev, u64 *keys, int *ticket, int64_t *idx,
                           int32_t *hist, hipStream_t s) {
@@ -355,7 +372,7 @@ static int run_exact_rows(const void *x, int x_dtype, const float *e, const floa
     const int64_t ncb = (K + 63) / 64;           // work items of the few-rows form per 16 listed rows
     const int grid = (int)(ncb < 256 ? 256 : (ncb > 1024 ? 1024 : ncb));
     if (D % 4) return fail(VQHIP_EINVAL, "exact_kernel: D % 4 != 0 (the proposal route has D % 8 == 0)");
-    const int few_max = D <= VQ_FEW_MAX_D ? VQ_EXACT_FEW_MAX : 0;
+    const int few_max = exact_few_max(D);
     const int lds = few_max ? vq_few_lds_bytes(D) : 0;
     static LdsCache sets[2];
     const int bf = x_dtype == VQHIP_DTYPE_F32 ? 0 : 1;
@@ -843,7 +860,7 @@ static int col_rows_direct(const void *x, const float *e, const int32_t *rows, c
     }
     const int64_t ncb = (N + 63) / 64;
     const int grid = (int)(ncb < 256 ? 256 : (ncb > 1024 ? 1024 : ncb));
-    const int few_max = D <= VQ_FEW_MAX_D ? VQ_EXACT_FEW_MAX : 0;
+    const int few_max = exact_few_max(D);
     const int lds = few_max ? vq_few_lds_bytes(D) : 0;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)exact_kernel<0>, lds, lds_set)) return rc;
