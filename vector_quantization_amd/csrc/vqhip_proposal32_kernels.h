@@ -76,7 +76,10 @@ struct VqGroupLists { int *bcnt; uint32_t *blist; char *bfrag; float *rece2; int
 // request in identify32_kernel — GT MFMAs on 32 requests at a time — and nothing in second-pass rows: a lane identifies ONE
 // candidate whatever the group size, everything else it has seen is a bound either way.
 template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS = 1, int GT = 1>
-__global__ __launch_bounds__(WAVES * 64, 4) void coarse32_kernel(
+#ifndef VQ_W32_TT2_OCC
+#define VQ_W32_TT2_OCC 4        // waves per SIMD the two-wide-tile form (>= 262 144 rows) is compiled for (A/B: 3)
+#endif
+__global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coarse32_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
     const float *__restrict__ rho2, int Dp, int metric, const int *__restrict__ n_dev, VqGroupLists grp, int pad_stage, int tpb) {
