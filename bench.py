@@ -76,6 +76,9 @@ def parse():
     ap.add_argument('--min-seconds', type=float, default=8.0,
                     help='repeat the K-step block until this much timed GPU work has accumulated (0: one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bind', choices=('auto', 'on', 'off'), default='auto',
+                    help='pin the rank to one L3 slice of its GPU\'s NUMA node (vector_quantization_amd/affinity.py). auto: on for the '
+                         'host-sensitive per-rank training workloads (cvq, vqkd), off for the GPU-bound ones')
     ap.add_argument('--no-verify', action='store_true', help='skip the parity self-check after the timed region')
     ap.add_argument('--no-cvq', action='store_true', help='world > 1, vqgan workload: skip the communicating cvq block')
     return ap.parse_args()
@@ -224,6 +227,14 @@ class Bench:
             else:
                 dist.init_process_group('nccl', device_id=self.dev)
         self.coll_dev = 'cpu' if self.share_gpu else self.dev
+        # host-thread placement (a launcher's job, done here because the rank knows its device only now): see affinity.py
+        self.binding = None
+        want = getattr(args, 'bind', 'off')
+        if want == 'on' or (want == 'auto' and getattr(args, 'workload', '') in ('cvq', 'vqkd')):
+            from vector_quantization_amd import affinity
+            torch.cuda.init()
+            self.binding = affinity.bind_rank(local_rank, int(os.environ.get('LOCAL_RANK', '0')), probe=True,
+                                              world_on_node=int(os.environ.get('LOCAL_WORLD_SIZE', str(self.world))))
         # ranks that really take part in the collectives (all-reduce of ones)
         self.rccl_ranks = 1
         if self.distributed:
@@ -678,6 +689,10 @@ def main():
         if parity is not None:
             out_line['parity'] = parity
         out_line.update(extra)
+        if B.binding is not None:
+            out_line['host_binding'] = {k: B.binding[k] for k in ('cpus', 'numa_local', 'slice', 'slices_on_node')}
+            from vector_quantization_amd import affinity
+            affinity.restore(B.binding['previous'])              # the CPU baseline below gets every core back
         if not args.no_cpu_baseline and world == 1:          # reported once, at N=1 (rank 0's host cores)
             out_line['cpu_baseline'] = cpu_baseline()
         emit(json.dumps(out_line))

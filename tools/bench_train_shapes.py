@@ -9,8 +9,9 @@
 One step = forward (encode, codebook update of the callback, decode, loss) + backward from a given upstream gradient of
 the straight-through output, on fresh latents every step (a pool drawn around the codebook rows, as bench.py's cvq block).
 Per shape: eager ms per step back to back, the time after which the HOST has issued a step (host-bound when the two
-agree), and the same step replayed from HIP graphs (GraphedQuantizer).  usage: bench_train_shapes.py [names...] [--bf16]
-VQ_TRAIN_STEPS / VQ_TRAIN_SETTLE override the step counts; VQ_TRAIN_NO_GRAPH=1 skips the graphed leg."""
+agree), and the same step replayed from HIP graphs (GraphedQuantizer).  usage: bench_train_shapes.py [names...] [--bf16] [--no-bind]
+VQ_TRAIN_STEPS / VQ_TRAIN_SETTLE / VQ_TRAIN_POOL override the step counts and the number of pooled batches; VQ_TRAIN_NO_GRAPH=1 skips
+the graphed leg."""
 import functools
 import os
 import sys
@@ -67,7 +68,7 @@ def run(name, bf16):
     dev = torch.device('cuda', 0)
     g = torch.Generator(device=dev).manual_seed(3407)
     w = torch.nn.functional.normalize(torch.randn(K, D, device=dev, generator=g))
-    npool = max(8, min(64, (1 << 24) // (N * D)))
+    npool = int(os.environ.get('VQ_TRAIN_POOL', '0')) or max(8, min(64, (1 << 24) // (N * D)))
     pool = []
     for _ in range(npool):
         t = w[torch.randint(0, K, (N,), device=dev, generator=g)] + 0.05 * torch.randn(N, D, device=dev, generator=g)
@@ -136,5 +137,10 @@ def run(name, bf16):
 if __name__ == '__main__':
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     bf16 = '--bf16' in sys.argv
+    if '--no-bind' not in sys.argv:       # these steps are as much host work as GPU work: one L3 slice of the GPU's NUMA node (affinity.py)
+        from vector_quantization_amd import affinity
+        torch.cuda.init()
+        info = affinity.bind_rank(0, 0, probe=True)
+        print(f'host threads bound to CPUs {info["cpus"]} (GPU-local NUMA node: {info["numa_local"]})' if info else 'host threads: not bound')
     for name in (args or ['cvq', 'vqkd', 'cluster', 'llamagen']):
         run(name, bf16)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Where the time of a SHORT proposal pass goes: a diagnostic build stamps s_memrealtime (100 MHz) at seven points of every
+workgroup of coarse_kernel (tools/build_exp.sh phase -DVQ_PHASE_STAMPS):
+
+    VQHIP_LIB=build/exp/libvqhip_phase.so python tools/phase_stamps.py N K D [L2|Cosine] [bf16|fp32]
+
+entry | first stages requested (token fragments requested, margins computed) | first barrier passed (first stage landed) |
+stream done | records stored and drained | ticket drawn | end (the workgroup that completes a token block also decides its rows).
+Printed per point: microseconds after the FIRST workgroup's entry — minimum, median, maximum over the workgroups — next to the
+kernel's duration by HIP events on the same launches."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vector_quantization_amd import _lib, ops
+
+N, K, D = (int(a) for a in sys.argv[1:4])
+metric = sys.argv[4] if len(sys.argv) > 4 else 'L2'
+dt = sys.argv[5] if len(sys.argv) > 5 else 'fp32'
+g = torch.Generator(device='cuda').manual_seed(3407)
+w = torch.randn(K, D, device='cuda', generator=g)
+if metric != 'L2':
+    w = torch.nn.functional.normalize(w)
+x = w[torch.randint(0, K, (N,), device='cuda', generator=g)] + 0.05 * torch.randn(N, D, device='cuda', generator=g)
+if dt == 'bf16':
+    x = x.bfloat16()
+L = _lib.lib()
+fn = getattr(ctypes.CDLL(_lib.LIB_PATH), 'vqhip_debug_phase_stamps', None)
+if fn is None:
+    sys.exit('this library has no phase stamps: tools/build_exp.sh phase -DVQ_PHASE_STAMPS, then VQHIP_LIB=build/exp/libvqhip_phase.so')
+cb = ops.prepare_codebook(w, metric)
+for _ in range(20):
+    ops.argmin(x, cb)
+torch.cuda.synchronize()
+L.vqhip_profile_enable(1)
+reps = 50
+for _ in range(reps):
+    ops.argmin(x, cb)
+torch.cuda.synchronize()
+ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+L.vqhip_profile_collect(ctypes.byref(ms), ctypes.byref(cnt))
+L.vqhip_profile_enable(0)
+slots = 4096
+buf = (ctypes.c_ulonglong * (8 * slots))()
+fn.restype = ctypes.c_int
+assert fn(buf, slots) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(slots, 8).astype(np.int64)
+a = a[a[:, 0] > 0]
+# stale slots of earlier, larger launches: keep the workgroups whose entry lies within 1 ms of the latest entry
+a = a[a[:, 0] > a[:, 0].max() - 100000]
+t0 = a[:, 0].min()
+names = ['entry', 'first stages requested', 'first barrier passed', 'stream done', 'records stored', 'ticket drawn', 'end']
+print(f'{N} x {K} x {D} {metric} {dt}: {len(a)} workgroups; proposal kernel {ms.value / max(1, cnt.value) * 1e3:.1f} us by HIP events '
+      f'(mean of {cnt.value} launches); {int(a[:, 7].sum())} workgroups decided a token block')
+for i, nm in enumerate(names):
+    col = a[:, i]
+    ok = col > 0
+    if not ok.any():
+        print(f'  {nm:24s}: not stamped (decision stage in its own launch)')
+        continue
+    us = (col[ok] - t0) / 100.0
+    print(f'  {nm:24s}: min {us.min():6.2f}  median {np.median(us):6.2f}  max {us.max():6.2f} us after the first entry')
+d = (a[:, 3] - a[:, 2]) / 100.0
+print(f'  stream (first barrier -> done) per workgroup: min {d.min():.2f} median {np.median(d):.2f} max {d.max():.2f} us')
+dec = a[a[:, 7] == 1]
+if len(dec) and (dec[:, 5] > 0).all():
+    dd = (dec[:, 6] - dec[:, 5]) / 100.0
+    print(f'  decision stage of the deciding workgroups: min {dd.min():.2f} median {np.median(dd):.2f} max {dd.max():.2f} us')

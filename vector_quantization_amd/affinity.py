@@ -1,0 +1,159 @@
+"""Host-thread placement for a rank (launcher-side helper; nothing in the library calls it on its own).
+
+A per-rank training step at the reference's shipped batch sizes (3 072 - 12 544 tokens, configs/*/interface.py) is 0.1 - 0.3 ms
+of GPU work enqueued by 0.1 - 0.2 ms of host work: the Python thread, the HIP runtime's helper threads and autograd's device
+thread hand the step to one another several times.  Left to the scheduler on a two-socket host they land on arbitrary cores —
+measured on the 2 x 64-core EPYC boxes of this pool (profiles/r05_host_placement.txt): the SAME CVQ-VAE step runs at 0.193 -
+0.205 ms when the process stays inside one L3 slice (one CCX: 8 cores + their SMT siblings) and at 0.30 - 0.35 ms when it
+happens to sit on a hyperthread whose sibling is busy or its threads are spread over CCXs, switching between the two at random
+times within one process.  `bind_rank` pins the calling process (every existing thread, and through inheritance every later
+one) to one L3 slice of the NUMA node the GPU hangs off; ranks on one node take successive slices.  It is what `numactl
+--physcpubind` / a launcher's `--bind-to l3` does, done from Python because the rank only knows its device after start-up."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Set
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        if '-' in part:
+            lo, hi = part.split('-')
+            out.extend(range(int(lo), int(hi) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def _read(path: str) -> Optional[str]:
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def gpu_local_cpus(device_index: int) -> Optional[List[int]]:
+    """CPUs of the NUMA node the GPU's PCIe function hangs off (sysfs `local_cpulist`), or None when the topology cannot be
+    read (containers without /sys/class/drm, non-Linux)."""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id      # int; with domain / device below
+        dom = getattr(torch.cuda.get_device_properties(device_index), 'pci_domain_id', 0)
+        dev = getattr(torch.cuda.get_device_properties(device_index), 'pci_device_id', 0)
+        txt = _read(f'/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/local_cpulist')
+        if txt and txt.strip():
+            return _parse_cpulist(txt)
+    except Exception:                                                        # noqa: BLE001 - placement is best effort
+        pass
+    # no PCI address from torch: the AMD render nodes in PCI order (HIP's default enumeration order)
+    try:
+        nodes = []
+        for name in os.listdir('/sys/class/drm'):
+            if not name.startswith('renderD'):
+                continue
+            dev = os.path.realpath(f'/sys/class/drm/{name}/device')
+            if (_read(dev + '/vendor') or '').strip() == '0x1002':
+                nodes.append(dev)
+        nodes.sort()
+        if device_index < len(nodes):
+            txt = _read(nodes[device_index] + '/local_cpulist')
+            if txt and txt.strip():
+                return _parse_cpulist(txt)
+    except OSError:
+        pass
+    return None
+
+
+def l3_slices(cpus: Set[int]) -> List[List[int]]:
+    """The L3 slices (lists of logical CPUs that share a last-level cache) covering `cpus`, in CPU order, each restricted to
+    `cpus`; one slice holding everything when sysfs has no cache topology."""
+    seen: Set[int] = set()
+    out: List[List[int]] = []
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        txt = _read(f'/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list')
+        group = [g for g in (_parse_cpulist(txt) if txt else []) if g in cpus] or [c]
+        if not txt:
+            group = sorted(cpus - seen)
+        out.append(group)
+        seen.update(group)
+    return out
+
+
+def set_process_affinity(cpus: Set[int]) -> int:
+    """sched_setaffinity for EVERY thread of this process (the HIP runtime and torch start helper threads early; new threads
+    inherit their creator's mask).  Returns the number of threads moved."""
+    n = 0
+    try:
+        tids = [int(t) for t in os.listdir('/proc/self/task')]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            n += 1
+        except OSError:                      # a thread that ended meanwhile
+            pass
+    return n
+
+
+def _spin_seconds(n: int = 60000) -> float:
+    """A fixed piece of single-threaded work: slower on a core whose SMT sibling (or the core itself) is busy with someone else."""
+    import time
+    t0 = time.perf_counter()
+    a = 0
+    for i in range(n):
+        a += i & 7
+    return time.perf_counter() - t0
+
+
+def bind_rank(device_index: int = 0, local_rank: int = 0, slices: int = 1, probe: bool = False, world_on_node: int = 1) -> Optional[dict]:
+    """Pin this process to `slices` L3 slice(s) of the GPU's NUMA node (the `local_rank`-th group of them, wrapping).  Returns a
+    description {cpus, numa_local, slice, previous} for logs, or None when nothing could be done (then nothing was changed).
+    `restore(previous)` undoes it, e.g. in front of a CPU-side computation that wants every core.
+    probe: on a machine shared with other jobs the rank's own slice may be the busy one — time a few milliseconds of fixed work
+    on each slice of the rank's share of the node (slices local_rank, local_rank + world_on_node, ...) and take the fastest."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    allowed = set(os.sched_getaffinity(0))
+    local = gpu_local_cpus(device_index)
+    pool = (set(local) & allowed) if local else set()
+    numa_local = bool(pool)
+    if not pool:
+        pool = allowed
+    groups = l3_slices(pool)
+    if not groups:
+        return None
+    per = max(1, int(slices))
+    start = (local_rank * per) % len(groups)
+    if probe and per == 1 and len(groups) > max(1, world_on_node):
+        best = None
+        for cand in range(local_rank % max(1, world_on_node), len(groups), max(1, world_on_node)):
+            try:
+                os.sched_setaffinity(0, set(groups[cand]))
+            except OSError:
+                continue
+            _spin_seconds(5000)
+            t = min(_spin_seconds(), _spin_seconds())
+            if best is None or t < best[0]:
+                best = (t, cand)
+        os.sched_setaffinity(0, allowed)
+        if best is not None:
+            start = best[1]
+    chosen: Set[int] = set()
+    for i in range(per):
+        chosen.update(groups[(start + i) % len(groups)])
+    if not chosen:
+        return None
+    set_process_affinity(chosen)
+    return {'cpus': sorted(chosen), 'numa_local': numa_local, 'slice': start, 'slices_on_node': len(groups), 'previous': sorted(allowed)}
+
+
+def restore(previous) -> None:
+    if previous:
+        set_process_affinity(set(previous))

@@ -117,7 +117,7 @@ template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = fal
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
                              const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
-    constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
+    constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES + VQ_STAGE_LDS_EXTRA;
     auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, NOAUX, GROUPS>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
@@ -1590,6 +1590,25 @@ int vqhip_debug_clock_stamps(unsigned long long *out_host, int n) {
     if (!out_host || n <= 0 || n > VQ_CLOCK_SLOTS) return fail(VQHIP_EINVAL, "vqhip_debug_clock_stamps: bad argument");
     VQ_HIP(hipDeviceSynchronize());
     VQ_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vq_clock_dbg), (size_t)n * 16, 0, hipMemcpyDeviceToHost));
+    return VQHIP_OK;
+}
+#endif
+
+#ifdef VQ_STAGE_STAMPS
+// diagnostic builds only (tools/stage_stamps.py): the per-iteration stamps of the first workgroups of the last coarse_kernel launch
+int vqhip_debug_stage_stamps(unsigned long long *out_host, int wgs) {
+    if (!out_host || wgs <= 0 || wgs > VQ_STAGE_WGS) return fail(VQHIP_EINVAL, "vqhip_debug_stage_stamps: bad argument");
+    VQ_HIP(hipDeviceSynchronize());
+    VQ_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vq_stage_dbg), (size_t)wgs * 8 * VQ_STAGE_ITERS * 5 * 8, 0, hipMemcpyDeviceToHost));
+    return VQHIP_OK;
+}
+#endif
+#ifdef VQ_PHASE_STAMPS
+// diagnostic builds only (tools/phase_stamps.py): the per-workgroup phase stamps of the last coarse_kernel launch
+int vqhip_debug_phase_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n <= 0 || n > VQ_PHASE_SLOTS) return fail(VQHIP_EINVAL, "vqhip_debug_phase_stamps: bad argument");
+    VQ_HIP(hipDeviceSynchronize());
+    VQ_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vq_phase_dbg), (size_t)n * 64, 0, hipMemcpyDeviceToHost));
     return VQHIP_OK;
 }
 #endif

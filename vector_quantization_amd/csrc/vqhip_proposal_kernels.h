@@ -71,6 +71,30 @@ __device__ __forceinline__ int tile_row16(int e, int lane) { return 16 * (e >> 2
 #define VQ_CLOCK_SLOTS 16384
 __device__ unsigned long long vq_clock_dbg[2 * VQ_CLOCK_SLOTS];
 #endif
+#ifdef VQ_PHASE_STAMPS
+// diagnostic build only (tools/phase_stamps.py): eight absolute s_memrealtime stamps (100 MHz) per workgroup, taken by its first
+// lane — entry, first stages requested, first barrier passed, stream done, records stored, ticket drawn, end
+#define VQ_PHASE_SLOTS 4096
+__device__ unsigned long long vq_phase_dbg[8 * VQ_PHASE_SLOTS];
+#define VQ_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x < VQ_PHASE_SLOTS) vq_phase_dbg[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VQ_PHASE(i) do { } while (0)
+#endif
+#ifdef VQ_STAGE_STAMPS
+// diagnostic build only (tools/stage_stamps.py): s_memtime (shader clock) at five points of every iteration of the stage loop, kept in
+// LDS behind the ring and dumped after the loop: [workgroup < 64][wave < 8][iteration < 24][5]
+#define VQ_STAGE_WGS 64
+#define VQ_STAGE_ITERS 24
+__device__ unsigned long long vq_stage_dbg[VQ_STAGE_WGS * 8 * VQ_STAGE_ITERS * 5];
+#define VQ_STAGE_LDS_EXTRA (8 * VQ_STAGE_ITERS * 5 * 8)
+#define VQ_STAMP(k) do { if (lane == 0 && stamp_it < VQ_STAGE_ITERS) stamp_lds[(wave * VQ_STAGE_ITERS + stamp_it) * 5 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VQ_STAGE_LDS_EXTRA 0
+#define VQ_STAMP(k) do { } while (0)
+#endif
+#ifndef VQ_TICKET_NOFENCE
+#define VQ_TICKET_NOFENCE 1
+#endif
 #ifndef VQ_D32_PLAIN_OCC
 #define VQ_D32_PLAIN_OCC 2
 #endif
@@ -81,6 +105,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
     const float *__restrict__ rho2, int Dp, int metric, VqDecideOut dec, int pad_stage, int tpb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    VQ_PHASE(0);
     static_assert(NSTEP % 2 == 0, "16x16x32 layout: 32-dim k-steps");
     static_assert(!GROUPS || FILTER, "group records are a form of the filtered epilogue");
     constexpr bool GBRANCH = TT >= VQ_GROUP_BRANCH_MIN_TT;
@@ -182,10 +207,15 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
     // size: ring and look-ahead -6 %, the lag another -2 % (lagging the odd waves instead: -1 % less; three ahead
     // without lag: +9 % slower) — MI355X guide, 'Two waves per SIMD', item 9
     constexpr int AHEAD = NBUF >= 3 ? 2 : 1;                 // NBUF == 3 (large D): two ahead, no lag
-    const int lag = (NBUF >= 4 && wave >= WAVES / 2) ? 1 : 0;
+#ifndef VQ_LAG_MIN_STAGES
+#define VQ_LAG_MIN_STAGES 48     // slices shorter than this run without the lag (one iteration less)
+#endif
+    const int lag = (NBUF >= 4 && wave >= WAVES / 2 && st1 - st0 >= VQ_LAG_MIN_STAGES) ? 1 : 0;
     if (st0 < st1) issue_stage(st0, 0);
     if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
+    VQ_PHASE(1);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+    VQ_PHASE(2);
 
     f32x4 accA[2][TT], accB[2][TT];
 #pragma unroll
@@ -205,8 +235,19 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
     // delta s_memtime / delta s_memrealtime x 100 MHz.  The stamps go to a buffer of their own that nothing else reads.
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int64_t it = st0; it < st1 + (NBUF >= 4 ? 1 : 0); ++it) {
+#ifdef VQ_STAGE_STAMPS
+    unsigned long long *stamp_lds = (unsigned long long *)(lds + NBUF * STAGE_BYTES);
+    for (int i = threadIdx.x; i < 8 * VQ_STAGE_ITERS * 5; i += WAVES * 64) stamp_lds[i] = 0;
+#endif
+    for (int64_t it = st0; it < st1 + ((NBUF >= 4 && st1 - st0 >= VQ_LAG_MIN_STAGES) ? 1 : 0); ++it) {
+#ifdef VQ_STAGE_STAMPS
+        const int stamp_it = (int)(it - st0);
+#endif
+        VQ_STAMP(0);
+#ifndef VQ_EXP_NO_DMA            // (timing-only diagnostic build: the ring is never refilled inside the loop)
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+#endif
+        VQ_STAMP(1);
         const int64_t st = it - lag;
         if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
         const int buf = (int)((st - st0) % NBUF);
@@ -250,7 +291,27 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
 #pragma unroll
                 for (int t = 0; t < TT; ++t) t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
             }
-        } else
+        } else {
+        // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets), across the tiles of the stage
+        // (STAGE_PF; off: every tile starts with its own first reads exposed); chunk ch = 2*s32 + c of a tile feeds the TT MFMAs
+        // of code half c at k-step s32
+#ifndef VQ_PF_TT2
+#define VQ_PF_TT2 3
+#endif
+#ifndef VQ_PF_TT4
+#define VQ_PF_TT4 2
+#endif
+#ifndef VQ_CHUNK_SB
+#define VQ_CHUNK_SB 2          // 1: TT <= 2 forms only, 2: every unfiltered form of NSTEP 4..16, 0: off (A/B builds)
+#endif
+#ifndef VQ_STAGE_PF
+#define VQ_STAGE_PF 1
+#endif
+        // (D = 512, NSTEP = 32: measured 2.5 % slower with the chunks held together and the deeper ring — left as it was)
+        constexpr bool CHUNK_SB = NSTEP >= 4 && NSTEP <= 16 && !FILTER && (VQ_CHUNK_SB == 2 || (VQ_CHUNK_SB == 1 && TT <= 2));
+        constexpr int PF = NSTEP <= 32 ? (CHUNK_SB ? (TT <= 2 ? VQ_PF_TT2 : VQ_PF_TT4) : 1) : (NSTEP <= 48 ? 2 : 4);   // deeper where a chunk feeds fewer MFMAs
+        constexpr bool STAGE_PF = (VQ_STAGE_PF != 0) && CHUNK_SB && TPS >= 2;
+        half8 af[PF + 1];
 #pragma unroll
         for (int ti = 0; ti < TPS; ++ti) {
             f32x4 (&cur)[2][TT] = (PIPE && (ti & 1)) ? accB : accA;
@@ -267,30 +328,31 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
             uint32_t old[TT];
 #pragma unroll
             for (int t = 0; t < TT; ++t) old[t] = __float_as_uint(b1[t]);
-            // A fragments PF chunks ahead of the MFMAs that consume them (ring of PF+1 register sets);
-            // chunk ch = 2*s32 + c feeds the TT MFMAs of code half c at k-step s32
-            constexpr int PF = NSTEP <= 32 ? 1 : (NSTEP <= 48 ? 2 : 4);   // deeper where a chunk feeds fewer MFMAs
-            half8 af[PF + 1];
+            // ring slot of chunk ch of tile ti: by its index in the stage (STAGE_PF) or in the tile
+            constexpr int RING = PF + 1;
+            const int g0 = STAGE_PF ? ti * NSTEP : 0;
+            if (!STAGE_PF || ti == 0) {
 #pragma unroll
-            for (int i = 0; i < PF; ++i)
-                if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
+                for (int i = 0; i < PF; ++i)
+                    if (i < NSTEP) af[i] = *(const half8 *)(base + (ti * NSTEP + i) * VQ_CHUNK_BYTES + lane * 16);
+            }
 #pragma unroll
             for (int ch = 0; ch < NSTEP; ++ch) {
 #ifdef VQ_EXP_NO_LDS_READS      // timing-only diagnostic build: the A fragment of every chunk is the register set loaded first (opaque to the compiler)
-                if (ch + PF < NSTEP) { af[(ch + PF) % (PF + 1)] = af[0]; asm volatile("" : "+v"(af[(ch + PF) % (PF + 1)])); }
+                if (ch + PF < NSTEP) { af[(ch + PF) % RING] = af[0]; asm volatile("" : "+v"(af[(ch + PF) % RING])); }
 #else
-                if (ch + PF < NSTEP)
-                    af[(ch + PF) % (PF + 1)] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
+                if (ch + PF < NSTEP || (STAGE_PF && ti + 1 < TPS))
+                    af[(g0 + ch + PF) % RING] = *(const half8 *)(base + (ti * NSTEP + ch + PF) * VQ_CHUNK_BYTES + lane * 16);
 #endif
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     if constexpr (!WITH_AUX) {
                         if (ch < 2) {                      // first k-step of this code half: C = inline constant 0
-                            cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                            cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[(g0 + ch) % RING], xf[t][ch >> 1], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
                             continue;
                         }
                     }
-                    cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ch % (PF + 1)], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
+                    cur[ch & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[(g0 + ch) % RING], xf[t][ch >> 1], cur[ch & 1][t], 0, 0, 0);
                 }
                 if constexpr (FILTER) {
                     // token tile t of the previous code tile: maximum of its 8 elements, one compare, wave-uniform skip
@@ -350,6 +412,10 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
                         b1[t] = vmax(b1[t], v);
                     }
                 }
+                // the statements of a chunk stay together: left alone, hipcc sinks the fragment read of chunk ch + PF down to its
+                // use (ds_read -> s_waitcnt lgkmcnt(0) -> MFMAs: the LDS latency of every chunk exposed, covered only by the
+                // SIMD's other wave)
+                if constexpr (CHUNK_SB) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (!PIPE && !PIPE_H) {   // large D: one tile per stage, epilogue in place (the SIMD's other wave covers it)
 #pragma unroll
@@ -368,12 +434,17 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
                     t1[t] = (__float_as_uint(b1[t]) != old[t]) ? tgp : t1[t];
             }
         }
+        }
       };   // run_stage
+#ifdef VQ_EXP_NO_COMPUTE         // timing-only diagnostic build: the ring, its requests and the barriers alone
+        asm volatile("" :: "v"(xf[0][0]));
+#else
         if constexpr (NOAUX) {
             if (st == (int64_t)pad_stage) run_stage(std::true_type{}); else run_stage(std::false_type{});
         } else {
             run_stage(std::true_type{});
         }
+#endif
         if constexpr (FILTER && (!GROUPS || GBRANCH)) {   // refresh the skip thresholds: best score among the token's four lanes, less the margin
 #pragma unroll
             for (int t = 0; t < TT; ++t) th[t] = quad_rows_max(b1[t]) - mg[t];
@@ -381,8 +452,24 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         // next stage landed (vmcnt(0)) and everybody is done reading this one.  (A barrier that keeps the pieces of the
         // stage requested in this iteration in flight — s_waitcnt vmcnt(pieces) instead of 0 — was measured: 1-3 %
         // slower at D <= 128 and 2x slower at D = 256, profiles/r02_ring_partial_wait.txt; the full drain stays.)
+#ifdef VQ_STAGE_STAMPS
+        VQ_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        VQ_STAMP(3);
         __syncthreads();
+        VQ_STAMP(4);
+#elif defined(VQ_EXP_NO_BARRIER)    // timing-only diagnostic build
+        asm volatile("" ::: "memory");
+#else
+        __syncthreads();
+#endif
     }
+#ifdef VQ_STAGE_STAMPS
+    __syncthreads();
+    if (blockIdx.x < VQ_STAGE_WGS)
+        for (int i = threadIdx.x; i < 8 * VQ_STAGE_ITERS * 5; i += WAVES * 64) vq_stage_dbg[(size_t)blockIdx.x * 8 * VQ_STAGE_ITERS * 5 + i] = stamp_lds[i];
+    __syncthreads();
+#endif
 #ifdef VQ_CLOCK_STAMPS
     {
         const unsigned long long clk_t1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
@@ -393,6 +480,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         }
     }
 #endif
+    VQ_PHASE(3);
     if (PIPE_H && st1 > st0) {   // drain: second half of the last tile
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -519,8 +607,18 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         const int64_t tokn = (tb * tpb + wave * TT + t) * 16 + (lane & 15);
         if (lane < 16 && tokn < N && wave * TT + t < tpb) {
             float *rp = rec + (int64_t)sl * VQ_REC_FIELDS * Np + tokn;
-            rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
-            rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+            if (VQ_TICKET_NOFENCE && dec.idx != nullptr && nslices > 1) {
+                // read by ANOTHER workgroup of this launch (the one that draws the block's last ticket): agent-scope stores, which go
+                // past this XCD's L2 on their own — no write-back of the whole L2 (the release fence) in front of the ticket
+                __hip_atomic_store(rp, r.v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rp + Np, __uint_as_float(r.c1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rp + 2 * Np, r.v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rp + 3 * Np, __uint_as_float(r.c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rp + 4 * Np, r.v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                rp[0] = r.v1; rp[Np] = __uint_as_float(r.c1); rp[2 * Np] = r.v2;
+                rp[3 * Np] = __uint_as_float(r.c2); rp[4 * Np] = r.v3;
+            }
         }
     }
 
@@ -532,13 +630,14 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         int *flags = (int *)lds;                         // the stage ring is free now (first barrier below)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        VQ_PHASE(4);
         if (threadIdx.x == 0) {
             int last = 1;
             if (nslices > 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (every wave drained its record stores before the barrier above; the records are read back with agent-scope loads)
+                if (!VQ_TICKET_NOFENCE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 last = (atomicAdd(&dec.arrive[tb], 1) == nslices - 1) ? 1 : 0;
-                if (last) {
+                if (last && !VQ_TICKET_NOFENCE) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -548,6 +647,10 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
         __syncthreads();
         const bool last = flags[0] != 0;
         __syncthreads();                                 // everybody has read the flag before the LDS words are reused
+        VQ_PHASE(5);
+#ifdef VQ_PHASE_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < VQ_PHASE_SLOTS) vq_phase_dbg[8 * blockIdx.x + 7] = last ? 1 : 0;
+#endif
         if (last) {
             int *wcount = (int *)lds, *wbase = wcount + 3 * 16;
             int64_t n = tb * (int64_t)(tpb * 16) + threadIdx.x;      // tpb*16 <= BM <= WAVES*64 threads: one token per thread
@@ -556,5 +659,6 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
             decide_rows<true>(n, oob, cbst, Dp, metric, nslices, rec, xh2, rho2, Np, dec, wcount, wbase);
         }
     }
+    VQ_PHASE(6);
   }
 }
