@@ -29,5 +29,5 @@ bash tools/pmc_shape.sh ${tag}_tok_pmc 524288 16384 8 Cosine > $o/${tag}_tok_pmc
 timeout 900 python -m pytest tests/test_gpu_rccl.py -q > $o/${tag}_rccl_test.log 2>&1; echo "rccl test rc=$?"
 bash tools/rccl_ws1_ab.sh ${tag}_rccl_ab 3 > $o/${tag}_rccl_ab.txt 2>&1; cat $o/${tag}_rccl_ab.txt
 # round 5: training steps at the per-rank shapes of the shipped configs (eager one-call and graph-replayed) and their per-launch timelines
-python tools/bench_train_shapes.py cvq vqkd cluster llamagen cvq64k 2>&1 | grep "ms per step" > $o/${tag}_train_shapes.txt; cat $o/${tag}_train_shapes.txt
+python tools/bench_train_shapes.py cvq vqkd cluster llamagen cvq64k 2>&1 | grep "ms per step\|bound to\|listed for" > $o/${tag}_train_shapes.txt; cat $o/${tag}_train_shapes.txt
 (bash tools/timeline_train.sh ${tag}_tl_cvq cvq vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_vqkd vqkd vqkd_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_cluster cluster vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_llamagen llamagen normalize_bwd_kernel) > $o/${tag}_train_timelines.txt 2>&1
