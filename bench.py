@@ -60,6 +60,7 @@ if ROOT not in sys.path:
 
 K_CODES, DIM, TOK_PER_IMAGE = 16384, 256, 256
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
+SUSTAINED_F16_RANDOM_TFLOPS = 1768.0    # measured, this pool's MI355X (profiles/r05_mfma_random.txt): reported beside the roofline, never as its peak
 HBM_PEAK_GBS = 8000.0
 EMB = 'torch_nn_modules_sparse_Embedding'
 
@@ -663,7 +664,12 @@ def main():
                     'step_frac': step_tf / MFMA_F16_DENSE_PEAK_TFLOPS,
                     'step_frac_note': 'the same flops over the WHOLE step (ms_per_step: what `value` is), against the same peak',
                     'step_algorithmic_bytes': alg_bytes,
-                    'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
+                    'hbm_frac_algorithmic': alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    # context, NOT the roofline: what the same instruction sustains on this chip when nothing else runs
+                    'measured_ceiling': {'tflops': SUSTAINED_F16_RANDOM_TFLOPS, 'frac_of_it': achieved_tf / SUSTAINED_F16_RANDOM_TFLOPS,
+                                         'what': 'bare v_mfma_f32_16x16x32_f16 on all 1024 SIMDs with N(0,1) fp16 operands held in registers, launches '
+                                                 'of 3 ms: matrix pipe 100 % busy at a shader clock of 1.78 GHz (power management; 2.31-2.40 GHz '
+                                                 'and 2.34-2.43 PFLOP/s on constant operands) - profiles/r05_mfma_random.txt, tools/micro/mfma_random.hip'}}
         if wl in ('cvq', 'vqkd'):
             roofline['kernel_ms_note'] = ('average over the proposal launches of a step: the row pass (N x K) and, when codes are listed, '
                                           'the role-swapped column pass (listed codes x N) — `achieved` prices the row pass only')
