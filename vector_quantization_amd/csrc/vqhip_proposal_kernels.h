@@ -308,10 +308,8 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
 #define VQ_STAGE_PF 1
 #endif
         // (D = 512, NSTEP = 32: measured 2.5 % slower with the chunks held together and the deeper ring — left as it was)
-#ifndef VQ_CHUNK_SB_FILTER
-#define VQ_CHUNK_SB_FILTER 0
-#endif
-        constexpr bool CHUNK_SB = NSTEP >= 4 && NSTEP <= 16 && (!FILTER || VQ_CHUNK_SB_FILTER) && (VQ_CHUNK_SB == 2 || (VQ_CHUNK_SB == 1 && TT <= 2));
+        // (the filtered forms of D = 64 / 128 lose 1-3 % with it and D = 768 / 1024 gain nothing at any ring depth: profiles/r05_ab_stage_loop.txt)
+        constexpr bool CHUNK_SB = NSTEP >= 4 && NSTEP <= 16 && !FILTER && (VQ_CHUNK_SB == 2 || (VQ_CHUNK_SB == 1 && TT <= 2));
         constexpr int PF = NSTEP <= 32 ? (CHUNK_SB ? (TT <= 2 ? VQ_PF_TT2 : VQ_PF_TT4) : 1) : (NSTEP <= 48 ? 2 : 4);   // deeper where a chunk feeds fewer MFMAs
         constexpr bool STAGE_PF = (VQ_STAGE_PF != 0) && CHUNK_SB && TPS >= 2;
         half8 af[PF + 1];
