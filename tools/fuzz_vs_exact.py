@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised campaign on the GPU: vqhip_argmin (fp16 proposals + exact re-rank) against vqhip_argmin_exact (all-fp32
 MFMA, itself bit-equal to the CPU oracle in tests/) at sizes the CPU oracle cannot reach.  Any mismatch is a bug.
-usage: fuzz_vs_exact.py [seconds] [seed]   (VQ_FUZZ_DIMS=8,16: only those D; VQ_FUZZ_FORCE_EXACT=1: see below)"""
+usage: fuzz_vs_exact.py [seconds] [seed]   (VQ_FUZZ_DIMS=8,16: only those D; VQ_FUZZ_SMALL_N=1: 64 .. 16 384 rows against >= 4096 codes;
+VQ_FUZZ_FORCE_EXACT=1: see below)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,6 +22,9 @@ while time.time() < t_end:
     D = DIMS[ri(0, len(DIMS))]
     K = [ri(1, 64), ri(64, 4096), 8192, 16384, ri(4096, 20000)][ri(0, 5)]
     N = [ri(1, 512), ri(512, 70000), 65536, ri(70000, 300000)][ri(0, 4)]
+    if os.environ.get('VQ_FUZZ_SMALL_N') == '1':        # batches that decide inside the proposal kernel over several codebook slices
+        N = ri(64, 16385)
+        K = [8192, 16384, ri(4096, 20000)][ri(0, 3)]
     if N * K * D > 3e12: N = max(1, int(3e12 / (K * D)))
     metric = 'L2' if ri(0, 3) else ('Cosine' if ri(0, 3) else 'CosineBF16')     # CosineBF16: the bf16-autocast semantics (opt-in)
     kind = ri(0, 7)
