@@ -149,9 +149,11 @@ def test_cvq_one_call_in_place_updates_and_external_probability_change():
         assert torch.equal(outs[0][1], other[1])
 
 
-@pytest.mark.parametrize('N', [3000, 40000])                      # 40 000 tokens: the ordered (bit-reproducible) centroid sums
-def test_vqkd_one_call_equals_hook_by_hook(N):
-    K, D = 1024, 32
+# 40 000 tokens: the ordered (bit-reproducible) centroid sums; D = 8 / 16 / 24: the other widths of the L-lanes-per-row front, tail
+# and backward kernels (vqhip_step_kernels.h: 8, 16 and 32 lanes per row, D = 24 leaves lanes of a group idle); D = 64: the wave-per-row forms
+@pytest.mark.parametrize('N,D', [(3000, 32), (40000, 32), (3000, 8), (3000, 16), (3000, 24), (3000, 64)])
+def test_vqkd_one_call_equals_hook_by_hook(N, D):
+    K = 1024
     w0 = synth.unit_rows(synth.rng(8).standard_normal((K, D), dtype=np.float32))
     xs = batches(N, K, D, w0, 4, 34)
     gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) / (N * D)
@@ -166,6 +168,19 @@ def test_vqkd_one_call_equals_hook_by_hook(N):
         q = build(vqkd_cfg(K, D), w0, no_grad_params=True)
         recs.append(run_steps(q, xs[:2], gz, one_call, autocast=True))
     assert_same(recs[0], recs[1], exact_w=(N >= 32768))
+
+
+def test_vqkd_one_call_loss_is_reproducible_bit_for_bit():
+    """The loss of the one-call VQ-KD forward is a fixed-order sum of per-workgroup partials (vqkd_tail_finish): the same step
+    from the same state gives the same bits (above 32 768 tokens the centroid sums are the ordered ones, so the codebooks are too)."""
+    K, D, N = 1024, 32, 40000
+    w0 = synth.unit_rows(synth.rng(8).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 2, 35)
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) / (N * D)
+    runs = [run_steps(build(vqkd_cfg(K, D), w0, no_grad_params=True), xs, gz, True) for _ in range(3)]
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a['loss'], b['loss']) and torch.equal(a['w'], b['w']) and torch.equal(a['gx'], b['gx'])
 
 
 def test_vqkd_one_call_matches_the_reference_fixture_and_its_gradient():

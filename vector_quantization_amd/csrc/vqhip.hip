@@ -424,6 +424,25 @@ int64_t vqhip_codebook_exact_offset(int64_t K, int D) {
     return vq_cb_layout(K, D).off_eexact;
 }
 
+// front of the VQ-KD / NormalizeCallback forwards (vqhip_step_kernels.h): the L-lanes-per-row form at D <= 32
+static int launch_vqkd_front(const float *w_in, float *w_mid, int64_t K, const void *x, int x_dtype, float *xn, int64_t N, int D, float eps,
+                             float *zero, int64_t nzero, int w_passes, hipStream_t s) {
+    if (D <= 32) {
+        const int L = D <= 8 ? 8 : (D <= 16 ? 16 : 32), rpb = 4 * (64 / L);
+        const int kblocks = (int)((K + rpb - 1) / rpb), xblocks = (int)((N + rpb - 1) / rpb);
+#define VQ_FRONT_SMALL(DT, LL) vqkd_front_small_kernel<DT, LL><<<kblocks + xblocks, 256, 0, s>>>(w_in, w_mid, K, x, xn, N, D, eps, kblocks, zero, nzero, w_passes)
+        if (x_dtype == VQHIP_DTYPE_F32) { if (L == 8) VQ_FRONT_SMALL(0, 8); else if (L == 16) VQ_FRONT_SMALL(0, 16); else VQ_FRONT_SMALL(0, 32); }
+        else { if (L == 8) VQ_FRONT_SMALL(1, 8); else if (L == 16) VQ_FRONT_SMALL(1, 16); else VQ_FRONT_SMALL(1, 32); }
+#undef VQ_FRONT_SMALL
+    } else {
+        const int kblocks = (int)((K + 3) / 4), xblocks = (int)((N + 3) / 4);
+        if (x_dtype == VQHIP_DTYPE_F32) vqkd_front_kernel<0><<<kblocks + xblocks, 256, 0, s>>>(w_in, w_mid, K, x, xn, N, D, eps, kblocks, zero, nzero, w_passes);
+        else vqkd_front_kernel<1><<<kblocks + xblocks, 256, 0, s>>>(w_in, w_mid, K, x, xn, N, D, eps, kblocks, zero, nzero, w_passes);
+    }
+    VQ_CHECK_LAUNCH("vqkd_front_kernel");
+    return VQHIP_OK;
+}
+
 int64_t vqhip_codebook_bytes(int64_t K, int D) {
     if (K <= 0 || D <= 0) return 0;
     return vq_cb_layout(K, D).total;
@@ -1305,10 +1324,8 @@ int vqhip_vqkd_forward(vqhip_vqkd_forward_t *a, void *stream) {
             VQ_HIP(hipMemsetAsync(payload, 0, (size_t)nzero * 4, s));
             nzero = 0;
         }
-        const int kblocks = (int)((K + 3) / 4), xblocks = (int)((N + 3) / 4);
-        if (a->x_dtype == VQHIP_DTYPE_F32) vqkd_front_kernel<0><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_mid, K, a->x, a->xn, N, D, 1e-12f, kblocks, payload, nzero);
-        else vqkd_front_kernel<1><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_mid, K, a->x, a->xn, N, D, 1e-12f, kblocks, payload, nzero);
-        VQ_CHECK_LAUNCH("vqkd_front_kernel");
+        if (int rc = launch_vqkd_front(a->w_in, a->w_mid, K, a->x, a->x_dtype, a->xn, N, D, 1e-12f, payload, nzero, 2, s)) return rc;
+        const int xblocks = (int)((N + 3) / 4);             // wave per token: the scatter below
         if (int rc = vqhip_encode_ex(a->xn, VQHIP_DTYPE_F32, a->w_mid, N, K, D, a->metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws,
                                      vq_align1k(vq_ws_layout(N, K, D).total), VQHIP_ENCODE_ZERO_HIST, stream)) return rc;
         const int hb = (int)((K + 255) / 256);
@@ -1333,8 +1350,18 @@ int vqhip_vqkd_forward(vqhip_vqkd_forward_t *a, void *stream) {
         vqkd_update_packed_kernel<<<waves_grid(K, 4), 256, 0, s>>>(a->w_mid, a->w_out, a->packed, K, D, a->ema_decay);
         VQ_CHECK_LAUNCH("vqkd_update_packed_kernel");
         if (a->tail) {
-            int grid = (int)((N + 15) / 16); grid = grid > 256 ? 256 : grid;
-            vqkd_tail_kernel<<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse);
+            // per-workgroup partial sums of the loss (<= 256 doubles): the record area of the encode's workspace, free by now
+            double *tail_partials = (double *)((char *)a->ws + vq_ws_layout(N, K, D).off_rec);
+            if (D <= 32) {                                  // L lanes per token (vqhip_step_kernels.h)
+                const int L = D <= 8 ? 8 : (D <= 16 ? 16 : 32), rpb = 16 * (64 / L);
+                int grid = (int)((N + rpb - 1) / rpb); grid = grid > 256 ? 256 : grid;
+                if (L == 8) vqkd_tail_small_kernel<8><<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse, tail_partials);
+                else if (L == 16) vqkd_tail_small_kernel<16><<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse, tail_partials);
+                else vqkd_tail_small_kernel<32><<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse, tail_partials);
+            } else {
+                int grid = (int)((N + 15) / 16); grid = grid > 256 ? 256 : grid;
+                vqkd_tail_kernel<<<grid, 1024, 0, s>>>(a->xn, a->w_out, a->idx, N, D, 1e-12f, a->z_ste, (double *)a->scratch16, a->mse, tail_partials);
+            }
             VQ_CHECK_LAUNCH("vqkd_tail_kernel");
         }
     }
@@ -1357,10 +1384,7 @@ int vqhip_vq_forward(vqhip_vq_forward_t *a, void *stream) {
     int rows_dtype = a->x_dtype;
     const float *codes = a->w_in;
     if (a->normalize) {
-        const int kblocks = (int)((K + 3) / 4), xblocks = (int)((N + 3) / 4);
-        if (a->x_dtype == VQHIP_DTYPE_F32) vqkd_front_kernel<0><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_out, K, a->x, a->xn, N, D, 1e-12f, kblocks, nullptr, 0, 1);
-        else vqkd_front_kernel<1><<<kblocks + xblocks, 256, 0, s>>>(a->w_in, a->w_out, K, a->x, a->xn, N, D, 1e-12f, kblocks, nullptr, 0, 1);
-        VQ_CHECK_LAUNCH("vqkd_front_kernel");
+        if (int rc = launch_vqkd_front(a->w_in, a->w_out, K, a->x, a->x_dtype, a->xn, N, D, 1e-12f, nullptr, 0, 1, s)) return rc;
         rows = a->xn; rows_dtype = VQHIP_DTYPE_F32; codes = a->w_out;
     }
     if (int rc = vqhip_encode_ex(rows, rows_dtype, codes, N, K, D, a->metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws, a->ws_bytes,
@@ -1375,10 +1399,20 @@ int vqhip_vqkd_backward(const void *x, int x_dtype, const float *xn, const float
     if (!x || !xn || !w || !idx || !grad_x || N < 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: bad argument");
     if (N == 0) return VQHIP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (x_dtype != VQHIP_DTYPE_F32 && x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: x_dtype");
+    if (D <= 32) {                                          // L lanes per token (vqhip_step_kernels.h)
+        const int L = D <= 8 ? 8 : (D <= 16 ? 16 : 32), rpb = 4 * (64 / L);
+        int grid = (int)((N + rpb - 1) / rpb); grid = grid > 2048 ? 2048 : grid;
+#define VQ_BWD_SMALL(DT, LL) vqkd_backward_small_kernel<DT, LL><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x)
+        if (x_dtype == VQHIP_DTYPE_F32) { if (L == 8) VQ_BWD_SMALL(0, 8); else if (L == 16) VQ_BWD_SMALL(0, 16); else VQ_BWD_SMALL(0, 32); }
+        else { if (L == 8) VQ_BWD_SMALL(1, 8); else if (L == 16) VQ_BWD_SMALL(1, 16); else VQ_BWD_SMALL(1, 32); }
+#undef VQ_BWD_SMALL
+        VQ_CHECK_LAUNCH("vqkd_backward_kernel");
+        return VQHIP_OK;
+    }
     int grid = (int)((N + 3) / 4); grid = grid > 2048 ? 2048 : grid;
     if (x_dtype == VQHIP_DTYPE_F32) vqkd_backward_kernel<0><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x);
-    else if (x_dtype == VQHIP_DTYPE_BF16) vqkd_backward_kernel<1><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x);
-    else return fail(VQHIP_EINVAL, "vqhip_vqkd_backward: x_dtype");
+    else vqkd_backward_kernel<1><<<grid, 256, 0, s>>>(x, xn, w, idx, N, D, 1e-12f, g_zste, g_loss, grad_x);
     VQ_CHECK_LAUNCH("vqkd_backward_kernel");
     return VQHIP_OK;
 }

@@ -53,6 +53,43 @@ __global__ __launch_bounds__(256) void vqkd_front_kernel(const float *__restrict
     for (int d = lane; d < D; d += 64) xn[n * D + d] = load_elem<DT>(x, n * D + d) / den;
 }
 
+// The same launch at D <= 32 (the VQ-KD and LlamaGen shapes): L lanes per row, 64 / L rows per wave instead of a wave per row —
+// at D = 32 half of the lanes of the wave-per-row form idle, at D = 8 seven of eight, and the launch is 20 000 waves of two or three
+// dependent passes each (8.6 us for 8192 + 12 544 rows of 32 dims: 2.6 MB).  The halving tree runs inside the L-lane group: the very
+// additions of the full-wave tree, whose upper levels only add the zeros of the lanes past D (row_small_kernel) — bit-identical.
+template <int DT, int L>
+__global__ __launch_bounds__(256) void vqkd_front_small_kernel(const float *__restrict__ w_in, float *__restrict__ w_mid, int64_t K,
+                                                               const void *__restrict__ x, float *__restrict__ xn, int64_t N, int D,
+                                                               float eps, int kblocks, float *__restrict__ zero, int64_t nzero,
+                                                               int w_passes) {
+    constexpr int RPW = 64 / L, RPB = 4 * RPW;             // rows per wave / per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nzero; i += (int64_t)gridDim.x * 1024)
+        *(float4 *)(zero + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int d = lane % L, rw = lane / L;
+    auto group_sum = [](float p) {
+#pragma unroll
+        for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        return p;
+    };
+    if ((int)blockIdx.x < kblocks) {
+        const int64_t k = (int64_t)blockIdx.x * RPB + wave * RPW + rw;
+        const bool live = k < K && d < D;
+        const float a = live ? w_in[k * D + d] : 0.0f;
+        const float n1 = sqrtf(group_sum(fmaf(a, a, 0.0f))), den1 = (n1 < eps) ? eps : n1;
+        const float y = a / den1;
+        if (w_passes == 1) { if (live) w_mid[k * D + d] = y; return; }
+        const float n2 = sqrtf(group_sum(live ? fmaf(y, y, 0.0f) : 0.0f)), den2 = (n2 < eps) ? eps : n2;
+        if (live) w_mid[k * D + d] = y / den2;
+        return;
+    }
+    const int64_t n = (int64_t)(blockIdx.x - kblocks) * RPB + wave * RPW + rw;
+    const bool live = n < N && d < D;
+    const float a = live ? load_elem<DT>(x, n * D + d) : 0.0f;
+    const float nrm = sqrtf(group_sum(fmaf(a, a, 0.0f))), den = (nrm < eps) ? eps : nrm;
+    if (live) xn[n * D + d] = a / den;
+}
+
 // Header of the packed exchange buffer from the epilogue histogram (blocks [0, header_blocks)) and the centroid sums
 // payload[idx[n]] += F.normalize(xn[n]) (callbacks.py:124: the latents, already normalised once by NormalizeCallback, are
 // normalised again; computed here from xn in the oracle's order — NOT read from the encode's xq, which holds bf16-rounded
@@ -124,15 +161,49 @@ __global__ void vqkd_update_packed_kernel(const float *w_in, float *w_out, const
     }
 }
 
+// End of the tail kernels: the workgroup's 16 wave sums -> one partial per workgroup in `partials` (agent-scope store, drained),
+// ONE ticket atomic per workgroup; the workgroup that draws the last ticket adds the partials in a fixed order (lane i takes
+// partials i, i + 64, ...; halving tree) — the loss is bit-reproducible from run to run, which the earlier form (a double-
+// precision atomicAdd per workgroup on one address, then the ticket: two serialised same-address atomics per workgroup, 4 us of
+// a 10 us kernel at 196 workgroups) was not.  `sse`: the 16-byte zeroed scratch (ticket at sse + 1), left zeroed.
+__device__ __forceinline__ void vqkd_tail_finish(double s, double *red, double *partials, double *sse, float *mse, int64_t N, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int last_s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i];
+        __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last_s = (atomicAdd((int *)(sse + 1), 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (last_s && wave == 0) {
+        double t = 0.0;
+        for (int i = lane; i < (int)gridDim.x; i += 64) t += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) {
+            const float mean = (float)(t / ((double)N * (double)D));
+            mse[0] = mean; mse[1] = mean; mse[2] = 0.0f; mse[3] = 0.0f;
+            __hip_atomic_store((int *)(sse + 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Tail of the VQ-KD forward, wave per token (grid-stride), 16 waves per workgroup and at most 256 workgroups (the double sum and
 // the ticket are two same-address atomics per WORKGROUP: 1024 workgroups of 4 waves made this a 33 us kernel, 16 x 256 a 6 us one):
 //   z = w[idx[n]];  z_ste = xn + (z - xn)  (utils/ste.py:10);  loss term: (F.normalize(z) - F.normalize(xn))^2
 //   mse[0] = mean over N*D (CommitmentLoss with mse norm=True, losses.py:37,62), mse[1..3] = mse[0], 0, 0
-// `sse`: the 16-byte zeroed scratch of gather_ste_loss_kernel (double sum + ticket), left zeroed.
+// `sse`: the 16-byte zeroed scratch of gather_ste_loss_kernel (ticket), left zeroed; `partials`: >= gridDim.x doubles (vqkd_tail_finish).
 __global__ __launch_bounds__(1024) void vqkd_tail_kernel(const float *__restrict__ xn,
                                                          const float *__restrict__ w, const int64_t *__restrict__ idx, int64_t N,
                                                          int D, float eps, float *__restrict__ z_ste, double *sse,
-                                                         float *__restrict__ mse) {
+                                                         float *__restrict__ mse, double *__restrict__ partials) {
     __shared__ double red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0;
@@ -151,25 +222,7 @@ __global__ __launch_bounds__(1024) void vqkd_tail_kernel(const float *__restrict
             s += (double)(df * df);
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i];
-        int *ticket = (int *)(sse + 1);
-        const double before = atomicAdd(sse, t);              // (returning atomic: complete before the ticket is taken)
-        asm volatile("" :: "v"(before) : "memory");
-        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
-            const double total = __hip_atomic_load(sse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float mean = (float)(total / ((double)N * (double)D));
-            mse[0] = mean; mse[1] = mean; mse[2] = 0.0f; mse[3] = 0.0f;
-            __hip_atomic_store(sse, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    vqkd_tail_finish(s, red, partials, sse, mse, N, D);
 }
 
 // Backward of   xn = F.normalize(x);  z_ste = xn + sg(z - xn);  loss = mean((F.normalize(sg z) - F.normalize(xn))^2)
@@ -226,6 +279,74 @@ __global__ __launch_bounds__(256) void vqkd_backward_kernel(const void *__restri
             const float y = load_elem<DT>(x, n * D + d) / dx;
             gx[n * D + d] = cx ? gxn / dx : (gxn - y * dot2) / dx;
         }
+    }
+}
+
+// The tail and the backward at D <= 32 (the shipped VQ-KD config has D = 32): L lanes per token, 64 / L tokens per wave, every
+// element of a row in a register of its own — one trip to memory per token instead of two or three dependent ones by a wave whose
+// upper lanes idle.  Same per-element expressions; the group sums are the full-wave trees without their all-zero upper levels
+// (bit-identical gradients and straight-through outputs; the double-precision loss sum is regrouped, as it is between any two
+// launches of the wave-per-token form: its cross-workgroup atomics already arrive in any order).
+template <int L>
+__device__ __forceinline__ float vq_group_sum(float p) {
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+template <int L>
+__global__ __launch_bounds__(1024) void vqkd_tail_small_kernel(const float *__restrict__ xn, const float *__restrict__ w,
+                                                               const int64_t *__restrict__ idx, int64_t N, int D, float eps,
+                                                               float *__restrict__ z_ste, double *sse, float *__restrict__ mse,
+                                                               double *__restrict__ partials) {
+    constexpr int RPW = 64 / L;
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = lane % L, rw = lane / L;
+    double s = 0.0;
+    for (int64_t base = ((int64_t)blockIdx.x * 16 + wave) * RPW; base < N; base += (int64_t)gridDim.x * 16 * RPW) {
+        const int64_t n = base + rw;
+        const bool live = n < N && d < D;
+        const int64_t k = n < N ? idx[n] : 0;
+        const float zv = live ? w[k * D + d] : 0.0f, xv = live ? xn[n * D + d] : 0.0f;
+        const float nz = sqrtf(vq_group_sum<L>(fmaf(zv, zv, 0.0f))), nx = sqrtf(vq_group_sum<L>(fmaf(xv, xv, 0.0f)));
+        const float den = (nz < eps) ? eps : nz, dnx = (nx < eps) ? eps : nx;
+        if (live) {
+            if (z_ste) z_ste[n * D + d] = xv + (zv - xv);
+            const float df = zv / den - xv / dnx;
+            s += (double)(df * df);
+        }
+    }
+    vqkd_tail_finish(s, red, partials, sse, mse, N, D);
+}
+
+template <int DT, int L>
+__global__ __launch_bounds__(256) void vqkd_backward_small_kernel(const void *__restrict__ x, const float *__restrict__ xn,
+                                                                  const float *__restrict__ w, const int64_t *__restrict__ idx,
+                                                                  int64_t N, int D, float eps, const float *__restrict__ g_zste,
+                                                                  const float *__restrict__ g_loss, float *__restrict__ gx) {
+    constexpr int RPW = 64 / L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = lane % L, rw = lane / L;
+    const float gl = g_loss ? *g_loss : 0.0f;
+    const float sc = gl * (2.0f / ((float)N * (float)D));
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW; base < N; base += (int64_t)gridDim.x * 4 * RPW) {
+        const int64_t n = base + rw;
+        const bool live = n < N && d < D;
+        const int64_t k = n < N ? idx[n] : 0;
+        const float a = live ? load_elem<DT>(x, n * D + d) : 0.0f, b = live ? xn[n * D + d] : 0.0f, c = live ? w[k * D + d] : 0.0f;
+        const float gz = (live && g_zste) ? g_zste[n * D + d] : 0.0f;
+        const float nx = sqrtf(vq_group_sum<L>(fmaf(a, a, 0.0f))), nn = sqrtf(vq_group_sum<L>(fmaf(b, b, 0.0f))),
+                    nz = sqrtf(vq_group_sum<L>(fmaf(c, c, 0.0f)));
+        const bool cx = nx < eps, cn = nn < eps;
+        const float dx = cx ? eps : nx, dn = cn ? eps : nn, dz = (nz < eps) ? eps : nz;
+        const float t = b / dn;
+        const float gt = sc * (t - c / dz);
+        const float dot1 = vq_group_sum<L>(fmaf(t, gt, 0.0f));
+        const float g1 = cn ? gt / dn : (gt - t * dot1) / dn;
+        const float gxn = g1 + gz;
+        const float y = a / dx;
+        const float dot2 = vq_group_sum<L>(live ? fmaf(y, gxn, 0.0f) : 0.0f);
+        if (live) gx[n * D + d] = cx ? gxn / dx : (gxn - y * dot2) / dx;
     }
 }
 
