@@ -313,8 +313,10 @@ int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p
  *   -> histogram header + centroid sums of normalize(xn) scattered straight into the packed buffer (ONE launch; `ordered`
  *   != 0: vqhip_token_order + vqhip_segsum_rows instead, bit-reproducible) -> [all-reduce] -> the EMA update read straight
  *   from the packed buffer (w_mid -> w_out) -> tail (tail != 0): z_ste = xn + (w_out[idx] - xn), mse[0] = mse[1] =
- *   mean((normalize(w_out[idx]) - normalize(xn))^2), mse[2] = mse[3] = 0.  xq: the encode's by-product (as vqhip_encode).
- *   packed: vqhip_pack_floats(K, K, D) floats, always used.
+ *   mean((normalize(w_out[idx]) - normalize(xn))^2), mse[2] = mse[3] = 0 — a double-precision sum of per-workgroup partials
+ *   added in a fixed order (they are parked in the record area of `ws`, free by then): the same step gives the same bits.
+ *   xq: the encode's by-product (as vqhip_encode).  packed: vqhip_pack_floats(K, K, D) floats, always used.
+ *   At D <= 32 the front, the tail and the backward give a row 8 / 16 / 32 lanes instead of a wave (same values).
  *   metric: VQHIP_METRIC_COS or VQHIP_METRIC_COS_BF16.  ws: vqhip_vqkd_forward_ws_bytes(N, K, D).
  * vqhip_vqkd_backward — gradient of that tail with respect to x: grad_x = normalize_bwd(x; g_zste + normalize_bwd(xn;
  *   g_loss * 2/(N D) * (normalize(xn) - normalize(w[idx])))); g_zste [N, D] / g_loss (DEVICE scalar) nullable. */
