@@ -79,7 +79,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bind', choices=('auto', 'on', 'off'), default='auto',
                     help='pin the rank to one L3 slice of its GPU\'s NUMA node (vector_quantization_amd/affinity.py). auto: on for the '
-                         'host-sensitive per-rank training workloads (cvq, vqkd), off for the GPU-bound ones')
+                         'host-sensitive per-rank training workloads (cvq, vqkd) and for every multi-GPU run (its cvq block is one; ranks '
+                         'take successive slices), off for the single-GPU GPU-bound ones')
     ap.add_argument('--no-verify', action='store_true', help='skip the parity self-check after the timed region')
     ap.add_argument('--no-cvq', action='store_true', help='world > 1, vqgan workload: skip the communicating cvq block')
     return ap.parse_args()
@@ -231,7 +232,7 @@ class Bench:
         # host-thread placement (a launcher's job, done here because the rank knows its device only now): see affinity.py
         self.binding = None
         want = getattr(args, 'bind', 'off')
-        if want == 'on' or (want == 'auto' and getattr(args, 'workload', '') in ('cvq', 'vqkd')):
+        if want == 'on' or (want == 'auto' and (getattr(args, 'workload', '') in ('cvq', 'vqkd') or (self.world > 1 and not self.share_gpu))):
             from vector_quantization_amd import affinity
             torch.cuda.init()
             self.binding = affinity.bind_rank(local_rank, int(os.environ.get('LOCAL_RANK', '0')), probe=True,
