@@ -415,7 +415,7 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
             rec['ms_per_step_graphed'] = ge / steps * 1e3
             rec['tokens_per_s_graphed'] = tokens * B.world * steps / ge
             rec['graphed_note'] = ('GraphedQuantizer: forward (with the in-place codebook update and the packed all-reduce) and '
-                                   'backward replayed from HIP graphs; CVQ-VAE: captured at 256 / 4096 / K listed codes, chained through '
+                                   'backward replayed from HIP graphs; CVQ-VAE: captured at 128 / 1024 / 4096 / 8192 / K listed codes, chained through '
                                    'the pinned count word (the replay waits for the previous forward: the eager one-call step is the faster one)')
         else:
             rec['graphed_error'] = err or 'graph capture failed on another rank'

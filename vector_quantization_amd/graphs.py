@@ -20,7 +20,7 @@ What capture needs from the step, and how the quantizer provides it:
 Collectives: captured as issued; RCCL ("nccl") supports capture, gloo does not — use the graph at world size 1 or on RCCL.
 
 CVQ-VAE (the sparse-anchor flow): a captured step cannot size its listed-code launches from a count the host reads, so the
-train-mode step is captured at SEVERAL capacities (256, 4096 and K listed codes) and chained: every replay ends by writing the
+train-mode step is captured at SEVERAL capacities (128, 1024, 4096, 8192 and K listed codes) and chained: every replay ends by writing the
 next step's list, and publishes that list's LENGTH — with a sequence number, to a pinned host word — as soon as the step's
 histogram is final (one small launch behind the encode / the exchange: the probabilities' update needs nothing else); before the
 next replay the host polls the word for the number it expects and picks the smallest captured capacity that fits, while the
@@ -61,7 +61,7 @@ class GraphedQuantizer(nn.Module):
     codebook is exactly what it was before the constructor ran.  (A VQ-KD quantizer's lazy k-means init, which needs host
     logic, must already have happened: call the quantizer once eagerly first.)"""
 
-    def __init__(self, quantizer: nn.Module, sample_x: torch.Tensor, warmup: int = 3, bucket_caps=(256, 4096)) -> None:
+    def __init__(self, quantizer: nn.Module, sample_x: torch.Tensor, warmup: int = 3, bucket_caps=(128, 1024, 4096, 8192)) -> None:
         super().__init__()
         if not sample_x.is_cuda:
             raise ValueError('GraphedQuantizer needs a device tensor (no CPU path)')
