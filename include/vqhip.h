@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define VQHIP_VERSION 500   /* round 5: + one host call per training forward (vqhip_cvq_forward, vqhip_vqkd_forward) */
+#define VQHIP_VERSION 600   /* round 6: + NearestAnchor(sync=True) across ranks by a key exchange (vqhip_cvq_col_keys, vqhip_cvq_pack_sync,
+                              * vqhip_allreduce_min_i64, vqhip_cvq_forward_t.anchor_sync / rank / keys); vqhip_cvq_apply takes the capacity */
 
 #define VQHIP_METRIC_L2 0   /* L2Distance      vq/algorithms/vq/distances.py:28-32 */
 #define VQHIP_METRIC_COS 1  /* CosineDistance  vq/algorithms/vq/distances.py:35-46 */
@@ -257,7 +258,7 @@ int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream)
  * vqhip_col_argmin_rows: col_idx[i] = nearest latent of code rows[i] for i < count — vqhip_col_argmin's pipeline and
  *   arithmetic on the listed codes; the launches are sized for `cap` (>= the count; the host need not know it: a HIP graph
  *   captures cap = K), rows past the count cost an early exit; ws = vqhip_col_rows_workspace_bytes(N, cap, D).  A SHORT list
- *   (ceil(cap / 32) * ceil(N / 128) * D <= 2^18; fp32 latents or the cosine metric) skips the proposal pipeline: the whole-batch fp32 pass of the
+ *   (ceil(cap / 32) * ceil(N / 128) * D <= 2^18; fp32 latents) skips the proposal pipeline: the whole-batch fp32 pass of the
  *   definition itself over the listed codes, one launch behind a tiny one (two more for the L2 norms) instead of five — the
  *   same indices (tuning key 15 = 0 sends short lists through the pipeline as well: A/B, tests).
  * vqhip_cvq_pack: this rank's packed buffer — header from the int32 epilogue histogram, payload row i = x[col_idx[i]]
@@ -265,6 +266,9 @@ int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream)
  * vqhip_cvq_apply: p_out = p_in*g + (hist/numel)*(1-g); decay as above; w_out[k] = w_in[k]*decay + a*(1-decay) for listed
  *   codes, w_in[k]*decay (= w_in[k]) for the others.  packed != NULL: counts and anchor sums from the all-reduced buffer,
  *   a = sum/world; packed == NULL (one rank): counts from hist/numel, a = x[col_idx[slot[k]]].  Outputs may alias inputs.
+ *   cap: the capacity the column pass / pack were sized for; a code whose slot lies at or beyond it has no anchor in
+ *   col_idx / packed (a list longer than the capacity the caller chose is the caller's error): it keeps w_k * decay_k and
+ *   nothing outside the buffers is read.
  *   Bit-identical to vqhip_cvq_update / vqhip_cvq_step on finite data (a non-listed code keeps w_k instead of w_k*1 + a*0:
  *   only a negative-zero weight or a non-finite anchor could tell the difference). */
 int vqhip_cvq_rows(const float *p, int64_t K, float ema_decay, float eps, int32_t *rows, int32_t *slot, int32_t *count,
@@ -276,7 +280,27 @@ int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtyp
                    int64_t cap, int64_t K, int D, float *packed, void *stream);
 int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
                     const void *x, int x_dtype, const int64_t *col_idx, const float *packed, int world, const int32_t *slot,
-                    int64_t K, int D, float ema_decay, float eps, void *stream);
+                    int64_t cap, int64_t K, int D, float ema_decay, float eps, void *stream);
+/* NearestAnchor(sync=True) over more than one rank (vq/algorithms/cvqvae/anchors.py:50-57,83-84; configs/cluster/model.py:28).
+ * The reference all-gathers the latents and the whole [N, K] matrix and takes the column argmin of the concatenation — the
+ * nearest latent of a code over ALL ranks' tokens, the lowest (rank, row) among equal distances; the anchor is NOT averaged.
+ * Here every rank runs vqhip_col_argmin_rows over its own tokens, then:
+ * vqhip_cvq_col_keys: keys[i] = (distance of listed code rows[i] to its local winner col_idx[i] — the fp32 definition's own
+ *   value, ordered as torch.argmin orders it: NaN first, -0 == +0 — : rank, 8 bits : row, 24 bits) for i < count, INT64_MAX up
+ *   to cap; stored as int64 with the top bit flipped, so that a SIGNED MIN all-reduce over keys[0 .. cap) (8 cap bytes; gloo
+ *   and RCCL both have it) leaves on every rank the key of the global winner.  x / e are the operands the column pass was
+ *   given (cosine: both normalised).  N <= VQHIP_SYNC_MAX_ROWS tokens per rank, rank < 256.
+ * vqhip_cvq_pack_sync: vqhip_cvq_pack with payload row i = x[row] on the rank the reduced key names and -0.0f elsewhere
+ *   (x + (-0) == x for every x), so the SUM all-reduce of the packed buffer delivers the winner's row bit for bit whatever
+ *   the order of the sum; vqhip_cvq_apply is then called with world = 1 (no averaging: anchors.py:59-63).
+ * Exchange per step: 8 cap + 4 (2K + 4 + cap D) bytes, against the reference's all-gather of world * N * (K + D) floats.
+ * vqhip_allreduce_min_i64: the MIN on a vqhip_rccl_comm_init communicator, on the caller's stream (as vqhip_allreduce_packed). */
+#define VQHIP_SYNC_MAX_ROWS (1 << 24)
+int vqhip_cvq_col_keys(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
+                       const int64_t *col_idx, int64_t N, int64_t K, int D, int metric, int rank, int64_t *keys, void *stream);
+int vqhip_cvq_pack_sync(const int32_t *hist, int64_t numel, const void *x, int x_dtype, const int64_t *keys, const int32_t *count,
+                        int64_t cap, int rank, int64_t K, int D, float *packed, void *stream);
+int vqhip_allreduce_min_i64(int64_t *buf, int64_t n, void *comm, void *stream);
 /* ---- ONE host call per training forward (round 5) -------------------------------------------------------------------------
  * The reference's training step runs the quantizer's forward as ~20 ATen calls; the entry points above
  * replace them one for one, which leaves an eager nn.Module step with ~10 host calls — at the reference's per-rank batches
@@ -306,6 +330,10 @@ int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p
  *   BEFORE phase (host fields).  ws: vqhip_cvq_forward_ws_bytes(N, K, D, cap_max) with cap_max >= cap; packed: at least
  *   vqhip_pack_floats(K, cap, D) floats (exchange != 0).  xq: cosine only (as vqhip_encode).  z_ste / mse nullable together
  *   (no decode tail).  w_out / p_out may alias w_in / p_in.  early_word_host / early_seq_dev: see the struct.
+ *   anchor_sync != 0 (with exchange != 0): NearestAnchor(sync=True) — BEFORE ends with vqhip_cvq_col_keys into `keys` instead
+ *   of the pack; the caller MIN-all-reduces keys[0 .. cap_used) as int64, calls the VQHIP_STEP_PACK_SYNC phase
+ *   (vqhip_cvq_pack_sync), SUM-all-reduces packed[0 .. exchange_floats) and calls AFTER (anchors not averaged).
+ *   VQHIP_STEP_ALL does all of it on `comm` (vqhip_allreduce_min_i64 + vqhip_allreduce_packed).
  *
  * vqhip_vqkd_forward — VQKDQuantizer + VQKDCallback in train mode (vq/algorithms/vq/callbacks/normalize.py:22-29,
  *   vq/algorithms/vqkd/quantizers/callbacks.py:44-75,114-129, vq/algorithms/vq/losses.py:53-62 with mse norm=True):
@@ -323,12 +351,14 @@ int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p
 #define VQHIP_STEP_BEFORE_EXCHANGE 1
 #define VQHIP_STEP_AFTER_EXCHANGE 2
 #define VQHIP_STEP_ALL 3
+#define VQHIP_STEP_PACK_SYNC 4     /* anchor_sync only: between the caller's MIN all-reduce of the keys and its SUM all-reduce of packed */
 typedef struct vqhip_cvq_forward_t {
     int64_t struct_bytes;
     int64_t N, K;
     int32_t D, x_dtype, metric, world;
     float ema_decay, eps, beta;
-    int32_t phases, exchange, list_ready, prefetch, reserved0;
+    int32_t phases, exchange, list_ready, prefetch;
+    int32_t anchor_sync, rank;      /* NearestAnchor(sync=True) with exchange != 0: the key exchange of vqhip_cvq_col_keys; this rank's number */
     int64_t cap;
     const void *x;
     const float *w_in, *p_in;
@@ -349,6 +379,7 @@ typedef struct vqhip_cvq_forward_t {
      * and must choose the next replay's capacity without an event in the middle of the graph (it polls the word) */
     unsigned long long *early_word_host;
     int32_t *early_seq_dev;
+    int64_t *keys;                  /* anchor_sync: cap int64 (DEVICE), MIN-all-reduced between BEFORE and PACK_SYNC */
 } vqhip_cvq_forward_t;
 int64_t vqhip_cvq_forward_ws_bytes(int64_t N, int64_t K, int D, int64_t cap_max);
 int vqhip_cvq_forward(vqhip_cvq_forward_t *args, void *stream);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_sizes(lib):
-    assert lib.vqhip_version() == _lib.ABI_VERSION == 500
+    assert lib.vqhip_version() == _lib.ABI_VERSION == 600
     cb = lib.vqhip_codebook_bytes(16384, 256)
     # fp16 fragment image (K*D*2) + fp32 normalised copy (K*D*4) + norms + aux chunks
     assert cb >= 16384 * 256 * 6 and cb < 16384 * 256 * 7
@@ -112,6 +112,23 @@ def test_one_call_forwards_validate_their_argument_blocks(lib):
     assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'packed' in lib.vqhip_last_error()
     a.packed = 0x1000
     assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'communicator' in lib.vqhip_last_error()
+    # NearestAnchor(sync=True): the key exchange needs its buffer, this rank's number and rows that fit 24 bits
+    a.anchor_sync, a.rank, a.comm = 1, 0, 0x1000
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'keys' in lib.vqhip_last_error()
+    a.keys, a.rank = 0x1000, 2
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'rank' in lib.vqhip_last_error()
+    a.rank, a.phases = 1, 5
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'phases' in lib.vqhip_last_error()
+    a.phases, a.anchor_sync = _lib.STEP_PACK_SYNC, 0
+    assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22 and b'phases' in lib.vqhip_last_error()      # PACK_SYNC is a sync phase
+    a.phases = _lib.STEP_ALL
+    fake = ctypes.c_void_p(0x1000)
+    assert lib.vqhip_cvq_col_keys(fake, 0, fake, fake, fake, 8, fake, (1 << 24) + 1, K, D, 0, 0, fake, None) == -22 and b'24 bits' in lib.vqhip_last_error()
+    assert lib.vqhip_cvq_col_keys(fake, 0, fake, fake, fake, 8, fake, N, K, D, 0, 256, fake, None) == -22
+    assert lib.vqhip_cvq_col_keys(fake, 0, fake, fake, fake, K + 1, fake, N, K, D, 0, 0, fake, None) == -22
+    assert lib.vqhip_cvq_pack_sync(fake, N, fake, 0, None, fake, 8, 0, K, D, fake, None) == -22
+    assert lib.vqhip_allreduce_min_i64(None, 8, fake, None) == -22
+    assert lib.vqhip_cvq_apply(fake, fake, fake, fake, fake, N, fake, 0, fake, None, 1, fake, K + 1, K, D, 0.99, 1e-3, None) == -22
     a.D = 12
     assert lib.vqhip_cvq_forward(ctypes.byref(a), None) == -22
     b = _lib.VqkdForwardArgs()

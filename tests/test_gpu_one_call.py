@@ -291,6 +291,52 @@ def test_graphed_cvq_capacity_buckets_follow_the_list():
         assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
 
 
+def test_graphed_cvq_replays_interleaved_with_eager_steps():
+    """Round-5 advisor: an eager train step between two replays (a ragged last batch the graph refuses by shape) rewrites the
+    device-side list in place without touching the early word or ``p._version`` — the next replay used to trust a stale
+    length and could pick a capacity SMALLER than the list (anchors of the codes beyond it read from unwritten slots), and an
+    eager step after a replay read a count the replay had not produced.  `CvqStepState.writer` names the last writer: both
+    directions recount.  A second, smaller eager batch makes the list GROW between replays (codes fall out of use), which is
+    exactly the case where the stale length is too small.  Compared with the all-eager module step by step."""
+    from vector_quantization_amd.graphs import GraphedQuantizer
+    N, K, D = 3000, 2048, 64
+    w0 = synth.unit_rows(synth.rng(5).standard_normal((K, D), dtype=np.float32))
+    xs = batches(N, K, D, w0, 10, 36)
+    small = [x[:700].clone() for x in xs]                        # the "ragged last batch": another shape, eager only
+    gz = torch.randn(N, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) / (N * D)
+    plan = ['g', 'g', 'g', 'e', 'g', 'e', 'e', 'g', 'g', 'e']      # g: full batch (replayed in run B), e: small batch (eager in both)
+
+    def run(graphed):
+        q = build(cvq_cfg(K, D, 'Cosine'), w0)
+        gq = None
+        out, caps = [], []
+        for i, kind in enumerate(plan):
+            x = (xs[i] if kind == 'g' else small[i]).clone().requires_grad_(True)
+            q.zero_grad(set_to_none=True)
+            if kind == 'g' and graphed:
+                if gq is None:
+                    gq = GraphedQuantizer(q, xs[0], bucket_caps=(64, 256, 1024))
+                z, loss, quant = gq(x)
+                caps.append(gq.last_capacity)
+            else:
+                z, loss, memo = q(x, {})
+                quant = memo['quant']
+                caps.append(q._callbacks.callbacks[0].last_exchange_rows)
+            torch.autograd.backward([loss, z], [None, gz[:x.shape[0]]])
+            out.append((quant.clone(), z.detach().clone(), float(loss), q.embedding.weight.detach().clone(),
+                        q.get_buffer('_probability').clone()))
+        return out, caps
+
+    ref, counts = run(False)
+    got, used = run(True)
+    for i, ((qa, za, la, wa, pa), (qb, zb, lb, wb, pb)) in enumerate(zip(ref, got)):
+        assert torch.equal(qa, qb) and torch.equal(za, zb) and torch.equal(pa, pb), (i, plan[i])
+        assert torch.equal(wa, wb), (i, plan[i], counts, used)
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(la))
+    for i, kind in enumerate(plan):                              # a replay never ran below the length of its list
+        assert used[i] >= counts[i], (i, kind, counts, used)
+
+
 @pytest.mark.parametrize('kind,dist,D,bf16,train', [('plain', 'L2', 256, True, True), ('plain', 'L2', 256, True, False), ('plain', 'Cosine', 32, False, True),
                                                     ('normalize', 'L2', 8, False, True), ('normalize', 'L2', 8, True, False),
                                                     ('normalize', 'Cosine', 64, False, True)])
@@ -329,11 +375,13 @@ def test_plain_and_normalize_forward_one_call_equals_hook_by_hook(kind, dist, D,
 
 
 @pytest.mark.parametrize('metric,D,dtype', [('Cosine', 256, torch.float32), ('L2', 256, torch.float32), ('CosineBF16', 64, torch.float32),
-                                            ('L2', 8, torch.float32), ('Cosine', 768, torch.float32), ('L2', 64, torch.bfloat16)])
+                                            ('L2', 8, torch.float32), ('Cosine', 768, torch.float32), ('L2', 64, torch.bfloat16),
+                                            ('Cosine', 64, torch.bfloat16)])
 def test_column_pass_over_a_short_list_direct_form_equals_the_pipeline(metric, D, dtype):
     """vqhip_col_argmin_rows on a short list runs the definition's own fp32 pass over the listed codes instead of the
     role-swapped proposal pipeline (tuning key 15): identical indices, also against a brute-force float64 column argmin;
-    bf16 latents under L2 keep the pipeline (the pass reads fp32 rows)."""
+    bf16 latents keep the pipeline under either metric (the pass reads fp32 rows: round-5 advisor — the cosine case read the
+    bf16 buffer as fp32)."""
     from vector_quantization_amd import _lib, ops
     N, K = 3072, 4096
     g = torch.Generator(device='cuda').manual_seed(D)
@@ -348,6 +396,8 @@ def test_column_pass_over_a_short_list_direct_form_equals_the_pipeline(metric, D
         xq, eq = ops.normalize_rows(x), ops.normalize_rows(w)
         if metric == 'CosineBF16':
             xq, eq = xq.bfloat16().float(), eq.bfloat16().float()
+        elif dtype == torch.bfloat16:
+            xq = xq.bfloat16()                                   # bf16 rows handed to the cosine column pass as they are
     else:
         xq, eq = x, w
     L = _lib.lib()

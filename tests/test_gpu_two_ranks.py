@@ -88,8 +88,8 @@ def _worker(rank, world, port, outdir):
     from vector_quantization_amd.utils import exchange_log
     gen = synth.rng(100)
     wk = synth.unit_rows(gen.standard_normal((K, D), dtype=np.float32))
-    steps = [(gen.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + wk[gen.integers(0, K // 8, N)])[rank::world]
-             for _ in range(5)]
+    full = [gen.standard_normal((N, D), dtype=np.float32) * np.float32(0.3) + wk[gen.integers(0, K // 8, N)] for _ in range(5)]
+    steps = [f[rank::world] for f in full]
     runs = {}
     for sparse in (None, False):
         cfg = _cfg('cvq', K, D, 'Cosine', False)
@@ -116,6 +116,37 @@ def _worker(rank, world, port, outdir):
     assert runs[None][4][0] == K and runs[None][4][-1] < K, runs[None][4]       # first step: p = 0, every code listed
     rec['sparse_rows'] = np.asarray(runs[None][4])
     rec['sparse_w'] = runs[None][0].cpu().numpy()
+    # NearestAnchor(sync=True) — the cluster config (configs/cluster/model.py:28): the key exchange of SURVEY.md §8e (default; one
+    # call per forward and hook by hook) against the reference's data flow (latents gathered, column argmin over ALL of them on
+    # every rank: sparse_anchors=False).  One rank contributes each anchor row, so the codebooks are bit-identical at ANY world
+    # size; the exchange is a MIN all-reduce of 8 M bytes of keys and the packed SUM of 4 (2K + 4 + M D) bytes — no latent
+    # travels.  The duplicated latents of `ties` make two ranks hold the SAME nearest row of a code: the lowest (rank, row) wins
+    ties = [s.copy() for s in steps]
+    for s in ties:
+        s[1::2] = full[0][:1]                      # every rank's odd rows = one and the same latent
+    for dname in ('Cosine', 'L2'):
+        sruns = {}
+        for route in ('one_call', 'hooks', 'gather'):
+            cfg = _cfg('cvq', K, D, dname, True)
+            cfg['callbacks'][0]['sparse_anchors'] = False if route == 'gather' else None
+            q = build(cfg, init=dict(type='vqgan'), weight=wk)
+            q.one_call_steps = route == 'one_call'
+            calls, nbytes, rows = [], [], []
+            for xs in steps + ties:
+                exchange_log.start()
+                q(torch.from_numpy(xs).cuda(), {})
+                st = exchange_log.stop()
+                calls.append(st['calls']); nbytes.append(st['bytes']); rows.append(q._callbacks.callbacks[0].last_exchange_rows)
+            assert is_sync(q.embedding.weight.detach()) and is_sync(q.get_buffer('_probability'))
+            sruns[route] = (q.embedding.weight.detach().clone(), q.get_buffer('_probability').clone(), calls, nbytes, rows)
+        for route in ('one_call', 'hooks'):
+            assert torch.equal(sruns[route][1], sruns['gather'][1]), (dname, route)
+            assert torch.equal(sruns[route][0], sruns['gather'][0]), (dname, route)
+            assert sruns[route][2] == [2 if m else 1 for m in sruns[route][4]], (dname, route, sruns[route][2])
+            assert sruns[route][3] == [8 * m + 4 * (2 * K + 4 + m * D) for m in sruns[route][4]], (dname, route)
+        assert sruns['one_call'][4] == sruns['hooks'][4] and sruns['one_call'][4][0] == K
+        rec[f'sync_rows_{dname.lower()}'] = np.asarray(sruns['one_call'][4])
+        rec[f'sync_w_{dname.lower()}'] = sruns['one_call'][0].cpu().numpy()
     # lazy k-means init: gather to rank 0, Lloyd iterations there, broadcast (callbacks.py:77-112).  DRY_RUN off, as in
     # the reference run (rank 0 alone calls _update_embedding inside the loop)
     os.environ['DRY_RUN'] = ''
@@ -141,7 +172,7 @@ def test_callbacks_at_world_size_eight(tmp_path):
     for r in ranks[1:]:
         np.testing.assert_array_equal(ranks[0]['sparse_rows'], r['sparse_rows'])
         for k in ranks[0]:
-            if k.endswith('w_new') or k.endswith('_p') or k in ('lazy_w', 'sparse_w'):
+            if k.endswith('w_new') or k.endswith('_p') or k in ('lazy_w', 'sparse_w') or k.startswith('sync_w'):
                 assert ranks[0][k].tobytes() == r[k].tobytes(), f'ranks disagree on {k}'
     g = np.load(os.path.join(GOLDEN, 'update_8rank.npz'))
     for r in range(8):
@@ -183,7 +214,7 @@ def test_callbacks_at_world_size_two(tmp_path):
     r0, r1 = (dict(np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))) for r in range(2))
     np.testing.assert_array_equal(r0['sparse_rows'], r1['sparse_rows'])                  # every rank sized the same exchange
     for k in r0:
-        if k.endswith('w_new') or k.endswith('_p') or k in ('lazy_w', 'sparse_w'):
+        if k.endswith('w_new') or k.endswith('_p') or k in ('lazy_w', 'sparse_w') or k.startswith('sync_w'):
             assert r0[k].tobytes() == r1[k].tobytes(), f'ranks disagree on {k}'          # bit-identical codebooks
     g = np.load(os.path.join(GOLDEN, 'update_vqkd.npz'))
     np.testing.assert_array_equal(r0['vqkd_quant'], g['quant_rank0'].astype(np.int64))

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VQHIP_LIB') or os.path.join(_HERE, 'libvqhip.so')   # VQHIP_LIB: experiment builds
 
-ABI_VERSION = 500          # VQHIP_VERSION of include/vqhip.h this binding was written against
+ABI_VERSION = 600          # VQHIP_VERSION of include/vqhip.h this binding was written against
 METRIC_L2, METRIC_COS, METRIC_COS_BF16 = 0, 1, 5
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
@@ -24,7 +24,7 @@ class CvqForwardArgs(ctypes.Structure):
     _fields_ = [('struct_bytes', _i64), ('N', _i64), ('K', _i64),
                 ('D', _i32), ('x_dtype', _i32), ('metric', _i32), ('world', _i32),
                 ('ema_decay', _f32), ('eps', _f32), ('beta', _f32),
-                ('phases', _i32), ('exchange', _i32), ('list_ready', _i32), ('prefetch', _i32), ('reserved0', _i32),
+                ('phases', _i32), ('exchange', _i32), ('list_ready', _i32), ('prefetch', _i32), ('anchor_sync', _i32), ('rank', _i32),
                 ('cap', _i64),
                 ('x', _vp), ('w_in', _vp), ('p_in', _vp), ('w_out', _vp), ('p_out', _vp),
                 ('rows', _vp), ('slot', _vp), ('count', _vp), ('count_host', _vp), ('count_event', _vp), ('comm', _vp),
@@ -33,7 +33,7 @@ class CvqForwardArgs(ctypes.Structure):
                 ('z_ste', _vp), ('mse', _vp), ('scratch16', _vp),
                 ('ws', _vp), ('ws_bytes', _i64),
                 ('cap_used', _i64), ('exchange_floats', _i64),
-                ('early_word_host', _vp), ('early_seq_dev', _vp)]
+                ('early_word_host', _vp), ('early_seq_dev', _vp), ('keys', _vp)]
 
 
 class VqkdForwardArgs(ctypes.Structure):
@@ -61,7 +61,7 @@ class VqForwardArgs(ctypes.Structure):
                 ('ws', _vp), ('ws_bytes', _i64)]
 
 
-STEP_BEFORE_EXCHANGE, STEP_AFTER_EXCHANGE, STEP_ALL = 1, 2, 3
+STEP_BEFORE_EXCHANGE, STEP_AFTER_EXCHANGE, STEP_ALL, STEP_PACK_SYNC = 1, 2, 3, 4
 
 # name -> (restype, argtypes); mirrors include/vqhip.h one to one
 SIGNATURES = {
@@ -114,7 +114,10 @@ SIGNATURES = {
     'vqhip_vqkd_forward': (_i32, [ctypes.POINTER(VqkdForwardArgs), _vp]),
     'vqhip_vq_forward': (_i32, [ctypes.POINTER(VqForwardArgs), _vp]),
     'vqhip_vqkd_backward': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
-    'vqhip_cvq_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _f32, _f32, _vp]),
+    'vqhip_cvq_apply': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _f32, _f32, _vp]),
+    'vqhip_cvq_col_keys': (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    'vqhip_cvq_pack_sync': (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp]),
+    'vqhip_allreduce_min_i64': (_i32, [_vp, _i64, _vp, _vp]),
     'vqhip_order_workspace_bytes': (_i64, [_i64, _i64]),
     'vqhip_token_order': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     'vqhip_segsum_workspace_bytes': (_i64, [_i64, _i32]),

@@ -857,7 +857,7 @@ static inline int64_t col_direct_bytes(int64_t N, int64_t cap, int D, int64_t K)
 }
 static bool col_direct_ok(int x_dtype, int metric, int64_t cap, int64_t N, int64_t K, int D, int64_t ws_bytes) {
     if (!g_tune_col_direct.load() || cap <= 0 || (D % 4) != 0) return false;
-    if (metric == VQHIP_METRIC_L2 && x_dtype != VQHIP_DTYPE_F32) return false;        // the pass reads the tokens as fp32 rows
+    if (x_dtype != VQHIP_DTYPE_F32) return false;        // the pass reads the tokens as fp32 rows, whatever the metric
     if (((cap + 31) / 32) * ((N + 127) / 128) * (int64_t)D > VQ_COL_DIRECT_MAX_WORK) return false;
     return ws_bytes >= col_direct_bytes(N, cap, D, K);
 }
@@ -1166,19 +1166,52 @@ int vqhip_cvq_pack(const int32_t *hist, int64_t numel, const void *x, int x_dtyp
 
 int vqhip_cvq_apply(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist, int64_t numel,
                     const void *x, int x_dtype, const int64_t *col_idx, const float *packed, int world, const int32_t *slot,
-                    int64_t K, int D, float ema_decay, float eps, void *stream) {
-    if (!w_in || !w_out || !p_in || !p_out || !slot || K <= 0 || D <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: bad argument");
+                    int64_t cap, int64_t K, int D, float ema_decay, float eps, void *stream) {
+    if (!w_in || !w_out || !p_in || !p_out || !slot || K <= 0 || D <= 0 || cap < 0 || cap > K) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (packed != nullptr) {
         if (world < 1 || world > VQ_PACK_MAX_WORLD) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: world must be in [1, 256] (exact fp32 count sums)");
-        cvq_apply_kernel<0, true><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, nullptr, 0, nullptr, nullptr, packed, world, slot, K, D, ema_decay, eps);
+        cvq_apply_kernel<0, true><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, nullptr, 0, nullptr, nullptr, packed, world, slot, (int)cap, K, D, ema_decay, eps);
     } else {
         if (!hist || numel <= 0) return fail(VQHIP_EINVAL, "vqhip_cvq_apply: the one-rank form needs hist and numel");   // (x, col_idx: read for listed codes only)
-        if (x_dtype == VQHIP_DTYPE_F32) cvq_apply_kernel<0, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, K, D, ema_decay, eps);
-        else if (x_dtype == VQHIP_DTYPE_BF16) cvq_apply_kernel<1, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, K, D, ema_decay, eps);
+        if (x_dtype == VQHIP_DTYPE_F32) cvq_apply_kernel<0, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, (int)cap, K, D, ema_decay, eps);
+        else if (x_dtype == VQHIP_DTYPE_BF16) cvq_apply_kernel<1, false><<<waves_grid(K, 4), 256, 0, s>>>(w_in, w_out, p_in, p_out, hist, numel, x, col_idx, nullptr, 1, slot, (int)cap, K, D, ema_decay, eps);
         else return fail(VQHIP_EINVAL, "vqhip_cvq_apply: x_dtype");
     }
     VQ_CHECK_LAUNCH("cvq_apply_kernel");
+    return VQHIP_OK;
+}
+
+// ---- NearestAnchor(sync=True) across ranks: keys of the local winners, the masked pack (include/vqhip.h) ---------------
+int vqhip_cvq_col_keys(const void *x, int x_dtype, const float *e, const int32_t *rows, const int32_t *count, int64_t cap,
+                       const int64_t *col_idx, int64_t N, int64_t K, int D, int metric, int rank, int64_t *keys, void *stream) {
+    if (!x || !e || !rows || !count || !col_idx || !keys || N <= 0 || K <= 0 || D <= 0 || cap < 0 || cap > K)
+        return fail(VQHIP_EINVAL, "vqhip_cvq_col_keys: bad argument");
+    if (N > VQHIP_SYNC_MAX_ROWS || rank < 0 || rank >= VQ_PACK_MAX_WORLD)
+        return fail(VQHIP_EINVAL, "vqhip_cvq_col_keys: a key holds 24 bits of row and 8 bits of rank (N <= 2^24, rank < 256)");
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_cvq_col_keys: metric");
+    if (cap == 0) return VQHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((cap + 63) / 64);
+    if (x_dtype == VQHIP_DTYPE_F32) cvq_col_keys_kernel<0><<<grid, 64, 0, s>>>(x, e, rows, count, cap, col_idx, D, metric, rank, keys);
+    else if (x_dtype == VQHIP_DTYPE_BF16) cvq_col_keys_kernel<1><<<grid, 64, 0, s>>>(x, e, rows, count, cap, col_idx, D, metric, rank, keys);
+    else return fail(VQHIP_EINVAL, "vqhip_cvq_col_keys: x_dtype");
+    VQ_CHECK_LAUNCH("cvq_col_keys_kernel");
+    return VQHIP_OK;
+}
+
+int vqhip_cvq_pack_sync(const int32_t *hist, int64_t numel, const void *x, int x_dtype, const int64_t *keys, const int32_t *count,
+                        int64_t cap, int rank, int64_t K, int D, float *packed, void *stream) {
+    if (!hist || !packed || K <= 0 || D <= 0 || numel <= 0 || cap < 0 || cap > K || rank < 0 || rank >= VQ_PACK_MAX_WORLD ||
+        (cap > 0 && (!x || !keys || !count)))
+        return fail(VQHIP_EINVAL, "vqhip_cvq_pack_sync: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int hb = (int)((K + 255) / 256);
+    const int grid = hb + waves_grid(cap, 4);
+    if (x_dtype == VQHIP_DTYPE_BF16) cvq_pack_sync_kernel<1><<<grid, 256, 0, s>>>(hist, numel, x, keys, count, cap, rank, K, D, packed, hb);
+    else if (x_dtype == VQHIP_DTYPE_F32) cvq_pack_sync_kernel<0><<<grid, 256, 0, s>>>(hist, numel, x, keys, count, cap, rank, K, D, packed, hb);
+    else return fail(VQHIP_EINVAL, "vqhip_cvq_pack_sync: x_dtype");
+    VQ_CHECK_LAUNCH("cvq_pack_sync_kernel");
     return VQHIP_OK;
 }
 
@@ -1199,7 +1232,8 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
         return fail(VQHIP_EINVAL, "vqhip_cvq_forward: needs N, K > 0 and D <= 1024, D % 8 == 0");
     if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: metric");
     if (a->x_dtype != VQHIP_DTYPE_F32 && a->x_dtype != VQHIP_DTYPE_BF16) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: x_dtype");
-    if (a->phases < 1 || a->phases > VQHIP_STEP_ALL) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: phases");
+    const bool sync = a->exchange && a->anchor_sync;
+    if (a->phases < 1 || (a->phases > VQHIP_STEP_ALL && !(sync && a->phases == VQHIP_STEP_PACK_SYNC))) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: phases");
     if (!a->x || !a->w_in || !a->p_in || !a->w_out || !a->p_out || !a->rows || !a->slot || !a->count || !a->cb || !a->idx || !a->hist || !a->ws)
         return fail(VQHIP_EINVAL, "vqhip_cvq_forward: null pointer");
     const bool cos = VQ_IS_COS(metric);
@@ -1211,6 +1245,11 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
         if (a->phases == VQHIP_STEP_ALL && !a->comm && a->world > 1)
             return fail(VQHIP_EINVAL, "vqhip_cvq_forward: VQHIP_STEP_ALL over more than one rank needs a communicator (or issue the collective between the two phases)");
     }
+    if (sync) {
+        if (!a->keys) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: anchor_sync needs the keys buffer");
+        if (a->rank < 0 || a->rank >= a->world) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: anchor_sync needs this rank's number in [0, world)");
+        if (N > VQHIP_SYNC_MAX_ROWS) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: anchor_sync holds a row in 24 bits (N <= 2^24 per rank)");
+    }
     hipStream_t s = (hipStream_t)stream;
     const int64_t enc_bytes = vq_align1k(vqhip_workspace_bytes(N, K, D));
     VQ_NEED("vqhip_cvq_forward: ws too small", a->ws_bytes, enc_bytes + vq_align1k(K * 8));
@@ -1218,7 +1257,7 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
     int64_t *col_idx = (int64_t *)(w + enc_bytes);
     char *col_ws = w + enc_bytes + vq_align1k(K * 8);
     const int64_t col_ws_have = a->ws_bytes - enc_bytes - vq_align1k(K * 8);
-    if (a->phases & VQHIP_STEP_BEFORE_EXCHANGE) {
+    if (a->phases != VQHIP_STEP_PACK_SYNC && (a->phases & VQHIP_STEP_BEFORE_EXCHANGE)) {
         if (int rc = vqhip_encode_ex(a->x, a->x_dtype, a->w_in, N, K, D, metric, a->cb, a->cb_bytes, a->idx, a->hist, a->xq, a->ws,
                                      enc_bytes, VQHIP_ENCODE_ZERO_HIST, stream)) return rc;
         if (!a->list_ready)
@@ -1244,20 +1283,30 @@ int vqhip_cvq_forward(vqhip_cvq_forward_t *a, void *stream) {
             const float *codes = cos ? (const float *)((const char *)a->cb + L.off_eexact) : a->w_in;
             if (int rc = vqhip_col_argmin_rows(rows_x, cos ? VQHIP_DTYPE_F32 : a->x_dtype, codes, a->rows, a->count, cap, N, K, D, metric,
                                                col_idx, col_ws, col_ws_have, stream)) return rc;
+            if (sync)                    // the local winners' keys: the ranks agree on the global winner by a MIN all-reduce
+                if (int rc = vqhip_cvq_col_keys(rows_x, cos ? VQHIP_DTYPE_F32 : a->x_dtype, codes, a->rows, a->count, cap, col_idx, N, K, D, metric,
+                                                a->rank, a->keys, stream)) return rc;
         }
-        if (a->exchange)
+        if (a->exchange && !sync)
             if (int rc = vqhip_cvq_pack(a->hist, N, a->x, a->x_dtype, col_idx, a->count, cap, K, D, a->packed, stream)) return rc;
+    }
+    if (sync && (a->phases == VQHIP_STEP_ALL || a->phases == VQHIP_STEP_PACK_SYNC)) {
+        if (a->cap_used < 0 || a->cap_used > K) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap_used (the BEFORE phase writes it)");
+        if (a->phases == VQHIP_STEP_ALL && a->comm && a->cap_used > 0)
+            if (int rc = vqhip_allreduce_min_i64(a->keys, a->cap_used, a->comm, stream)) return rc;
+        if (int rc = vqhip_cvq_pack_sync(a->hist, N, a->x, a->x_dtype, a->keys, a->count, a->cap_used, a->rank, K, D, a->packed, stream)) return rc;
     }
     if (a->phases == VQHIP_STEP_ALL && a->exchange && a->comm)
         if (int rc = vqhip_allreduce_packed(a->packed, a->exchange_floats, a->comm, stream)) return rc;
-    if (a->phases & VQHIP_STEP_AFTER_EXCHANGE) {
+    if (a->phases != VQHIP_STEP_PACK_SYNC && (a->phases & VQHIP_STEP_AFTER_EXCHANGE)) {
         if (a->cap_used < 0 || a->cap_used > K) return fail(VQHIP_EINVAL, "vqhip_cvq_forward: cap_used (the BEFORE phase writes it)");
         if (a->exchange && a->early_word_host && a->early_seq_dev) {      // the next list's length, right behind the reduced histogram
             cvq_count_next_kernel<true><<<1, 1024, 0, s>>>(a->p_in, nullptr, 0, a->packed, K, a->ema_decay, a->eps, a->early_seq_dev, a->early_word_host);
             VQ_CHECK_LAUNCH("cvq_count_next_kernel");
         }
+        // sync: the packed rows ARE the global winners' latents (every other rank added -0): no averaging (anchors.py:59-63)
         if (int rc = vqhip_cvq_apply(a->w_in, a->w_out, a->p_in, a->p_out, a->hist, N, a->x, a->x_dtype, col_idx, a->exchange ? a->packed : nullptr,
-                                     a->world, a->slot, K, D, a->ema_decay, a->eps, stream)) return rc;
+                                     sync ? 1 : a->world, a->slot, a->cap_used, K, D, a->ema_decay, a->eps, stream)) return rc;
         if (a->prefetch) {
             // the list of the NEXT step; its length also goes straight to the caller's pinned host word (a store of the kernel
             // itself — pinned host memory is device-visible at its own address — instead of a 4-byte copy launch behind it)
@@ -1681,7 +1730,7 @@ struct RcclApi {
 }  // namespace
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
-static const int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32 = 7, ncclSum = 0
+static const int kNcclFloat32 = 7, kNcclInt64 = 4, kNcclSum = 0, kNcclMin = 3;        // rccl.h: ncclFloat32 = 7, ncclInt64 = 4, ncclSum = 0, ncclMin = 3
 
 static int rccl_fail(const char *what, int rc) {
     return fail(VQHIP_ERCCL, what, g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error");
@@ -1746,6 +1795,14 @@ int vqhip_allreduce_packed(float *buf, int64_t floats, void *comm, void *stream)
     if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_allreduce_packed: RCCL not loaded");
     if (floats == 0) return VQHIP_OK;
     const int rc = g_rccl.all_reduce(buf, buf, (size_t)floats, kNcclFloat32, kNcclSum, comm, (hipStream_t)stream);
+    return rc == 0 ? VQHIP_OK : rccl_fail("ncclAllReduce", rc);
+}
+
+int vqhip_allreduce_min_i64(int64_t *buf, int64_t n, void *comm, void *stream) {
+    if (!buf || !comm || n < 0) return fail(VQHIP_EINVAL, "vqhip_allreduce_min_i64: bad argument");
+    if (!g_rccl.handle) return fail(VQHIP_ERCCL, "vqhip_allreduce_min_i64: RCCL not loaded");
+    if (n == 0) return VQHIP_OK;
+    const int rc = g_rccl.all_reduce(buf, buf, (size_t)n, kNcclInt64, kNcclMin, comm, (hipStream_t)stream);
     return rc == 0 ? VQHIP_OK : rccl_fail("ncclAllReduce", rc);
 }
 

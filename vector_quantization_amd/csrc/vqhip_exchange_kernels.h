@@ -219,6 +219,78 @@ __global__ void cvq_pack_kernel(const int32_t *__restrict__ hist, int64_t numel,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NearestAnchor(sync=True) over more than one rank (anchors.py:50-57,83-84): the reference all-gathers the latents AND the
+// [N, K] matrix and takes the column argmin of the concatenation.  Here every rank runs the column pass over its OWN tokens,
+// and the ranks agree on the winner per listed code through one MIN all-reduce of 8-byte keys:
+//   key = (distance of the definition, in torch.argmin's order: NaN first, -0 == +0) : rank (8 bits) : row (24 bits)
+// — the smallest key is the smallest distance, and among equal distances the lowest (rank, row), i.e. the lowest index of
+// the reference's concatenation `torch.cat(all_gather(d))`.  The keys travel as int64 with the top bit flipped, so that the
+// SIGNED minimum every backend offers (gloo, RCCL) orders them as the unsigned values; slots past the count hold INT64_MAX.
+// ------------------------------------------------------------------------------------------------
+#define VQ_SYNC_ROW_BITS 24
+#define VQ_SYNC_MAX_ROWS (1ll << VQ_SYNC_ROW_BITS)
+// x / e: the operands of the definition (L2: the latents as given and the codebook; cosine: both normalised — what the column
+// pass itself was given).  One lane per listed code: the k-ordered fma chain of the definition is sequential by nature, and
+// a list is a few dozen codes in the steady state (every code in the first steps: ~30 us at K = 16 384, D = 256).
+template <int DT>
+__global__ __launch_bounds__(64) void cvq_col_keys_kernel(const void *__restrict__ x, const float *__restrict__ e,
+                                                          const int32_t *__restrict__ rows, const int32_t *__restrict__ count,
+                                                          int64_t cap, const int64_t *__restrict__ col_idx, int D, int metric,
+                                                          int rank, int64_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    if (i >= (int64_t)count[0]) { keys[i] = INT64_MAX; return; }
+    const int64_t k = rows[i], n = col_idx[i];
+    float xn = 0.0f, en = 0.0f;
+    if (VQ_IS_L2(metric)) {
+        xn = sqnorm_thread<DT>(x, n * D, D);
+        en = sqnorm_thread<0>(e, k * D, D);
+    }
+    const float d = oracle_distance<DT>(x, n * D, e + k * D, D, metric, xn, en);
+    const u64 key = dist_key(d, ((uint32_t)rank << VQ_SYNC_ROW_BITS) | (uint32_t)n);
+    keys[i] = (int64_t)(key ^ 0x8000000000000000ull);
+}
+
+// The packed buffer of one rank behind the MIN all-reduce of the keys: header as cvq_pack_kernel; payload row i = x[row] on
+// the rank the reduced key names, -0.0f on every other rank (x + (-0) == x bit for bit for every x, -0 included: the SUM
+// all-reduce then delivers the winner's row exactly, in any order), zeros past the count.
+template <int DT>
+__global__ void cvq_pack_sync_kernel(const int32_t *__restrict__ hist, int64_t numel, const void *__restrict__ x,
+                                     const int64_t *__restrict__ keys, const int32_t *__restrict__ count, int64_t cap, int rank,
+                                     int64_t K, int D, float *__restrict__ packed, int header_blocks) {
+    if ((int)blockIdx.x < header_blocks) {
+        const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (k < K) {
+            const int64_t h = hist[k];
+            packed[k] = (float)(h & 0xFFFF);
+            packed[K + k] = (float)(h >> 16);
+        }
+        if (k == 0) {
+            packed[2 * K] = (float)(numel & 0xFFFF);
+            packed[2 * K + 1] = (float)((numel >> 16) & 0xFFFF);
+            packed[2 * K + 2] = (float)(numel >> 32);
+            packed[2 * K + 3] = 0.0f;
+        }
+        return;
+    }
+    const int64_t i = (int64_t)(blockIdx.x - header_blocks) * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= cap) return;
+    float *dst = packed + VQ_PACK_HEADER(K) + i * D;
+    if (i < (int64_t)count[0]) {
+        const uint32_t who = (uint32_t)((u64)keys[i] & 0xFFFFFFFFull);
+        if ((int)(who >> VQ_SYNC_ROW_BITS) == rank) {
+            const int64_t row = who & (uint32_t)(VQ_SYNC_MAX_ROWS - 1);
+            for (int d = lane; d < D; d += 64) dst[d] = load_elem<DT>(x, row * D + d);
+        } else {
+            for (int d = lane; d < D; d += 64) dst[d] = -0.0f;
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) dst[d] = 0.0f;
+    }
+}
+
 // The CVQ-VAE update with anchors for the listed codes only, wave per code — the expressions of cvq_update_kernel /
 // cvq_step_kernel in the same order (bit-identical results on finite data):
 //   p' = p g + (hist/numel)(1-g);  decay = 1 - exp(-p' K 10/(1-g) - eps);  w' = w decay + a (1-decay)   for listed codes,
@@ -228,7 +300,7 @@ __global__ void cvq_pack_kernel(const int32_t *__restrict__ hist, int64_t numel,
 template <int DT, bool PACKED>
 __global__ void cvq_apply_kernel(const float *w_in, float *w_out, const float *p_in, float *p_out, const int32_t *hist,
                                  int64_t numel, const void *x, const int64_t *col_idx, const float *packed, int world,
-                                 const int32_t *__restrict__ slot, int64_t K, int D, float ema_decay, float eps) {
+                                 const int32_t *__restrict__ slot, int cap, int64_t K, int D, float ema_decay, float eps) {
     const int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (k >= K) return;
@@ -237,8 +309,10 @@ __global__ void cvq_apply_kernel(const float *w_in, float *w_out, const float *p
     else freq = (float)hist[k] / (float)numel;
     const float pk = p_in[k] * ema_decay + freq * (1.0f - ema_decay);
     const float decay = cvq_decay_of(pk, K, ema_decay, eps), om = 1.0f - decay;
+    // a slot at or beyond the capacity the column pass and the pack were sized for has no anchor anywhere (a list longer than
+    // the caller's capacity: include/vqhip.h): the code keeps w * decay, nothing outside col_idx / packed is read
     const int s = slot[k];
-    if (s >= 0) {
+    if (s >= 0 && s < cap) {
         if constexpr (PACKED) {
             const float *a = packed + VQ_PACK_HEADER(K) + (int64_t)s * D;
             const float ws = (float)world;

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from .utils import all_reduce_sum, exchanging, get_world_size
+from .utils import all_reduce_min, all_reduce_sum, exchanging, get_rank, get_world_size
 
 MAX_WORLD = 256
 
@@ -47,5 +47,26 @@ def cvq_exchange(hist32: torch.Tensor, numel: int, x: torch.Tensor, col_idx: Opt
     if get_world_size() > MAX_WORLD:
         raise RuntimeError(f'packed exchange: exact fp32 count sums hold for up to {MAX_WORLD} ranks')
     packed = ops.cvq_pack(hist32, numel, x, col_idx, count, cap, K)
+    all_reduce_sum(packed)
+    return packed
+
+
+def cvq_exchange_sync(hist32: torch.Tensor, numel: int, x: torch.Tensor, xq: Optional[torch.Tensor], eq: Optional[torch.Tensor],
+                      rows: torch.Tensor, col_idx: Optional[torch.Tensor], count: Optional[torch.Tensor], cap: int, K: int,
+                      metric) -> torch.Tensor:
+    """The CVQ-VAE exchange under NearestAnchor(sync=True) (vq/algorithms/cvqvae/anchors.py:50-57,83-84): every rank's column
+    pass covered its own tokens (``col_idx``); the ranks agree on the global nearest latent per listed code through a MIN
+    all-reduce of 8·cap bytes of keys, the winner alone contributes its latent to the packed buffer (-0.0 elsewhere) and one SUM
+    all-reduce of 4·(2K + 4 + cap·D) bytes delivers histogram, token count and the winners' rows — against the reference's
+    all-gather of world·N·(K + D) floats.  ``xq`` / ``eq``: the operands the column pass was given.  Returns the reduced buffer
+    (``ops.cvq_apply`` with world = 1: the anchors are not averaged)."""
+    if get_world_size() > MAX_WORLD:
+        raise RuntimeError(f'packed exchange: exact fp32 count sums hold for up to {MAX_WORLD} ranks')
+    rank = get_rank()
+    keys = None
+    if cap > 0:
+        keys = ops.cvq_col_keys(xq, eq, rows, count, cap, col_idx, metric, rank)
+        all_reduce_min(keys)
+    packed = ops.cvq_pack_sync(hist32, numel, x, keys, count, cap, K, rank)
     all_reduce_sum(packed)
     return packed

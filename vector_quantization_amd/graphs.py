@@ -29,6 +29,7 @@ GPU is still busy with the rest of the previous replay (round 4 captured K only:
 """
 from __future__ import annotations
 
+import time
 from typing import Optional
 
 import torch
@@ -84,12 +85,13 @@ class GraphedQuantizer(nn.Module):
         step = self._step = _Step(quantizer)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._caps, self._calls, self._steps = [], [], []
+        self.poll_timeout_s = 2.0                # how long a replay waits for the previous one's list length before it counts itself
         self._cvq = self._chained_cvq_callback(quantizer, sample_x) if self._train else None
         from . import ops
         with ops.owned_mse_scratch(self._mse_scratch):
             if self._cvq is not None:
                 K = quantizer.codebook_size
-                self._caps = [c for c in bucket_caps if c < K] + [K]
+                self._caps = sorted({int(c) for c in bucket_caps if 0 < int(c) < K}) + [K]        # ascending, no duplicates
                 try:
                     for cap in self._caps:
                         self._cvq.capture_plan = dict(cap=cap, chained=True)
@@ -138,27 +140,45 @@ class GraphedQuantizer(nn.Module):
         cb = self._cvq
         p = cb.probability
         st = cb._step_state
-        if st is None or self._seq is None or self._list_version != (p._version, p.data_ptr()):
-            cb.refresh_list()                                     # first replay, or probabilities changed from outside (synchronises)
+        me = ('replay', id(self))
+        # The chain trusts rows / slot / count / the early word to describe the probabilities the replay starts from.  That holds
+        # only while the LAST writer of that state was a replay of this object: an eager train step in between (a ragged last
+        # batch, say) rewrites the list in place without touching the early word or `p._version`, and so does another
+        # GraphedQuantizer on the same module — `writer` (train_step.CvqStepState) names the last one
+        if st is None or self._seq is None or st.writer != me or self._list_version != (p._version, p.data_ptr()):
+            count = self._resync()
             st = cb._step_state
-            self._list_version = (p._version, p.data_ptr())
-            self._seq = int(st.seq_dev.item())
-            count = int(st.count_host[0])
         else:
             # the previous replay publishes {its sequence number, the length of THIS step's list} as soon as its histogram is final:
             # usually long since there — the rest of that replay (column pass, update, decode, backward) is what the GPU is running now
-            word, spins = int(st.early_host[0]), 0
-            while (word >> 32) != self._seq:
-                spins += 1
-                if spins > 50_000_000:
-                    raise RuntimeError('GraphedQuantizer: the previous replay never published its list length')
-                word = int(st.early_host[0])
-            count = word & 0xFFFFFFFF
+            word = int(st.early_host[0])
+            if (word >> 32) != self._seq:
+                deadline = time.monotonic() + self.poll_timeout_s
+                while (word >> 32) != self._seq and time.monotonic() < deadline:
+                    word = int(st.early_host[0])
+            if (word >> 32) == self._seq:
+                count = word & 0xFFFFFFFF
+            else:                                                 # never published (a failed replay, a non-coherent pinned pool): count on the spot
+                count = self._resync()
+                st = cb._step_state
         which = next(i for i, cap in enumerate(self._caps) if cap >= count)
         self.last_capacity = self._caps[which]
         z, loss = self._calls[which](x)
         self._seq += 1                                            # every replay advances the device counter by one
+        st.writer = me
+        st.list_of = None                                         # (an eager step after this one rebuilds the list: the host knows no count)
         return z, loss, self._steps[which].last_quant
+
+    def _resync(self) -> int:
+        """Rebuild the list for the current probabilities and re-read the device's sequence number (one synchronisation): the first
+        replay, probabilities changed from outside, or another writer since the last replay."""
+        cb = self._cvq
+        cb.refresh_list()
+        st = cb._step_state
+        p = cb.probability
+        self._list_version = (p._version, p.data_ptr())
+        self._seq = int(st.seq_dev.item())
+        return int(st.count_host[0])
 
     def forward(self, x: torch.Tensor):
         if tuple(x.shape) != self._shape or x.dtype != self._dtype:

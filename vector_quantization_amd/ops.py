@@ -636,9 +636,10 @@ def cvq_pack(hist32: torch.Tensor, numel: int, x: torch.Tensor, col_idx: torch.T
 def cvq_apply(w_in: torch.Tensor, w_out: torch.Tensor, p_in: torch.Tensor, p_out: torch.Tensor, slot: torch.Tensor,
               ema_decay: float, eps: float, hist32: Optional[torch.Tensor] = None, numel: int = 0,
               x: Optional[torch.Tensor] = None, col_idx: Optional[torch.Tensor] = None,
-              packed: Optional[torch.Tensor] = None, world: int = 1) -> None:
+              packed: Optional[torch.Tensor] = None, world: int = 1, cap: Optional[int] = None) -> None:
     """The CVQ-VAE update with anchors for the listed codes (``slot``): from the all-reduced ``packed`` buffer of ``world``
-    ranks, or (one rank) from ``hist32`` / ``numel`` / ``x`` / ``col_idx``.  ``w_out`` / ``p_out`` may alias the inputs."""
+    ranks, or (one rank) from ``hist32`` / ``numel`` / ``x`` / ``col_idx``.  ``w_out`` / ``p_out`` may alias the inputs.
+    ``cap``: the capacity the column pass / the pack were sized for (default: what the buffers handed in hold)."""
     _require_cuda(w_in, w_out, p_in, p_out, slot)
     K, D = w_in.shape
     for t in (w_in, w_out):
@@ -654,9 +655,47 @@ def cvq_apply(w_in: torch.Tensor, w_out: torch.Tensor, p_in: torch.Tensor, p_out
             assert x.shape[1] == D
     else:
         assert packed.dtype == torch.float32 and packed.is_contiguous()
+    if cap is None:
+        cap = (packed.numel() - (2 * K + 4)) // D if packed is not None else (col_idx.numel() if col_idx is not None else 0)
+    cap = max(0, min(int(cap), K))
     check(_lib.lib().vqhip_cvq_apply(_ptr(w_in), _ptr(w_out), _ptr(p_in), _ptr(p_out), _ptr(hist32), int(numel), _ptr(x), dt,
-                                     _ptr(col_idx), _ptr(packed), int(world), _ptr(slot), K, D, ema_decay, eps, _stream()),
+                                     _ptr(col_idx), _ptr(packed), int(world), _ptr(slot), cap, K, D, ema_decay, eps, _stream()),
           'vqhip_cvq_apply')
+
+
+SYNC_MAX_ROWS = 1 << 24
+
+
+@_on_tensor_device
+def cvq_col_keys(x: torch.Tensor, e: torch.Tensor, rows: torch.Tensor, count: torch.Tensor, cap: int, col_idx: torch.Tensor,
+                 metric, rank: int) -> torch.Tensor:
+    """NearestAnchor(sync=True) across ranks (include/vqhip.h: vqhip_cvq_col_keys): int64 [cap] keys of this rank's local column
+    winners — (distance, rank, row) in torch.argmin's order, MIN-all-reducible as signed integers.  ``x`` / ``e`` are the operands
+    ``col_argmin_rows`` was given."""
+    _require_cuda(x, e, rows, count, col_idx)
+    x, dt = _latents(x)
+    e = _codebook(e)
+    N, D = x.shape
+    K = e.shape[0]
+    keys = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+    if cap > 0:
+        check(_lib.lib().vqhip_cvq_col_keys(_ptr(x), dt, _ptr(e), _ptr(rows), _ptr(count), cap, _ptr(col_idx), N, K, D, METRICS[metric],
+                                            int(rank), _ptr(keys), _stream()), 'vqhip_cvq_col_keys')
+    return keys[:cap]
+
+
+@_on_tensor_device
+def cvq_pack_sync(hist32: torch.Tensor, numel: int, x: torch.Tensor, keys: torch.Tensor, count: torch.Tensor, cap: int, K: int,
+                  rank: int) -> torch.Tensor:
+    """``cvq_pack`` behind the MIN all-reduce of the keys: payload row i = x[row] on the rank the reduced key names, -0.0 elsewhere."""
+    _require_cuda(hist32, x)
+    x, dt = _latents(x)
+    D = x.shape[1]
+    assert hist32.dtype == torch.int32 and hist32.is_contiguous() and hist32.numel() == K
+    packed = torch.empty(pack_floats(K, cap, D), dtype=torch.float32, device=x.device)
+    check(_lib.lib().vqhip_cvq_pack_sync(_ptr(hist32), int(numel), _ptr(x), dt, _ptr(keys) if cap else None, _ptr(count) if cap else None,
+                                         cap, int(rank), K, D, _ptr(packed), _stream()), 'vqhip_cvq_pack_sync')
+    return packed
 
 
 def _any(t: torch.Tensor):

@@ -407,13 +407,19 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
     def _sparse_ok(self, d, hist32) -> bool:
         if self._sparse_anchors is False or type(self._anchor) is not NearestAnchor:
             return False
-        if self._anchor._sync and get_world_size() > 1:          # global nearest token: gathered latents (anchors.py:50-57)
-            return False
         if get_world_size() > exchange.MAX_WORLD:                # count pieces no longer exact in fp32: the dense flow below
+            return False
+        if self._sync_exchange() and d.shape[0] > ops.SYNC_MAX_ROWS:      # a key holds the row in 24 bits (include/vqhip.h)
             return False
         p = self.probability
         return (isinstance(d, LazyDistance) and hist32 is not None and p.is_cuda and p.dtype == torch.float32
                 and ops.coarse_supported(self.quantizer.embedding_dim))
+
+    def _sync_exchange(self) -> bool:
+        """NearestAnchor(sync=True) over more than one rank: the GLOBAL nearest latent per code (anchors.py:50-57).  The reference
+        all-gathers latents and the [N, K] matrix; here the ranks agree on the winner by a MIN all-reduce of 8-byte keys and the
+        winner alone contributes its row to the packed SUM (include/vqhip.h: vqhip_cvq_col_keys)."""
+        return bool(self._anchor._sync) and exchanging()
 
     def _listed_codes(self, p: torch.Tensor, K: int, capturing: bool):
         """(rows, slot, count, cap): the device-side list for the step that starts from ``p`` and a host-known bound on its
@@ -457,10 +463,14 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         p_out = p_in if inplace else torch.empty_like(p_in)
         if not exchanging():
             ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, hist32=hist32, numel=quant.numel(),
-                          x=xr, col_idx=col)
+                          x=xr, col_idx=col, cap=cap)
+        elif self._sync_exchange():                              # global winners: keys MIN-reduced, then the masked packed SUM
+            packed = exchange.cvq_exchange_sync(hist32, quant.numel(), xr, xq if cap > 0 else None, eq if cap > 0 else None, rows,
+                                                col, count, cap, K, d.metric)
+            ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, packed=packed, world=1, cap=cap)
         else:                                                    # histogram ‖ token count ‖ [cap, D] anchors: one all-reduce
             packed = exchange.cvq_exchange(hist32, quant.numel(), xr, col, count, cap, K)
-            ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, packed=packed, world=world)
+            ops.cvq_apply(w_in, w_out, p_in, p_out, slot, self._ema.decay, self._eps, packed=packed, world=world, cap=cap)
         if inplace:
             if p_out is not self.probability:                    # (a non-contiguous buffer was copied above)
                 self.probability.copy_(p_out)
@@ -487,7 +497,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
             return False
         if self._sparse_anchors is False or type(self._anchor) is not NearestAnchor:
             return False
-        if (self._anchor._sync and get_world_size() > 1) or get_world_size() > exchange.MAX_WORLD:
+        if get_world_size() > exchange.MAX_WORLD or (self._sync_exchange() and x.shape[0] > ops.SYNC_MAX_ROWS):
             return False
         if type(q.distance) not in (L2Distance, CosineDistance) or not ops.coarse_supported(q.embedding_dim) or q._cache_codebook:
             return False
@@ -514,7 +524,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         """_encode + after_encode (sparse-anchor flow of `_sparse_step`) + decode + MSE losses + STE of one training step from
         one host call.  Returns (quant, z_ste, m_cb, m_cm, m_vqgan) with the reference's memo side effects."""
         from .. import functional as VF, train_step
-        from ..utils import all_reduce_sum
+        from ..utils import all_reduce_min, all_reduce_sum, get_rank
         q = self.vector_quantizer
         weight = q.embedding.weight
         K, D = weight.shape
@@ -541,6 +551,7 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         w_out = w_in if w_inplace else torch.empty_like(w_in)
         p_out = p_in if inplace else torch.empty_like(p_in)
         exch = exchanging()
+        sync = self._sync_exchange()
         comm = None
         if exch and not exchange_log.enabled:
             from .. import rccl
@@ -551,7 +562,8 @@ class CVQVAECallback(UpdateMixin, BaseCallback):
         e_alias = weight.view_as(weight) if (torch.is_grad_enabled() and weight.requires_grad) else w_in
         out = train_step.cvq_forward(xd, w_in, p_in, w_out, p_out, metric, self._ema.decay, self._eps, beta, st, cap=cap,
                                      list_ready=list_ready, prefetch=prefetch, exchange=exch, world=get_world_size(), comm=comm,
-                                     all_reduce=all_reduce_sum if exch else None, tail=True, early_count=early)
+                                     all_reduce=all_reduce_sum if exch else None, tail=True, early_count=early,
+                                     anchor_sync=sync, rank=get_rank() if sync else 0, all_reduce_min=all_reduce_min if sync else None)
         self.last_exchange_rows = out['cap_used']
         self._listed = None                                      # (the hook-by-hook flow's prefetched list is void now)
         if Store.DRY_RUN:

@@ -111,12 +111,12 @@ def _bootstrap(device: torch.device) -> int:
     return comm.value
 
 
-def communicator(t: torch.Tensor) -> Optional[int]:
+def communicator(t: torch.Tensor, dtype: torch.dtype = torch.float32) -> Optional[int]:
     """The ncclComm_t for ``t``'s exchange, or None when ``dist.all_reduce`` is to be used (see the module docstring)."""
     m = mode()
     if m != 'direct' or not (dist.is_available() and dist.is_initialized()):      # 'auto' resolves to 'torch' (module docstring)
         return None
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         return None
     if dist.get_backend() != 'nccl':
         if m == 'direct':
@@ -145,6 +145,14 @@ def all_reduce(t: torch.Tensor, comm: int) -> torch.Tensor:
     L = _lib.lib()
     _lib.check(L.vqhip_allreduce_packed(t.data_ptr(), t.numel(), comm, torch.cuda.current_stream(t.device).cuda_stream),
                'vqhip_allreduce_packed')
+    return t
+
+
+def all_reduce_min(t: torch.Tensor, comm: int) -> torch.Tensor:
+    """In-place int64 MIN of ``t`` over the ranks, enqueued on the current stream (the key exchange of NearestAnchor(sync=True))."""
+    L = _lib.lib()
+    _lib.check(L.vqhip_allreduce_min_i64(t.data_ptr(), t.numel(), comm, torch.cuda.current_stream(t.device).cuda_stream),
+               'vqhip_allreduce_min_i64')
     return t
 
 

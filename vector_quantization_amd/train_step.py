@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 
 from . import _lib, ops
-from ._lib import STEP_AFTER_EXCHANGE, STEP_ALL, STEP_BEFORE_EXCHANGE, check
+from ._lib import STEP_AFTER_EXCHANGE, STEP_ALL, STEP_BEFORE_EXCHANGE, STEP_PACK_SYNC, check
 from .ops import METRICS, _bytes, _codebook, _latents, _mse_scratch, _on_tensor_device, _stream
 
 
@@ -69,28 +69,38 @@ class CvqStepState:
         self.early_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.seq_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.list_of = None
+        self.writer = None        # who wrote rows / slot / count last: 'eager' (a host-known count behind `event`) or a GraphedQuantizer's token
+        self.keys = None                                          # int64 [K]: NearestAnchor(sync=True)'s key exchange (lazily)
         self.arena = _Arena()
 
     def list_valid_for(self, p: torch.Tensor) -> bool:
+        """True when rows / slot / count AND the pinned count word behind `event` describe ``p``: the last writer was an eager
+        step (or `refresh_list`) for exactly this tensor.  A graph replay writes the list in place without a host-side record —
+        `writer` then names the replaying object and the next eager step recounts."""
         lo = self.list_of
-        return lo is not None and lo[0] is p and lo[1] == p._version and lo[2] == p.data_ptr()
+        return self.writer == 'eager' and lo is not None and lo[0] is p and lo[1] == p._version and lo[2] == p.data_ptr()
 
     def mark_list(self, p: torch.Tensor) -> None:
         self.list_of = (p, p._version, p.data_ptr())
+        self.writer = 'eager'
 
     def invalidate(self) -> None:
         self.list_of = None
+        self.writer = None
 
 
 @_on_tensor_device
 def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: torch.Tensor, p_out: torch.Tensor, metric,
                 ema_decay: float, eps: float, beta: float, state: CvqStepState, *, cap: int, list_ready: bool, prefetch: bool,
-                exchange: bool, world: int, comm: Optional[int], all_reduce=None, tail: bool = True, early_count: bool = False):
+                exchange: bool, world: int, comm: Optional[int], all_reduce=None, tail: bool = True, early_count: bool = False,
+                anchor_sync: bool = False, rank: int = 0, all_reduce_min=None):
     """The CVQ-VAE training forward as one library call (two around a caller-issued collective when ``comm`` is None and the
     exchange has more than one rank: ``all_reduce(packed_view)`` is then called between the halves).
 
     cap >= 0: capacity of the listed-code launches; cap < 0: the library reads the prefetched count itself (the pinned word
-    of ``state``, behind the event of its copy).  Returns a dict: idx, hist, xq (cosine), prepared (the codebook image),
+    of ``state``, behind the event of its copy).  ``anchor_sync`` (with ``exchange``): NearestAnchor(sync=True) — the ranks agree
+    on the global nearest latent per listed code through ``all_reduce_min(keys)`` before the packed SUM (three library calls
+    around the two collectives, one with a communicator).  Returns a dict: idx, hist, xq (cosine), prepared (the codebook image),
     z_ste, mse (fp32[4]), cap_used, exchange_floats."""
     ops._require_cuda(x, w_in, p_in, w_out, p_out)
     x, dt = _latents(x)
@@ -133,6 +143,17 @@ def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: 
     a.cap_used, a.exchange_floats = -1, 0
     a.early_word_host = state.early_host.data_ptr() if early_count else None
     a.early_seq_dev = state.seq_dev.data_ptr() if early_count else None
+    sync = bool(anchor_sync and exchange)
+    a.anchor_sync, a.rank = int(sync), int(rank)
+    keys = None
+    if sync:
+        if capturing:
+            keys = torch.empty(K, dtype=torch.int64, device=dev)
+        else:
+            if state.keys is None:
+                state.keys = torch.empty(K, dtype=torch.int64, device=dev)
+            keys = state.keys
+    a.keys = _p(keys)
     stream = _stream()
     if cap < 0 and not state.event_handle:           # no raw handle on this torch build: the wait happens here instead
         state.event.synchronize()
@@ -144,6 +165,11 @@ def cvq_forward(x: torch.Tensor, w_in: torch.Tensor, p_in: torch.Tensor, w_out: 
     else:
         a.phases = STEP_BEFORE_EXCHANGE
         check(L.vqhip_cvq_forward(ctypes.byref(a), stream), 'vqhip_cvq_forward')
+        if sync:
+            if a.cap_used > 0:
+                all_reduce_min(keys[:a.cap_used])
+            a.phases = STEP_PACK_SYNC
+            check(L.vqhip_cvq_forward(ctypes.byref(a), stream), 'vqhip_cvq_forward')
         all_reduce(packed[:a.exchange_floats])
         a.phases = STEP_AFTER_EXCHANGE
         check(L.vqhip_cvq_forward(ctypes.byref(a), stream), 'vqhip_cvq_forward')

@@ -185,6 +185,20 @@ def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def all_reduce_min(t: torch.Tensor) -> torch.Tensor:
+    """MIN all-reduce of an int64 tensor, in place, counted by ``exchange_log`` — the key exchange of NearestAnchor(sync=True)
+    (include/vqhip.h: vqhip_cvq_col_keys).  Routes as ``all_reduce_sum``."""
+    from . import rccl
+    if os.environ.get('VQ_DEBUG_SKIP_ALLREDUCE') == '1' and get_world_size() == 1:
+        return t
+    comm = rccl.communicator(t, dtype=torch.int64)
+    if comm is not None:
+        exchange_log.collective(rccl.all_reduce_min, t, comm)
+    else:
+        exchange_log.collective(dist.all_reduce, t, op=dist.ReduceOp.MIN)
+    return t
+
+
 # ---- one exchange step of the codebook update (SURVEY.md §8e) ----
 
 def all_reduce_statistics(hist: torch.Tensor, numel: Optional[int] = None, sums: Optional[torch.Tensor] = None):
