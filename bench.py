@@ -96,10 +96,34 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def count_gpus_sysfs():
+    """GPUs of this node as the kernel driver lists them — KFD topology nodes with SIMDs (CPU nodes have simd_count 0) — cut to
+    the devices a HIP/ROCR visibility mask leaves.  Pure file reads: the launching parent opens no device and loads no GPU
+    runtime (round-5 review: `torch.cuda.device_count()` is not guaranteed to stay clear of it on every ROCm build).  None when
+    the topology is not readable (the ranks then find out for themselves)."""
+    import glob
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            for ln in open(path):
+                f = ln.split()
+                if len(f) == 2 and f[0] == 'simd_count' and int(f[1]) > 0:
+                    n += 1
+        except OSError:
+            return None
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        mask = os.environ.get(var)
+        if mask is not None and mask.strip() != '':
+            n = min(n, len([m for m in mask.split(',') if m.strip() != '']))
+    return n
+
+
 def launch_ranks(n: int) -> int:
-    import torch
-    have = torch.cuda.device_count()            # counts devices without initialising the GPU runtime in this process
-    if have < n and os.environ.get('VQ_BENCH_SHARE_GPU') != '1':      # (share mode: a plumbing check, every rank on cuda:0 over gloo)
+    have = count_gpus_sysfs()
+    if have is not None and have < n and os.environ.get('VQ_BENCH_SHARE_GPU') != '1':      # (share mode: a plumbing check, every rank on cuda:0 over gloo)
         print(f'bench.py: {n}-rank launch failed: --gpus {n} but this node has {have} GPU(s); refusing to start '
               f'(never a silent smaller run)', file=sys.stderr)
         return 2
@@ -163,12 +187,13 @@ def cpu_baseline(reps: int = 5):
     med1, used1 = _time_cpu_forward(tr, x1, w1, 'L2', 'vqgan', reps)
     torch.set_num_threads(used)
     return {
-        'value': n2 / med, 'unit': 'tokens/s', 'cores': used, 'kind': 'port',
+        'value': n2 / med, 'unit': 'tokens/s', 'cores': os.cpu_count() or 1, 'threads_used': used, 'kind': 'port',
         'sample': f'median of {reps} timed forwards (after 1 warm-up) of the reference ATen path (torch.cdist+argmin+'
                   f'embedding+VQGAN loss+STE, fp32; oracle/torch_ref.py, pinned byte-identical to the reference files) '
-                  f'over {n2} tokens (32 images), K={K_CODES}, D={DIM}; best of several thread counts',
+                  f'over {n2} tokens (32 images), K={K_CODES}, D={DIM}; `cores` = os.cpu_count() of this host (BASELINE.md §2), `threads_used` = the '
+                  f'torch thread count that was fastest among a few (ATen\'s CPU GEMM does not scale to every hardware thread)',
         'ms_per_forward': med * 1e3,
-        'c1': {'value': 1024 / med1, 'unit': 'tokens/s', 'cores': used1, 'ms_per_forward': med1 * 1e3,
+        'c1': {'value': 1024 / med1, 'unit': 'tokens/s', 'cores': os.cpu_count() or 1, 'threads_used': used1, 'ms_per_forward': med1 * 1e3,
                'sample': f'same, BASELINE configs[0]: 1024 tokens, K=1024, D=256, median of {reps}'},
     }
 
@@ -281,7 +306,11 @@ class Bench:
             L.vqhip_profile_enable(0)
             prof = (ms_sum.value, launches.value)
         el = self.torch.tensor([t1 - t0], dtype=self.torch.float64, device=self.coll_dev)
+        self.last_rank_seconds = [t1 - t0]
         if self.distributed:
+            every = [self.torch.zeros_like(el) for _ in range(self.world)]
+            self.dist.all_gather(every, el)                       # each rank's own clock around the same K steps
+            self.last_rank_seconds = [float(t.item()) for t in every]
             self.dist.all_reduce(el, op=self.dist.ReduceOp.MAX)
         return float(el.item()), out, prof
 
@@ -290,10 +319,21 @@ class Bench:
         first block.  Returns (per-block seconds, last output, (kernel ms sum, launches))."""
         el, out, prof = self.timed(fn, steps, warmup, profile=True)
         blocks = [el]
+        self.block_rank_seconds = [self.last_rank_seconds]
         while sum(blocks) < min_seconds and len(blocks) < max_blocks:
             el, out, _ = self.timed(fn, steps, 0)
             blocks.append(el)
+            self.block_rank_seconds.append(self.last_rank_seconds)
         return blocks, out, prof
+
+    def gather_floats(self, value: float):
+        """[value on rank 0, value on rank 1, ...] on every rank."""
+        if not self.distributed:
+            return [float(value)]
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.coll_dev)
+        every = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(every, t)
+        return [float(v.item()) for v in every]
 
 
 def _median_block(blocks):
@@ -431,6 +471,61 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     return rec, prof
 
 
+def direct_route_subblock(B: Bench, tokens: int, timeout_s: float = 240.0):
+    """The communicating step once more with the exchange on the library's OWN communicator (VQHIP_ALLREDUCE=direct: RCCL enqueued
+    on the compute stream, rccl.py) — in a CHILD process per rank with a rendezvous of its own.  That route has executed at world
+    size 1 only (one-GPU builder boxes); its bootstrap catches failures but cannot catch a rank that hangs inside
+    ncclCommInitRank.  Here such a hang costs `timeout_s` and ends as a reported failure of THIS sub-block: the parent ranks —
+    which hold the line's numbers — only wait on their children and kill them (the exact process group they started) when the time
+    is up.  A child is a fresh `python bench.py --workload cvq` started with subprocess (never an exec from this process)."""
+    import signal
+    torch, dist = B.torch, B.dist
+    route = os.environ.get('VQ_BENCH_DIRECT_ROUTE') or ('torch' if B.share_gpu else 'direct')      # share mode (gloo): plumbing rehearsal only
+    port = torch.tensor([_free_port() if B.rank == 0 else 0], dtype=torch.int64, device=B.coll_dev)
+    dist.broadcast(port, 0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC_')}       # (the agent's store is not the child's)
+    env.update(VQHIP_ALLREDUCE=route, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(int(port.item())), VQ_BENCH_CHILD='1',
+               RANK=str(B.rank), WORLD_SIZE=str(B.world), LOCAL_RANK=os.environ.get('LOCAL_RANK', str(B.rank)))
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(B.world), '--workload', 'cvq', '--images', str(tokens // TOK_PER_IMAGE),
+           '--steps', '20', '--warmup', '5', '--min-seconds', '0.5', '--no-cpu-baseline', '--bind', 'off']      # (the child inherits this rank's CPUs)
+    t0 = time.perf_counter()
+    rec = {'route_requested': route, 'tokens_per_rank': tokens, 'timeout_s': timeout_s,
+           'what': 'the cvq step in a child process per rank with VQHIP_ALLREDUCE=' + route + ' (own ncclComm on the compute stream when direct)'}
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout_s)
+        rec['child_rc'] = proc.returncode
+        ok = proc.returncode == 0
+        if not ok:
+            rec['error'] = f'child exited with code {proc.returncode}: ' + (err or '')[-600:]
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)                   # the session this rank started, nothing else
+        except ProcessLookupError:
+            pass
+        out, err = proc.communicate()
+        ok = False
+        rec['error'] = f'child did not finish within {timeout_s:.0f} s (killed): ' + (err or '')[-600:]
+    rec['seconds'] = time.perf_counter() - t0
+    all_ok = B.all_ranks(ok)
+    if B.rank == 0 and ok:
+        lines = [ln for ln in (out or '').splitlines() if ln.startswith('{') and '"metric"' in ln]
+        if len(lines) == 1:
+            child = json.loads(lines[0])
+            blk = child.get('cvq', {})
+            for k in ('ms_per_step', 'tokens_per_s', 'collectives_per_step', 'exchange_bytes_per_step', 'collective_ms', 'exchange_route',
+                      'codebook_in_sync', 'exchange_rows', 'one_call_forward'):
+                rec[k] = blk.get(k)
+            rec['rccl_ranks'] = child.get('rccl_ranks')
+        else:
+            ok = False
+            rec['error'] = f'child printed {len(lines)} JSON lines'
+    rec['ok'] = bool(ok and all_ok)
+    if not all_ok and 'error' not in rec:
+        rec['error'] = 'the child of another rank failed or timed out'
+    return rec
+
+
 def verify_vqgan(B: Bench, q, x, w, out, N, K, D):
     """Outside the timed region: the timed batch's tokens against the all-fp32 route (every row) and the CPU oracle (a row
     sample); the loss against a float64 evaluation; which path the rows took."""
@@ -455,8 +550,7 @@ def verify_vqgan(B: Bench, q, x, w, out, N, K, D):
                      'single_candidate_rows': N - st[0] - st[1] - st[2]},
            'deterministic_rerun': same_again, 'loss': loss, 'loss_float64': loss64,
            'loss_rel_err': abs(loss - loss64) / max(1e-30, abs(loss64))}
-    assert mism == 0 and omis == 0 and same_again, f'bench.py parity self-check failed: {rec}'
-    assert rec['loss_rel_err'] <= 1e-5, rec
+    rec['ok'] = bool(mism == 0 and omis == 0 and same_again and rec['loss_rel_err'] <= 1e-5)
     return rec
 
 
@@ -552,6 +646,9 @@ def main():
                 if not cvq_graphs:
                     rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph replay of an RCCL collective has run at world size 1 only)'
                 extra['cvq'][str(toks)] = rec
+            if os.environ.get('VQ_BENCH_DIRECT', '1') != '0' and os.environ.get('VQ_BENCH_CHILD') != '1':
+                extra['cvq']['direct_route'] = direct_route_subblock(B, 12 * TOK_PER_IMAGE,
+                                                                     timeout_s=float(os.environ.get('VQ_BENCH_DIRECT_TIMEOUT', '240')))
         tokens_per_step_global = N * world
         scaling = 'weak'
         workload = ('VQGAN K=16384 D=256, 256x256 images -> 16x16 tokens, bf16 latents, VQGANQuantizer.forward of the '
@@ -610,9 +707,8 @@ def main():
         if not args.no_verify:                                   # tokens of the timed batch against the all-fp32 route
             xn, wn = ops.normalize_rows(x), ops.normalize_rows(w)
             mism = int((out[1].reshape(-1) != ops.argmin_exact(xn, wn, 'L2')).sum().item())
-            parity = {'parity_checked_rows': N, 'mismatches': mism,
+            parity = {'parity_checked_rows': N, 'mismatches': mism, 'ok': mism == 0,
                       'checked_against': 'vqhip_argmin_exact on the normalised operands, every row of the timed batch'}
-            assert mism == 0, parity
         tokens_per_step_global = N * world
         scaling = 'strong'
         workload = ('LlamaGen bulk tokenization: 2048 images per step in total, sharded over the ranks; '
@@ -620,10 +716,20 @@ def main():
         parallelism = f'dp{world} (images sharded, no collective)'
         metric = 'quantized tokens/sec, LlamaGen tokenizer encode K=16384 D=8'
 
+    # every rank checked its own timed batch: the line fails (exit code 3, after it is printed) if ANY rank's check failed
+    parity_ok = True
+    if parity is not None:
+        bad = B.gather_floats(0.0 if parity.get('ok') else 1.0)
+        mism_all = B.gather_floats(float(parity.get('mismatches', 0)))
+        parity['ranks_checked'] = len(bad)
+        parity['ranks_failed'] = [i for i, b in enumerate(bad) if b]
+        parity['mismatches_all_ranks'] = int(sum(mism_all))
+        parity_ok = not parity['ranks_failed']
+    kern_ms_ranks = B.gather_floats(prof[0] / max(1, prof[1]))     # the dominant kernel's average launch on each rank
     if rank == 0:
         elapsed = _median_block(blocks)
         tokens = tokens_per_step_global * args.steps
-        kern_ms = prof[0] / max(1, prof[1])
+        kern_ms = max(kern_ms_ranks)                               # the SLOWEST rank's kernel prices the roofline
         launches_per_step = prof[1] / max(1, args.steps)
         flops = 2.0 * N * K * D                                          # 2*K*D per token, per launch
         achieved_tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
@@ -661,7 +767,9 @@ def main():
                     'traffic_source': traffic_source,
                     'kernel_algorithmic_bytes': kernel_alg_bytes,
                     'traffic_over_kernel_algorithmic': (traffic / kernel_alg_bytes) if traffic else None,
-                    'kernel_ms': kern_ms, 'launches_timed': prof[1], 'launches_per_step': launches_per_step,
+                    'kernel_ms': kern_ms, 'kernel_ms_per_rank': [round(v, 5) for v in kern_ms_ranks],
+                    'kernel_ms_source': 'HIP events on the launch stream, this run; with more than one rank `achieved` / `frac` are the SLOWEST rank\'s',
+                    'launches_timed': prof[1], 'launches_per_step': launches_per_step,
                     'step_frac': step_tf / MFMA_F16_DENSE_PEAK_TFLOPS,
                     'step_frac_note': 'the same flops over the WHOLE step (ms_per_step: what `value` is), against the same peak',
                     'step_algorithmic_bytes': alg_bytes,
@@ -675,6 +783,10 @@ def main():
             roofline['kernel_ms_note'] = ('average over the proposal launches of a step: the row pass (N x K) and, when codes are listed, '
                                           'the role-swapped column pass (listed codes x N) — `achieved` prices the row pass only')
         per_step = sorted(b / args.steps * 1e3 for b in blocks)
+        rank_seconds = getattr(B, 'block_rank_seconds', None)
+        per_rank_ms = None
+        if rank_seconds and len(rank_seconds) == len(blocks):      # each rank's own clock around the median block's K steps
+            per_rank_ms = [round(v / args.steps * 1e3, 5) for v in rank_seconds[blocks.index(elapsed)]]
         out_line = {
             'metric': metric,
             'value': tokens / elapsed, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,
@@ -682,6 +794,7 @@ def main():
             'scaling': scaling, 'vs_baseline': None, 'dtype': 'f16+f32',
             'dtype_note': 'f16 MFMA (f32 accumulate) proposes candidates under a rigorous bound; the decision is exact f32',
             'data': 'synthetic', 'rccl_ranks': B.rccl_ranks, 'collective_backend': B.backend,
+            'per_rank_ms_per_step': per_rank_ms,
             'config': {'workload': workload, 'images_per_gpu': images, 'tokens_per_gpu_per_step': N, 'codebook': [K, D],
                        'parallelism': parallelism},
             'timing_note': f'value / ms_per_step: the median of {len(blocks)} timed blocks of exactly {args.steps} steps each '
@@ -708,6 +821,9 @@ def main():
         from vector_quantization_amd import rccl
         rccl.shutdown()
         dist.destroy_process_group()
+    if not parity_ok:
+        print(f'bench.py: parity self-check FAILED on rank(s) {parity["ranks_failed"]}: {parity}', file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == '__main__':

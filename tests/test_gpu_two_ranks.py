@@ -201,11 +201,39 @@ def test_bench_eight_ranks_on_a_shared_gpu(tmp_path):
     assert len(lines) == 1, res.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 8 and rec['rccl_ranks'] == 8 and rec['collective_backend'] == 'gloo' and rec['scaling'] == 'weak'
-    assert rec['parity']['mismatches'] == 0
+    assert rec['parity']['mismatches'] == 0 and rec['parity']['ranks_checked'] == 8 and rec['parity']['ranks_failed'] == []
+    assert rec['parity']['mismatches_all_ranks'] == 0
+    # what the first real multi-GPU run must show (round-5 review item 4): every rank's own clock and kernel time, the slowest one priced
+    assert len(rec['per_rank_ms_per_step']) == 8 and max(rec['per_rank_ms_per_step']) <= rec['ms_per_step'] * 1.0001
+    assert len(rec['roofline']['kernel_ms_per_rank']) == 8 and rec['roofline']['kernel_ms'] == max(rec['roofline']['kernel_ms_per_rank'])
+    direct = rec['cvq'].pop('direct_route')
     for toks, blk in rec['cvq'].items():
         assert blk['codebook_in_sync'] is True and blk['collectives_per_step'] == 1.0, (toks, blk)
         assert blk['one_call_forward'] is True
         assert blk['exchange_bytes_per_step'] >= 4 * (2 * 16384 + 4)
+    # the second sub-block: the same step in a child process per rank under a timeout (on RCCL: VQHIP_ALLREDUCE=direct; the shared-GPU
+    # rehearsal runs gloo, where only the plumbing — rendezvous of the children, their JSON, the agreement — can be exercised)
+    assert direct['ok'] is True and direct['route_requested'] == 'torch' and direct['rccl_ranks'] == 8, direct
+    assert direct['codebook_in_sync'] is True and direct['collectives_per_step'] == 1.0 and direct['ms_per_step'] > 0, direct
+
+
+def test_bench_direct_route_timeout_is_a_reported_failure(tmp_path):
+    """A child that does not finish in time (a rank hanging inside ncclCommInitRank on the first real multi-GPU run) is killed and
+    becomes `cvq.direct_route.ok == false` with the reason — the line itself is printed, complete, with exit code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU='1', VQ_BENCH_DIRECT_TIMEOUT='0.5')
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--images', '16',
+                          '--min-seconds', '0', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    direct = rec['cvq']['direct_route']
+    assert direct['ok'] is False and 'did not finish within' in direct['error'], direct
+    assert rec['n_gpus'] == 2 and rec['parity']['ranks_checked'] == 2 and len(rec['per_rank_ms_per_step']) == 2
+    assert all(blk['codebook_in_sync'] for k, blk in rec['cvq'].items() if k != 'direct_route')
 
 
 def test_callbacks_at_world_size_two(tmp_path):
