@@ -416,6 +416,7 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
     blocks, out, prof = B.timed_blocks(step, steps, warmup, min_seconds)
     el = _median_block(blocks)
     rec = {'tokens_per_rank': tokens, 'ms_per_step': el / steps * 1e3, 'tokens_per_s': tokens * B.world * steps / el,
+           'per_rank_ms_per_step': [round(v / steps * 1e3, 5) for v in B.block_rank_seconds[blocks.index(el)]],
            'blocks': len(blocks), 'ms_per_step_min': min(blocks) / steps * 1e3, 'ms_per_step_max': max(blocks) / steps * 1e3,
            'settle_steps': settle, 'exchange_rows_first_step': rows_first, 'exchange_rows': getattr(cvq_cb, 'last_exchange_rows', None),
            'one_call_forward': bool(q._one_call_step(x) is not None)}
@@ -593,6 +594,7 @@ def main():
         L.vqhip_set_tuning(2, int(os.environ['VQHIP_TUNE_SLICES']))
 
     parity = None
+    main_rank_seconds = None
     if wl == 'vqgan':
         images = args.images or 2048
         N, K, D = images * TOK_PER_IMAGE, K_CODES, DIM
@@ -621,6 +623,7 @@ def main():
             (loss + z.float().mean()).backward()
 
         blocks, out, prof = B.timed_blocks(step, args.steps, args.warmup, args.min_seconds)
+        main_rank_seconds = B.block_rank_seconds
         loss = float(out[1].item())
         hist = ops.hist(out[2]['quant'], K)                   # code-usage statistics outside the timed region
         used_codes = int((hist > 0).sum().item())
@@ -702,6 +705,7 @@ def main():
                 return q.encode(x, {})
 
         blocks, out, prof = B.timed_blocks(step, args.steps, args.warmup, args.min_seconds)
+        main_rank_seconds = B.block_rank_seconds
         loss = None
         used_codes = int((ops.hist(out[1], K) > 0).sum().item())
         if not args.no_verify:                                   # tokens of the timed batch against the all-fp32 route
@@ -783,10 +787,11 @@ def main():
             roofline['kernel_ms_note'] = ('average over the proposal launches of a step: the row pass (N x K) and, when codes are listed, '
                                           'the role-swapped column pass (listed codes x N) — `achieved` prices the row pass only')
         per_step = sorted(b / args.steps * 1e3 for b in blocks)
-        rank_seconds = getattr(B, 'block_rank_seconds', None)
         per_rank_ms = None
-        if rank_seconds and len(rank_seconds) == len(blocks):      # each rank's own clock around the median block's K steps
-            per_rank_ms = [round(v / args.steps * 1e3, 5) for v in rank_seconds[blocks.index(elapsed)]]
+        if main_rank_seconds is not None:                          # each rank's own clock around the median block's K steps
+            per_rank_ms = [round(v / args.steps * 1e3, 5) for v in main_rank_seconds[blocks.index(elapsed)]]
+        elif wl in ('cvq', 'vqkd'):
+            per_rank_ms = extra[wl].get('per_rank_ms_per_step')
         out_line = {
             'metric': metric,
             'value': tokens / elapsed, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps,

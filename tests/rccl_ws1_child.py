@@ -26,8 +26,9 @@ def cfg(kind, K, D):
         return dict(type='VQKDQuantizer', embedding=emb, distance=dict(type='CosineDistance'),
                     callbacks=[dict(type='VQKDCallback', ema=dict())],
                     losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True))))
+    # 'cvqsync': NearestAnchor(sync=True), the cluster config's anchor (configs/cluster/model.py:28) — the key exchange
     return dict(type='VQGANQuantizer', embedding=emb, distance=dict(type='CosineDistance'),      # configs/cvqvae/quantizer.py
-                callbacks=[dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))],
+                callbacks=[dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor', sync=kind == 'cvqsync'))],
                 losses=dict(vqgan_loss=dict(type='VQGANLoss')))
 
 
@@ -62,7 +63,7 @@ def main():
         torch.manual_seed(0)
         q = build_quantizer(cfg(kind, K, D))
         q.train()
-        q.init_weights(Config(dict(type='vqgan') if kind == 'cvq' else {}))
+        q.init_weights(Config(dict(type='vqgan') if kind.startswith('cvq') else {}))
         q = q.to(dev)
         q._forward_pre_hooks.clear()               # start from the given codebook: no lazy k-means init
         with torch.no_grad():
@@ -86,7 +87,7 @@ def main():
             quants.append((out[2] if graphed else out[2]['quant']).detach().clone().cpu().numpy())
         torch.cuda.synchronize()
         state = {'w': q.embedding.weight.detach().cpu().numpy(), 'quant': np.stack(quants)}
-        if kind == 'cvq':
+        if kind.startswith('cvq'):
             state['p'] = q.get_buffer('_probability').cpu().numpy()
         return state, calls, nbytes
 
@@ -95,7 +96,7 @@ def main():
 
     rec = {'N': N, 'K': K, 'D': D, 'steps': args.steps}
     os.environ['VQ_FORCE_EXCHANGE'] = '0'
-    ref = {kind: run(kind)[0] for kind in ('cvq', 'vqkd')}              # no process group: the one-rank flow
+    ref = {kind: run(kind)[0] for kind in ('cvq', 'vqkd', 'cvqsync')}   # no process group: the one-rank flow
 
     dist.init_process_group('nccl', device_id=dev)
     rec['backend'] = dist.get_backend()
@@ -106,7 +107,7 @@ def main():
     os.environ['VQ_FORCE_EXCHANGE'] = '1'
     for route in ('torch', 'direct'):
         os.environ['VQHIP_ALLREDUCE'] = route
-        for kind in ('cvq', 'vqkd'):
+        for kind in ('cvq', 'vqkd', 'cvqsync'):
             got, calls, nbytes = run(kind)
             rec[f'{kind}_{route}_bit_identical'] = same(ref[kind], got)
             rec[f'{kind}_{route}_collectives_per_step'] = calls / args.steps
@@ -116,7 +117,7 @@ def main():
     # for K listed codes; the results are still those of the eager step bit for bit.
     for route in ('direct', 'torch'):
         os.environ['VQHIP_ALLREDUCE'] = route
-        for kind in ('cvq', 'vqkd'):
+        for kind in ('cvq', 'vqkd', 'cvqsync'):
             try:
                 got, calls, _ = run(kind, graphed=True)
                 rec[f'{kind}_{route}_graphed_bit_identical'] = same(ref[kind], got)

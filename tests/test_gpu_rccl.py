@@ -43,17 +43,19 @@ def test_world_size_one_group_runs_on_rccl(ws1):
     assert ws1['backend'] == 'nccl' and ws1['world'] == 1 and ws1['rccl_ranks'] == 1
 
 
-@pytest.mark.parametrize('kind', ['cvq', 'vqkd'])
+@pytest.mark.parametrize('kind', ['cvq', 'vqkd', 'cvqsync'])
 @pytest.mark.parametrize('route', ['torch', 'direct'])
 def test_forced_exchange_equals_the_one_rank_flow(ws1, kind, route):
     assert ws1[f'{kind}_{route}_bit_identical'] is True
-    assert ws1[f'{kind}_{route}_collectives_per_step'] == 1.0           # ONE packed all-reduce per training step
+    # ONE packed all-reduce per training step; NearestAnchor(sync=True) adds the MIN all-reduce of the keys in front of it
+    # (direct route: vqhip_allreduce_min_i64 — int64 MIN on the library's own communicator, on RCCL)
+    assert ws1[f'{kind}_{route}_collectives_per_step'] == (2.0 if kind == 'cvqsync' else 1.0)
     if route == 'direct':
         st = ws1['status_direct']
         assert st['direct'] is True and st['error'] is None, st         # libvqhip's own communicator was used
 
 
-@pytest.mark.parametrize('kind', ['cvq', 'vqkd'])
+@pytest.mark.parametrize('kind', ['cvq', 'vqkd', 'cvqsync'])
 def test_graph_replay_with_the_collective_captured(ws1, kind):
     # the direct route puts the collective on the captured stream itself; the torch route is reported alongside
     assert ws1[f'{kind}_direct_graphed_error'] is None, ws1[f'{kind}_direct_graphed_error']

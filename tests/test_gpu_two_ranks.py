@@ -205,7 +205,7 @@ def test_bench_eight_ranks_on_a_shared_gpu(tmp_path):
     assert rec['parity']['mismatches_all_ranks'] == 0
     # what the first real multi-GPU run must show (round-5 review item 4): every rank's own clock and kernel time, the slowest one priced
     assert len(rec['per_rank_ms_per_step']) == 8 and max(rec['per_rank_ms_per_step']) <= rec['ms_per_step'] * 1.0001
-    assert len(rec['roofline']['kernel_ms_per_rank']) == 8 and rec['roofline']['kernel_ms'] == max(rec['roofline']['kernel_ms_per_rank'])
+    assert len(rec['roofline']['kernel_ms_per_rank']) == 8 and abs(rec['roofline']['kernel_ms'] - max(rec['roofline']['kernel_ms_per_rank'])) < 1e-4
     direct = rec['cvq'].pop('direct_route')
     for toks, blk in rec['cvq'].items():
         assert blk['codebook_in_sync'] is True and blk['collectives_per_step'] == 1.0, (toks, blk)
