@@ -102,6 +102,8 @@ def count_gpus_sysfs():
     runtime (round-5 review: `torch.cuda.device_count()` is not guaranteed to stay clear of it on every ROCm build).  None when
     the topology is not readable (the ranks then find out for themselves)."""
     import glob
+    if not os.path.isdir('/sys/class/kfd'):          # no amdgpu compute driver on this host: no GPU
+        return 0
     nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
     if not nodes:
         return None

@@ -137,7 +137,7 @@ template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS>
 static int launch_coarse32_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                                int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
                                const int *n_dev, const VqGroupLists &grp, int pad_stage, int tpb, hipStream_t s) {
-    constexpr int LDS = NBUF * (TPS * 2 + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES;
+    constexpr int LDS = NBUF * (TPS * 2 + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES + VQ_STAGE_LDS_EXTRA;
     auto kern = coarse32_kernel<TT, WAVES, TPS, NBUF, NOAUX, KS, VQ_GROUP_TILES>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
@@ -263,6 +263,10 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
                     int ns = pick_slices(ntb0, L.nstages, VQ_MIN_SLICES_FILTER);
                     ns = ns > VQ_GROUP_MAX_SLICES ? VQ_GROUP_MAX_SLICES : ns;
                     *nslices_out = ns;
+                    // (Workgroups of up to sixteen waves, one per CU, where the codebook is not sliced — 13 waves at configs[2]: 3.25 per
+                    //  SIMD through ONE ring instead of two workgroups on 192 CUs and one on 64 — were built and measured in round 6:
+                    //  -2.4 % at 100 352 x 8192 x 32, -1 % at 131 072, +2 % at D = 8 / 16 and +10 % once a launch needs two rounds of them.
+                    //  Not kept: the stream is bound by what the matrix pipe may draw, not by where the waves sit: profiles/r06_c3_notes.txt)
                     int tpb = (ns == 1) ? balanced_tiles_per_block(N, full) : full;
                     tpb = (tpb + 1) & ~1;                                           // whole wide tiles
                     *fused_decide_out = 0;                                          // identification first: the decision stage is its own launch

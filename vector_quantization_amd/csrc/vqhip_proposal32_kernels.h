@@ -75,6 +75,9 @@ struct VqGroupLists { int *bcnt; uint32_t *blist; char *bfrag; float *rece2; int
 // group update once per GROUP: 8 + 4 / GT vector instructions per 16 scores.  What a group costs elsewhere is GT tiles per
 // request in identify32_kernel — GT MFMAs on 32 requests at a time — and nothing in second-pass rows: a lane identifies ONE
 // candidate whatever the group size, everything else it has seen is a bound either way.
+#ifndef VQ_W32_PF
+#define VQ_W32_PF 1             // A fragments this many code tiles ahead of their MFMAs (0: the round-5 loop, read at use)
+#endif
 template <int TT, int WAVES, int TPS, int NBUF, bool NOAUX, int KS = 1, int GT = 1>
 #ifndef VQ_W32_TT2_OCC
 #define VQ_W32_TT2_OCC 4        // waves per SIMD the two-wide-tile form (>= 262 144 rows) is compiled for (A/B: 3)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
         N = nd < N ? nd : N;
         if ((int64_t)(blockIdx.x / nslices) * tpb * 16 >= N) return;
     }
+    VQ_PHASE(0);
     cb_stats_publish(cbst);
     const bool wave_active = wave * TT * 2 < tpb;
     const int sl = blockIdx.x % nslices;
@@ -148,7 +152,12 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
         }
     }
 
+    VQ_PHASE(1);
     __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+    VQ_PHASE(2);
+#ifdef VQ_PHASE_STAMPS
+    const unsigned long long phase_clk0 = __builtin_amdgcn_s_memtime();
+#endif
 
     f32x16 accA[TT], accB[TT];
 #pragma unroll
@@ -158,8 +167,20 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
                                                                // the slice, so it never becomes a request (finite: the id bits
                                                                // would turn -inf into a signalling NaN)
 
+#ifdef VQ_STAGE_STAMPS            // diagnostic build only (tools/stage_stamps.py): the five stamps of coarse_kernel's loop, same buffer
+    unsigned long long *stamp_lds = (unsigned long long *)(lds + NBUF * STAGE_BYTES);
+    for (int i = threadIdx.x; i < 8 * VQ_STAGE_ITERS * 5; i += WAVES * 64) stamp_lds[i] = 0;
+    __syncthreads();
+#endif
     for (int64_t it = st0; it < st1 + 1; ++it) {
+#ifdef VQ_STAGE_STAMPS
+        const int stamp_it = (int)(it - st0);
+#endif
+        VQ_STAMP(0);
+#ifndef VQ_EXP_NO_DMA            // (timing-only diagnostic build: the ring is never refilled inside the loop)
         if (it + AHEAD < st1) issue_stage(it + AHEAD, (int)((it + AHEAD - st0) % NBUF));
+#endif
+        VQ_STAMP(1);
         const int64_t st = it - lag;
         if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
         const int buf = (int)((st - st0) % NBUF);
@@ -167,13 +188,31 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
         auto run_stage = [&](auto with_aux_tag) __attribute__((always_inline)) {
             constexpr bool WITH_AUX = decltype(with_aux_tag)::value;
+            // A fragments PF tiles ahead of their MFMAs, through a ring of PF + 1 register sets; the statements of a tile stay
+            // together (sched_barrier): left alone, hipcc sinks every fragment read down to its use — ds_read, s_waitcnt
+            // lgkmcnt(0), MFMA: the LDS latency exposed once per code tile and wave (the shipped round-5 loop:
+            // profiles/r06_c3_stage_stamps.txt)
+            constexpr int PF = VQ_W32_PF, RING = PF + 1;
+            half8 afr[RING][KS];
+            auto load_af = [&](int tile, half8 (&dst)[KS]) __attribute__((always_inline)) {
+#ifdef VQ_EXP_NO_LDS_READS      // timing-only diagnostic build: every tile multiplies the fragments of the stage's first tile
+                if (tile != 0) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) { dst[s] = afr[0][s]; asm volatile("" : "+v"(dst[s])); }
+                    return;
+                }
+#endif
+#pragma unroll
+                for (int s = 0; s < KS; ++s) dst[s] = *(const half8 *)(base + (tile * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
+            };
+#pragma unroll
+            for (int i = 0; i < PF; ++i) load_af(i, afr[i % RING]);
 #pragma unroll
             for (int ti = 0; ti < TPS; ++ti) {
                 f32x16 (&cur)[TT] = (ti & 1) ? accB : accA;
                 f32x16 (&prv)[TT] = (ti & 1) ? accA : accB;
-                half8 af[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) af[s] = *(const half8 *)(base + (ti * NSTEP + sub) * VQ_CHUNK_BYTES + piece + s * 512);
+                if (ti + PF < TPS) load_af(ti + PF, afr[(ti + PF) % RING]);
+                half8 (&af)[KS] = afr[ti % RING];
                 f32x16 init;
                 if constexpr (WITH_AUX) {                 // -se |e|^2 / 2 of this lane's code rows (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -189,6 +228,16 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
                 // the tile whose scores are retired below is tile st * TPS + ti - 1: number (ti - 1) mod GT of group gid
                 const int pg = (ti + GT - 1) % GT;            // (a constant once the tile loop is unrolled)
                 const uint32_t gid = (uint32_t)(st * (TPS / GT)) + (uint32_t)((ti + GT - 1) / GT) - 1u;
+#ifdef VQ_EXP_NO_EPILOGUE       // timing-only diagnostic build: the scores are never looked at; every MFMA stays live because the
+                // accumulators chain from tile to tile (prv -> cur) and the drain below reads the last ones
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], xf[t][0], prv[t], 0, 0, 0);
+#pragma unroll
+                    for (int s = 1; s < KS; ++s) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s], xf[t][s], cur[t], 0, 0, 0);
+                }
+                (void)init; (void)pg; (void)gid;
+#else
 #pragma unroll
                 for (int s = 0; s + 1 < KS; ++s)          // all but the last k-step, token tiles interleaved
 #pragma unroll
@@ -214,6 +263,8 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
                         b1[t] = vmax(b1[t], h);
                     }
                 }
+#endif
+                if constexpr (PF > 0) __builtin_amdgcn_sched_barrier(0);
             }
         };
         if constexpr (NOAUX) {
@@ -221,8 +272,31 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
         } else {       // the aux reads (four 16-byte LDS reads per lane and tile) are skipped where every value is zero anyway
             if (const_norm && st != (int64_t)pad_stage) run_stage(std::false_type{}); else run_stage(std::true_type{});
         }
+#ifdef VQ_STAGE_STAMPS
+        VQ_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        VQ_STAMP(3);
+        __syncthreads();
+        VQ_STAMP(4);
+#else
         __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+#endif
     }
+#ifdef VQ_STAGE_STAMPS
+    __syncthreads();
+    if (blockIdx.x < VQ_STAGE_WGS)
+        for (int i = threadIdx.x; i < 8 * VQ_STAGE_ITERS * 5; i += WAVES * 64) vq_stage_dbg[(size_t)blockIdx.x * 8 * VQ_STAGE_ITERS * 5 + i] = stamp_lds[i];
+    __syncthreads();
+#endif
+    VQ_PHASE(3);
+#ifdef VQ_PHASE_STAMPS           // slot 7: shader cycles of this workgroup's stream loop (tools/phase_stamps.py: clock = cycles / (stamp 3 - stamp 2))
+    if (threadIdx.x == 0 && blockIdx.x < VQ_PHASE_SLOTS) {
+        vq_phase_dbg[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memtime() - phase_clk0;
+        // slot 5: where the workgroup ran — HW_REG_XCC_ID (id 20) << 32 | HW_REG_HW_ID (id 4: wave, simd, pipe, cu, sh, se)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        vq_phase_dbg[8 * blockIdx.x + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // drain: the last tile (odd parity: it sits in accB)
     if (st1 > st0) {
 #pragma unroll
@@ -301,6 +375,11 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
             grp.rece2[(int64_t)(sl * 2 + 1) * Np + tokn] = -INFINITY;
         }
     }
+#ifdef VQ_PHASE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    VQ_PHASE(4);
+    VQ_PHASE(6);
+#endif
 }
 
 // Serves the identification requests of coarse32_kernel: one wave per bucket (group of GT code tiles x replica), four batches

@@ -18,16 +18,6 @@ from .distances import BaseDistance, LazyDistance
 from .losses import CodebookLoss, CommitmentLoss, VQGANLoss
 
 
-@InitRegistry.register_('uniform_')
-def _uniform_init(a: float = 0.0, b: float = 1.0):
-    return lambda w: nn.init.uniform_(w, a, b)
-
-
-@InitRegistry.register_('normal_')
-def _normal_init(mean: float = 0.0, std: float = 1.0):
-    return lambda w: nn.init.normal_(w, mean, std)
-
-
 @VQITQuantizerRegistry.register_()
 class VectorQuantizer(BaseQuantizer):
     # False (or VQHIP_ONE_CALL=0 in the environment): the callback-driven training forwards run hook by hook, one library call

@@ -10,7 +10,21 @@ class ModelRegistry(Registry):
 
 
 class InitRegistry(Registry):
-    """Stands in for todd.registries.InitRegistry: weight initialisers by name ('uniform_', 'normal_', ...)."""
+    """Stands in for todd.registries.InitRegistry: weight initialisers by name.  Any in-place initialiser of ``torch.nn.init``
+    resolves by its own name — ``dict(type='trunc_normal_', std=0.02)``, ``dict(type='xavier_uniform_')`` ... — as a factory
+    ``(**kwargs) -> (tensor -> tensor)``, what the generic branch of the reference hands to ``InitRegistry.build(config)``
+    (vq/algorithms/vq/quantizers.py:87-90); explicitly registered names take precedence."""
+
+    @classmethod
+    def resolve(cls, type_):
+        if isinstance(type_, str):
+            key = type_.rsplit('.', 1)[-1]
+            if cls._lookup(key) is None:
+                from torch.nn import init
+                fn = getattr(init, key, None)
+                if callable(fn) and key.endswith('_') and not key.startswith('_'):
+                    return lambda **kwargs: (lambda w: fn(w, **kwargs))
+        return super().resolve(type_)
 
 
 class VQRegistry(Registry):
