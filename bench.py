@@ -592,6 +592,9 @@ def main():
     extra = {}
     wl = args.workload
     L = _lib.lib()
+    for kv in filter(None, os.environ.get('VQHIP_TUNE', '').split(',')):      # A/B knobs (results unchanged), e.g. VQHIP_TUNE=17=0
+        k_, v_ = kv.split('=')
+        L.vqhip_set_tuning(int(k_), int(v_))
     if 'VQHIP_TUNE_SLICES' in os.environ:                   # A/B knob (results unchanged): codebook slices
         L.vqhip_set_tuning(2, int(os.environ['VQHIP_TUNE_SLICES']))
 

@@ -2,7 +2,8 @@
 """Randomised campaign on the GPU: vqhip_argmin (fp16 proposals + exact re-rank) against vqhip_argmin_exact (all-fp32
 MFMA, itself bit-equal to the CPU oracle in tests/) at sizes the CPU oracle cannot reach.  Any mismatch is a bug.
 usage: fuzz_vs_exact.py [seconds] [seed]   (VQ_FUZZ_DIMS=8,16: only those D; VQ_FUZZ_SMALL_N=1: 64 .. 16 384 rows against >= 4096 codes;
-VQ_FUZZ_FORCE_EXACT=1: see below)"""
+VQ_FUZZ_FORCE_EXACT=1: see below; VQ_FUZZ_BF16=1: bf16 latents in every trial — with VQ_FUZZ_DIMS=256 the batches of more than
+16 384 rows take the proposal kernel that makes its own token fragments)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -49,7 +50,7 @@ while time.time() < t_end:
         from vector_quantization_amd import _lib       # (tuning key 12: both forms of that pass, list lengths around the switch at 16)
         _lib.lib().vqhip_set_tuning(12, [0, 1, 2, 3, 7, 12, 15, 16, 17, 33, 100][ri(0, 11)])
     if os.environ.get('VQ_FUZZ_VERBOSE'): print(f'trial {trials + 1}: N={N} K={K} D={D} {metric} kind={kind} scale={scale}', flush=True)
-    xd = x.bfloat16() if ri(0, 3) == 0 else x
+    xd = x.bfloat16() if (ri(0, 3) == 0 or os.environ.get('VQ_FUZZ_BF16') == '1') else x      # VQ_FUZZ_BF16=1: bf16 latents in every trial
     if metric != 'L2':
         xq = ops.normalize_rows(xd); wq = ops.normalize_rows(w)
         if metric == 'CosineBF16':

@@ -25,6 +25,8 @@ x = w[torch.randint(0, K, (N,), device='cuda', generator=g)] + 0.05 * torch.rand
 if dt == 'bf16':
     x = x.bfloat16()
 L = _lib.lib()
+for kv in filter(None, os.environ.get('VQHIP_TUNE', '').split(',')):      # e.g. VQHIP_TUNE=17=0 (vqhip_set_tuning keys)
+    k, v = kv.split('='); L.vqhip_set_tuning(int(k), int(v))
 fn = getattr(ctypes.CDLL(_lib.LIB_PATH), 'vqhip_debug_phase_stamps', None)
 if fn is None:
     sys.exit('this library has no phase stamps: tools/build_exp.sh phase -DVQ_PHASE_STAMPS, then VQHIP_LIB=build/exp/libvqhip_phase.so')
@@ -65,6 +67,10 @@ for i, nm in enumerate(names):
     print(f'  {nm:24s}: min {us.min():6.2f}  median {np.median(us):6.2f}  max {us.max():6.2f} us after the first entry')
 d = (a[:, 3] - a[:, 2]) / 100.0
 print(f'  stream (first barrier -> done) per workgroup: min {d.min():.2f} median {np.median(d):.2f} max {d.max():.2f} us')
+pr = (a[:, 2] - a[:, 0]) / 100.0
+late = (a[:, 0] - t0) > 500                       # workgroups of the later rounds (they enter as CUs free up)
+print(f'  prologue (entry -> first barrier passed) per workgroup: first round min {pr[~late].min():.2f} median {np.median(pr[~late]):.2f} max {pr[~late].max():.2f} us'
+      + (f'; later rounds ({int(late.sum())} workgroups) min {pr[late].min():.2f} median {np.median(pr[late]):.2f} max {pr[late].max():.2f} us' if late.any() else ''))
 if a[:, 7].max() > 1:            # coarse32_kernel's diagnostic build: slot 7 = shader cycles of the stream loop
     clk = a[:, 7] / np.maximum(d, 1e-9) / 1e3
     print(f'  shader clock inside the stream loop (s_memtime / s_memrealtime): min {clk.min():.2f} median {np.median(clk):.2f} max {clk.max():.2f} GHz; '

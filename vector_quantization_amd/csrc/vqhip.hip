@@ -112,13 +112,14 @@ static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update ins
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
+static std::atomic<int> g_tune_xdirect{1};  // key 17: 0 = D = 256 batches keep the fp16 token image (x_prep / pre_kernel token side) (A/B; results unchanged)
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false, bool GROUPS = false>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false, bool GROUPS = false, int XD = 0>
 static int launch_coarse_cfg(const char *ximg, int64_t N, const char *frag, int64_t nstages, int nslices, float *rec,
                              int64_t Np, const VqCbStats *cbst, const float *xh2, const float *rho2, int Dp, int metric,
                              const VqDecideOut &dec, int pad_stage, int tpb, hipStream_t s) {
     constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES + VQ_STAGE_LDS_EXTRA;
-    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, NOAUX, GROUPS>;
+    auto kern = coarse_kernel<NSTEP, TT, WAVES, TPS, NBUF, FILTER, NOAUX, GROUPS, XD>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
     const int64_t ntiles = (N + 15) / 16;
@@ -150,14 +151,14 @@ static int launch_coarse32_cfg(const char *ximg, int64_t N, const char *frag, in
     return VQHIP_OK;
 }
 
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, int XD = 0>
 static int launch_rescan_cfg(const char *ximg, const char *frag, int64_t nstages, const int *rescan_list, const int *counters,
-                             const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s) {
+                             const float *thr, int *rescan_cnt, int *cand_list, hipStream_t s, const void *xrows = nullptr) {
     constexpr int LDS = NBUF * (TPS * NSTEP + VQ_AUX_CHUNKS(TPS)) * VQ_CHUNK_BYTES + WAVES * TT * 16 * 4 * (1 + VQ_RESCAN_LOCAL);
-    auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF>;
+    auto kern = rescan_kernel<NSTEP, TT, WAVES, TPS, NBUF, XD>;
     static LdsCache lds_set;
     if (int rc = ensure_dyn_lds((const void *)kern, LDS, lds_set)) return rc;
-    kern<<<256, WAVES * 64, LDS, s>>>(ximg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list);
+    kern<<<256, WAVES * 64, LDS, s>>>(ximg, frag, nstages, rescan_list, counters, thr, rescan_cnt, cand_list, xrows);
     VQ_CHECK_LAUNCH("rescan_kernel");
     return VQHIP_OK;
 }
@@ -194,6 +195,21 @@ static int balanced_tiles_per_block(int64_t N, int full) {
     return best;
 }
 
+// The token side made inside the proposal kernel's prologue instead of a token image (coarse_kernel<..., XD>):
+// the D = 256 form with 64 tokens per wave, rows as the caller holds them, the decision stage in its own launch.  One predicate
+// for the front (which then skips its token side), the proposal launch and the second pass (which reads the rows instead).
+static bool vq_xdirect(int64_t N, int64_t K, int D, int x_dtype, int metric, const int *n_dev) {
+    if (!g_tune_xdirect.load() || D != 256 || n_dev != nullptr || vq_cb_layout(K, D).nstages < 2) return false;   // (one slice would decide in-kernel)
+    // bf16 rows only: a piece of 8 latents has the fragment's own 16 bytes and is converted in place.  fp32 rows (XD = 2: twice the
+    // bytes per piece, a round trip per token tile, 58 spilled registers) cost a workgroup +44 us of prologue at 20 000 x 16384 x 256
+    // against +3 us for bf16 (profiles/r06_xdirect.txt): they keep the token image
+    if (x_dtype != VQHIP_DTYPE_BF16 && g_tune_xdirect.load() != 2) return false;
+    if (metric != VQHIP_METRIC_L2 && metric != VQHIP_METRIC_COS && metric != VQHIP_METRIC_COS_BF16) return false;   // (not the role-swapped column pass)
+    if (N <= VQ_FUSED_DECIDE_MAX_N) return false;                                     // small batches decide inside the proposal kernel
+    if (g_tune_fused_decide.load() == 1) return false;
+    return !(N <= 4096 || (N <= 256 * 64 && K <= 4096));                               // the 64-tokens-per-wave form (launch_coarse: !small16)
+}
+
 static int pick_slices(int64_t ntb, int64_t nstages, int min_slices = 2) {
     if (const int forced = g_tune_slices.load(); forced > 0) { int ns = forced; while (ns > 1 && ns > nstages) ns >>= 1; return ns; }
     // Enough slices to put a workgroup on every CU, no more: fewer, longer workgroups amortise their prologue and
@@ -216,7 +232,7 @@ struct VqGroupRun { int used, ks, noaux, pad_stage; };
 static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const char *frag, float *rec, int64_t Np,
                          const VqCbStats *cbst, const float *xh2, const float *rho2, int metric, const VqDecideOut &dec,
                          int *nslices_out, int *fused_decide_out, hipStream_t s, VqGroupLists grp = VqGroupLists{nullptr, nullptr, nullptr, nullptr, 0, 1, 0},
-                         VqGroupRun *grun = nullptr) {
+                         VqGroupRun *grun = nullptr, int xd = 0) {
     const int nstep = L.nstep;
     // small batches use fewer tokens per wave so that more workgroups exist
     const bool small = N <= 256 * 64;
@@ -300,7 +316,9 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
 #elif defined(VQ_D256_FILTER)
         case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4, true) else VQ_CFG(16, 4, 8, VQ_TPS16, 4, true)
 #else
-        case 16: if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
+        case 16: if (xd == 1 && !small16) VQ_CFG(16, 4, 8, VQ_TPS16, 4, false, false, false, 1)
+                 if (xd == 2 && !small16) VQ_CFG(16, 4, 8, VQ_TPS16, 4, false, false, false, 2)
+                 if (small16) VQ_CFG(16, 2, 8, VQ_TPS16, 4) else VQ_CFG(16, 4, 8, VQ_TPS16, 4)
 #endif
         // large D: the token fragments of a wave must stay in registers for the whole stream
 #ifndef VQ_CFG_D512
@@ -538,14 +556,18 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     int *rescan_cnt = (int *)(w + W.off_rcnt), *cand_list = (int *)(w + W.off_rlist);
     int *arrive = (int *)(w + W.off_arrive);
     const int narrive = (int)W.narrive;          // arrival counters + the group path's bucket counters (one zeroed range)
-    const int xgrid = (int)((N + 31) / 32);
+    int xgrid = (int)((N + 31) / 32);
+    // no token image: the proposal kernel converts the rows it loads (coarse_kernel<..., XD>); the front only does the housekeeping
+    const int xd = vq_xdirect(N, K, D, x_dtype, metric, n_dev) ? (x_dtype == VQHIP_DTYPE_BF16 ? 1 : 2) : 0;
     if (!x_prepared) {
-        if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
-        else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive);
+        if (xd) xgrid = xgrid < 64 ? xgrid : 64;
+        if (x_dtype == VQHIP_DTYPE_F32) x_prep_kernel<0><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive, xd);
+        else x_prep_kernel<1><<<xgrid, 256, 0, s>>>(x, N, D, L.nstep, ximg, xh2, rho2, (float *)(w + W.off_xn), counters, (char *)cb, L, arrive, narrive, xd);
         VQ_CHECK_LAUNCH("x_prep_kernel");
     }
     // the proposal kernel also runs the decision stage (the workgroup that completes a token block merges its slices)
-    VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive, n_dev};
+    VqDecideOut dec{idx, hist, rescan_list, multi_list, exact_list, counters, keys, thr, rescan_cnt, arrive, n_dev,
+                    x, xh2, rho2, (float *)(w + W.off_xn)};
     VqDecideOut dec_arg = dec;                   // launch_coarse decides (knob 6, slice count) whether the proposal kernel runs the
     int fused_done = 0;                          // decision stage itself and reports it here
     // D <= 32 group path: request lists of the proposal kernel (cap = an equal share of the pool per code tile, whole batches of 32)
@@ -565,7 +587,7 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
         while ((1u << bits) < (uint32_t)(ntiles_cb / VQ_GROUP_TILES)) ++bits;
         grp.idmask = (1u << bits) - 1u;
     }
-    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s, grp, &grun);
+    rc = launch_coarse(ximg, N, L, c + L.off_frag, rec, Np, (const VqCbStats *)(c + L.off_stats), xh2, rho2, metric, dec_arg, &nslices, &fused_done, s, grp, &grun, xd);
     if (rc) return rc;
     const float *rece2 = nullptr;
     if (grun.used) {             // identify the group records: one candidate per request, written into the records
@@ -586,7 +608,9 @@ static int argmin_pipeline(const void *x, int x_dtype, const float *e_exact, con
     {
         const char *frag = c + L.off_frag;
         int rrc = VQHIP_OK;
-        switch (L.nstep) {
+        if (xd == 1) rrc = launch_rescan_cfg<16, 2, 8, VQ_TPS16, 4, 1>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s, x);
+        else if (xd == 2) rrc = launch_rescan_cfg<16, 2, 8, VQ_TPS16, 4, 2>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s, x);
+        else switch (L.nstep) {
 #define VQ_RESCAN(NS, TT, ...) case NS: rrc = launch_rescan_cfg<NS, TT, 8, __VA_ARGS__>(ximg, frag, L.nstages, rescan_list, counters, thr, rescan_cnt, cand_list, s); break;
             VQ_RESCAN(2, 2, VQ_TPS_D32, 4) VQ_RESCAN(4, 2, 4, 4) VQ_RESCAN(8, 2, 4, 4) VQ_RESCAN(16, 2, VQ_TPS16, 4) VQ_RESCAN(32, 2, 2) VQ_RESCAN(48, 2, 1) VQ_RESCAN(64, 1, 1)
 #undef VQ_RESCAN
@@ -640,11 +664,16 @@ static int encode_fused_front(const void *rows, int rows_dtype, int64_t N, const
     // scale raise the non-finite flag and the rows take the fp32 pass)
     const bool cosimg = VQ_IS_COS(cb_metric) || (cb_metric & 3) == VQ_METRIC_DOT;
     const int nblk_stats = cosimg ? (int)(L.nstages * L.tps) : (int)((Kc + 15) / 16);
-    const int xgrid = (int)((N + 31) / 32), narrive = (int)W.narrive;
+    // the rows the pipeline will be handed are the rows given here (no normalisation, token-major, no gather): where the proposal
+    // kernel makes its own fragments (vq_xdirect: the same predicate argmin_pipeline evaluates) the token side is housekeeping only
+    const int toff = (!xnorm && hw == 0 && grows == nullptr && vq_xdirect(N, Kc, D, rows_dtype, cb_metric, nullptr)) ? 1 : 0;
+    int xgrid = (int)((N + 31) / 32);
+    if (toff) xgrid = xgrid < 64 ? xgrid : 64;
+    const int narrive = (int)W.narrive;
     int *counters = (int *)(w + W.off_counters), *arrive = (int *)(w + W.off_arrive);
     float *xh2 = (float *)(w + W.off_xh2), *rho2 = (float *)(w + W.off_rho2), *xn = (float *)(w + W.off_xn);
     char *ximg = w + W.off_ximg;
-#define VQ_PRE(DT, XN, MAP, COSI) pre_kernel<DT, XN, MAP, COSI><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows)
+#define VQ_PRE(DT, XN, MAP, COSI) pre_kernel<DT, XN, MAP, COSI><<<nblk_stats + xgrid, 256, 0, s>>>(codes, Kc, cb_metric, c, L, nblk_stats, rows, N, D, L.nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, xq, 1e-12f, hist_zero, hw, xrows, nullptr, nullptr, toff)
 #define VQ_PRE2(DT, XN, MAP) do { if (cosimg) VQ_PRE(DT, XN, MAP, true); else VQ_PRE(DT, XN, MAP, false); } while (0)
     if (grows != nullptr) {
         if (rows_dtype != VQHIP_DTYPE_F32 || xnorm || hw > 0 || L.nstep == 2) return fail(VQHIP_EINVAL, "encode_fused_front: gather form");
@@ -1712,6 +1741,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 11) g_tune_w32 = value != 0;
     else if (key == 13) g_tune_map256 = value != 0;
     else if (key == 15) g_tune_col_direct = value != 0;
+    else if (key == 17) g_tune_xdirect = (value == 0 || value == 1 || value == 2) ? value : 1;       // 2: fp32 rows too (measurement)
     else if (key == 12) g_tune_force_exact = value > 0 ? (value < 1024 ? value : 1024) : 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

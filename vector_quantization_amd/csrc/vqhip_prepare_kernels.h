@@ -485,7 +485,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
                                             int32_t *__restrict__ hist_zero = nullptr, int64_t hist_len = 0,
                                             int64_t nblocks = 1, int64_t hw = 0, void *__restrict__ xrows = nullptr,
                                             const int32_t *__restrict__ grows = nullptr,
-                                            const int32_t *__restrict__ gcount = nullptr) {
+                                            const int32_t *__restrict__ gcount = nullptr, int tokens_off = 0) {
     static_assert(!GATHER || (DT == 0 && !XNORM && !NCHW), "GATHER: fp32 codebook rows, as given");
     __shared__ float red[2][8][32];
     // vqhip_encode(VQHIP_ENCODE_ZERO_HIST): the code-hit histogram the later kernels of this call add into starts from zero
@@ -498,6 +498,7 @@ __device__ __forceinline__ void x_prep_body(int64_t blk, const void *__restrict_
     // arrival counters of the proposal kernel's token blocks (at most one per 128 tokens: 4 blocks of this kernel)
     if (arrive != nullptr)                                      // every block zeroes its stride of the counter range
         for (int64_t i = blk * 256 + threadIdx.x; i < narrive; i += nblocks * 256) arrive[i] = 0;
+    if (tokens_off) return;           // the proposal kernel makes its token fragments itself (coarse_kernel<..., XD>): housekeeping only
     if constexpr (!NCHW && !GATHER) {
         if (nstep == 2) {                                       // padded dimension 32: the wave-level form (no LDS, no barrier)
             x_prep_small<DT, XNORM>(blk, x, N, D, ximg, xh2, rho2, xn, xq, eps, xround);
@@ -709,9 +710,9 @@ __global__ __launch_bounds__(256) void x_prep_kernel(const void *__restrict__ x,
                                                      char *__restrict__ ximg, float *__restrict__ xh2,
                                                      float *__restrict__ rho2, float *__restrict__ xn,
                                                      int *__restrict__ counters, char *cb, VqCbLayout L,
-                                                     int *__restrict__ arrive = nullptr, int narrive = 0) {
+                                                     int *__restrict__ arrive = nullptr, int narrive = 0, int tokens_off = 0) {
     x_prep_body<DT, false>(blockIdx.x, x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive, nullptr, 0.0f, 0, nullptr, 0,
-                           (int64_t)gridDim.x);
+                           (int64_t)gridDim.x, 0, nullptr, nullptr, nullptr, tokens_off);
 }
 // vqhip_encode / vqhip_col_argmin: the codebook statistics and the token side in ONE launch (they are independent;
 // the image kernel that follows needs the former, the proposal kernel both)
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
                                                   float *__restrict__ xq, float eps, int32_t *__restrict__ hist_zero,
                                                   int64_t hw = 0, void *__restrict__ xrows = nullptr,
                                                   const int32_t *__restrict__ grows = nullptr,
-                                                  const int32_t *__restrict__ gcount = nullptr) {
+                                                  const int32_t *__restrict__ gcount = nullptr, int tokens_off = 0) {
     // the smaller of the two groups of workgroups goes FIRST in the grid: dispatched behind the larger one it starts when that
     // one drains and its own latency (a chain of round trips either way) is added to the kernel — at 3072 tokens against 1024
     // statistics workgroups the token side started ~8 us into a 16 us kernel
@@ -739,5 +740,5 @@ __global__ __launch_bounds__(256) void pre_kernel(const float *e, int64_t K, int
         else cb_stats_body(x_first ? b - xgrid : b, e, K, D, metric, cb, L);
     }
     else x_prep_body<DT, XNORM, NCHW, GATHER>((int64_t)(x_first ? b : b - nblk_stats), x, N, D, nstep, ximg, xh2, rho2, xn, counters, arrive, narrive,
-                                              xq, eps, VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows, grows, gcount);
+                                              xq, eps, VQ_IS_BF16(metric) ? 1 : 0, hist_zero, K, (int64_t)xgrid, hw, xrows, grows, gcount, tokens_off);
 }

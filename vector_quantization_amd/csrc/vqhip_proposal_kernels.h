@@ -15,6 +15,9 @@ struct VqDecideOut {
     int *arrive;            // one arrival counter per token block of the proposal kernel (zeroed by x_prep_kernel)
     const int *n_dev;       // nullable DEVICE row count: only rows [0, min(N, *n_dev)) are live (vqhip_col_argmin_rows:
                             // the launch is sized for a capacity, the actual number of listed codes stays on the device)
+    // coarse_kernel<..., XD != 0> (the token side made in the proposal prologue, no token image): the rows as the caller holds
+    // them (row-major, D elements) and where slice 0 writes the per-row statistics x_prep_kernel would have written
+    const void *xrows; float *xh2_w, *rho2_w, *xn_w;
 };
 template <bool AGENT>
 __device__ __forceinline__ void decide_rows(int64_t n, bool oob, const VqCbStats *st, int Dp, int metric, int nslices,
@@ -98,8 +101,13 @@ __device__ unsigned long long vq_stage_dbg[VQ_STAGE_WGS * 8 * VQ_STAGE_ITERS * 5
 #ifndef VQ_D32_PLAIN_OCC
 #define VQ_D32_PLAIN_OCC 2
 #endif
+// XD != 0 (1: bf16 rows, 2: fp32 rows; D == the padded dimension): the workgroup makes its token fragments itself, from the
+// row-major latents — fp16 conversion with flush-to-zero, |xh|^2, |x - xh|^2 and the oracle-order |x|^2 exactly as x_prep_body
+// computes them (same fma chains, same folding order: bit-identical statistics) — and slice 0 writes the statistics.  The
+// 268 MB fp16 token image of the headline batch is then neither written nor read: pre_kernel's token side (85 us of HBM time
+// at 524 288 x 256 bf16) is gone, for a prologue that converts what it loaded anyway.
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false,
-          bool GROUPS = false>
+          bool GROUPS = false, int XD = 0>
 __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : VQ_D32_PLAIN_OCC) : WAVES / 4) void coarse_kernel(
     const char *__restrict__ ximg, int64_t N, const char *__restrict__ frag, int64_t nstages, int nslices,
     float *__restrict__ rec, int64_t Np, const VqCbStats *__restrict__ cbst, const float *__restrict__ xh2,
@@ -152,13 +160,121 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
 
     // ---- prologue: this wave's token fragments straight from the fragment-major fp16 image ----
     half8 xf[TT][NS32];
+    if constexpr (XD == 0) {
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        int64_t tt = tb * tpb + wave * TT + t;
-        tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
-        const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
+        for (int t = 0; t < TT; ++t) {
+            int64_t tt = tb * tpb + wave * TT + t;
+            tt = tt < ntt ? tt : ntt - 1;                    // out-of-range tiles read a valid tile and are never written
+            const char *src = ximg + tt * (int64_t)(NS32 * VQ_CHUNK_BYTES) + lane * 16;
 #pragma unroll
-        for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+        }
+    } else {
+        static_assert(XD == 0 || (!FILTER && !GROUPS && !NOAUX && (NSTEP % 4) == 0), "token side in the prologue: plain D % 64 == 0 forms");
+        const int q4 = lane >> 4, r16 = lane & 15;           // the fragment's own layout: token r16 of the tile, dims 32 s + 8 q4 .. + 8
+        constexpr int Dr = NS32 * 32;
+        // bf16 rows: a piece of 8 latents is 16 bytes, exactly the fragment's size — ALL the wave's pieces are requested into the
+        // fragment registers themselves, then converted in place (one round trip to HBM for the whole prologue, as with the image:
+        // a first form loaded into temporaries and hipcc, short of 128 more registers, made 32 round trips of it: +160 us per launch)
+        if constexpr (XD == 1) {
+            // Requested as whole rows — two 512-byte rows per wave-instruction, 1 KiB contiguous — and turned into the fragment
+            // layout through a wave-private LDS tile (16 rows x 528 bytes: the 16-byte pad makes the fragment reads conflict-free)
+            // in the ring's stages 2 and 3, which nothing writes before the first barrier of the stream.  (Requested in the fragment
+            // layout itself a wave-instruction is 16 rows x 64 bytes: twice the requests for the same bytes, +5 us per workgroup.)
+            static_assert(NS32 == 8 && NBUF >= 4 && 2 * STAGE_BYTES >= WAVES * 16 * 528, "row tile: D = 256, staged behind stage 1");
+            char *stg = lds + 2 * STAGE_BYTES + wave * (16 * 528);
+            const int hr = lane >> 5, c32 = lane & 31;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int64_t tok0 = (tb * tpb + wave * TT + t) * 16;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int64_t tok = tok0 + 2 * i + hr;
+                    const int64_t trow = tok < N ? tok : N - 1;  // rows past the end repeat the last one and are never written
+                    xf[t][i] = *(const half8 *)((const uint16_t *)dec.xrows + trow * Dr + 8 * c32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *(half8 *)(stg + (2 * i + hr) * 528 + 16 * c32) = xf[t][i];
+#pragma unroll
+                for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(stg + r16 * 528 + 64 * s + 16 * q4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int64_t tok = (tb * tpb + wave * TT + t) * 16 + r16;
+            const int64_t trow = tok < N ? tok : N - 1;
+            float raw32[XD == 2 ? NS32 : 1][8];              // fp32 rows: one token tile's pieces at a time (a round trip per tile)
+            if constexpr (XD == 2) {
+#pragma unroll
+                for (int s = 0; s < NS32; ++s) load8<0>(dec.xrows, trow * Dr + 32 * s + 8 * q4, raw32[s]);
+            }
+            // x_prep_body's thread g = 4 (s & 1) + q4 owns the pieces of this lane with that parity: two running sums each.
+            // The statistics are slice 0's business alone (wave-uniform branch): the other slices only convert.
+            const bool stats = sl == 0;
+            float sh[2] = {0.0f, 0.0f}, sr[2] = {0.0f, 0.0f}, pn[2][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pn[0][j] = 0.0f; pn[1][j] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < NS32; ++s) {
+                float v[8];
+                half8 f;
+                if constexpr (XD == 1) {
+                    // bf16 -> fp16 two at a time (v_cvt_pk_f16_f32).  A bf16 value below 2^-14 converts to an fp16 subnormal or
+                    // zero and never rounds up to 2^-14 (8 significant bits against 11), so flushing the INPUT where |v| < 2^-14
+                    // is to_f16_ftz's flush of the result; everything else converts as (_Float16)v does (RNE, overflow to inf)
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                    typedef float float2v __attribute__((ext_vector_type(2)));
+                    const u32x4 bits = __builtin_bit_cast(u32x4, xf[t][s]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t lo = bits[j] << 16, hi = bits[j] & 0xFFFF0000u;
+                        v[2 * j] = __uint_as_float(lo); v[2 * j + 1] = __uint_as_float(hi);
+                        float2v c;
+                        c[0] = (lo & 0x7FFFFFFFu) < 0x38800000u ? 0.0f : v[2 * j];
+                        c[1] = (hi & 0x7FFFFFFFu) < 0x38800000u ? 0.0f : v[2 * j + 1];
+                        const half2v h = __builtin_convertvector(c, half2v);
+                        f[2 * j] = h[0]; f[2 * j + 1] = h[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] = raw32[s][j]; f[j] = to_f16_ftz(v[j]); }
+                }
+                if (stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float b = (float)f[j], res = v[j] - b;
+                        sh[s & 1] = fmaf(b, b, sh[s & 1]); sr[s & 1] = fmaf(res, res, sr[s & 1]);
+                        pn[s & 1][j] = fmaf(v[j], v[j], pn[s & 1][j]);
+                    }
+                }
+                xf[t][s] = f;
+            }
+            if (!stats) continue;
+            // |xh|^2, |x - xh|^2: the eight threads' sums in thread order (g = 0 .. 7: pieces q4 = 0..3 of even s, then of odd s)
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                a += __shfl(sh[g >> 2], (g & 3) * 16 + r16, 64);
+                b += __shfl(sr[g >> 2], (g & 3) * 16 + r16, 64);
+            }
+            // oracle-order |x|^2: partial chain 8 g + j lives in the lane with q4 = g & 3; halving tree 32, 16, 8 across lanes, 4, 2, 1 inside
+            float q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = pn[0][j] + pn[1][j];                    // level 32
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = q[j] + __shfl_xor(q[j], 32, 64);        // level 16
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = q[j] + __shfl_xor(q[j], 16, 64);        // level 8
+            float a0 = q[0] + q[4], a1 = q[1] + q[5], a2 = q[2] + q[6], a3 = q[3] + q[7];
+            a0 = a0 + a2; a1 = a1 + a3;
+            a0 = a0 + a1;
+            if (sl == 0 && q4 == 0 && tok < N && wave * TT + t < tpb) { dec.xh2_w[tok] = a; dec.rho2_w[tok] = b; dec.xn_w[tok] = a0; }
+        }
     }
     if constexpr (PIPE_H) {
         // One wave per SIMD owns 512 registers, 256 of them accumulation registers — which the MFMA reads as operands just as

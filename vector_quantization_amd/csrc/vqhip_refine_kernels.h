@@ -247,11 +247,15 @@ __global__ void refine_decide_kernel(const char *cb, VqCbLayout L, int64_t N, in
 // codebook stages arrive by LDS-DMA through the same ring and are shared by the 8 waves — as a persistent grid over
 // (block of WAVES*TT*16 queued rows, slice of stages) items, the slice count chosen on the device from the queue
 // length so that every workgroup gets an item.
-template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2>
+// XD != 0 (1: bf16 rows, 2: fp32 rows): there is no token image (coarse_kernel<..., XD>) — the queued rows' fragments come from
+// the row-major latents `xrows` (D == the padded dimension): 4 or 8 whole cache lines per row instead of 32 pieces in 32 lines,
+// converted as the prologue of the proposal kernel converts them (the same fp16 values: the scores stay bitwise the stream's)
+template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, int XD = 0>
 __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restrict__ ximg, const char *__restrict__ frag,
                                                             int64_t nstages, const int *__restrict__ rescan_list,
                                                             const int *__restrict__ counters, const float *__restrict__ thr,
-                                                            int *__restrict__ rescan_cnt, int *__restrict__ cand_list) {
+                                                            int *__restrict__ rescan_cnt, int *__restrict__ cand_list,
+                                                            const void *__restrict__ xrows = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NS32 = NSTEP / 2;
     constexpr int NCH = TPS * NSTEP + VQ_AUX_CHUNKS(TPS);
@@ -302,9 +306,21 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
             // TT*NS32 loads of a lane are independent and in flight together, once per item.
             const int64_t tk = rescan_list[valid ? slot[t] : nrows - 1];
             mythr[t] = valid ? thr[tk] : INFINITY;
-            const char *src = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
+            if constexpr (XD == 0) {
+                const char *src = ximg + (tk >> 4) * (int64_t)(NS32 * VQ_CHUNK_BYTES) + ((lane >> 4) * 16 + (int)(tk & 15)) * 16;
 #pragma unroll
-            for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+                for (int s = 0; s < NS32; ++s) xf[t][s] = *(const half8 *)(src + s * VQ_CHUNK_BYTES);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS32; ++s) {
+                    float v[8];
+                    load8<(XD == 1 ? 1 : 0)>(xrows, tk * (int64_t)(NS32 * 32) + 32 * s + 8 * (lane >> 4), v);
+                    half8 f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = to_f16_ftz(v[j]);
+                    xf[t][s] = f;
+                }
+            }
         }
         __syncthreads();   // stage st0 landed
         for (int64_t st = st0; st < st1; ++st) {

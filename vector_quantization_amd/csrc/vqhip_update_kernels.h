@@ -14,6 +14,10 @@ __device__ __forceinline__ void nt_store4(float *q, float a, float b, float c, f
 
 // NT: the outputs (and the latents) are larger than the Infinity Cache and are streamed with non-temporal accesses;
 // smaller batches keep normal stores so that the consumer of z finds it in cache.
+// (Round 6 measured two more forms for bf16 latents on the headline's 805 MB — two or four rows in flight per wave with this access
+//  pattern: 179-186 us against 178.6; eight consecutive elements per lane, half a wave per row of D = 256: 208-266 us, its 16-byte
+//  accesses at a 32-byte stride cost more than the bytes in flight gain.  The kernel sits on a plateau of the memory system for a
+//  1 : 2 read : write mix, not on a shortage of requests: profiles/r06_gather.txt.  Neither is kept.)
 template <int DT, int NT>
 // mse != nullptr: `sse` is a 16-byte scratch {double sum; int ticket; int pad} that is zero on entry; the workgroup that
 // draws the last ticket writes mean((z - x)^2) as fp32 to mse[0] and mse[1] (the codebook and the commitment term share
