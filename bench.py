@@ -820,7 +820,7 @@ def main():
             out_line['parity'] = parity
         out_line.update(extra)
         if B.binding is not None:
-            out_line['host_binding'] = {k: B.binding[k] for k in ('cpus', 'numa_local', 'slice', 'slices_on_node')}
+            out_line['host_binding'] = {k: B.binding.get(k) for k in ('cpus', 'numa_local', 'slice', 'slices_on_node', 'position_on_node', 'ranks_on_node')}
             from vector_quantization_amd import affinity
             affinity.restore(B.binding['previous'])              # the CPU baseline below gets every core back
         if not args.no_cpu_baseline and world == 1:          # reported once, at N=1 (rank 0's host cores)

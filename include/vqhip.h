@@ -9,7 +9,11 @@
  *
  * Conventions: every pointer is a DEVICE pointer unless noted; tensors are dense row-major; `stream`
  * is a hipStream_t passed as void*; functions never allocate, never synchronise, never touch another
- * stream; they return 0 or a negative VQHIP_E* code.  x_dtype selects the latent storage type
+ * stream; they return 0 or a negative VQHIP_E* code.  Two documented exceptions to "never synchronise", both host-side waits the
+ * CALLER arms: the vqhip_rccl_* set-up calls (they block inside RCCL), and vqhip_cvq_forward with cap < 0, which waits on the
+ * caller's own event (hipEventSynchronize(count_event)) for a count the previous call queued a whole step earlier and then reads
+ * the caller's pinned host word — that word must be host-coherent memory (hipHostMalloc's default; not under HIP_HOST_COHERENT=0:
+ * pass cap >= 0 there).  x_dtype selects the latent storage type
  * (fp32, or bf16 as produced under autocast); codebooks are fp32 like nn.Embedding.weight.
  * Every caller-owned scratch buffer travels with its size (`ws_bytes`, `cb_bytes`): a buffer smaller than the matching
  * *_bytes function asks for is refused with VQHIP_EINVAL before anything is launched (vqhip_last_error names both numbers).

@@ -48,3 +48,15 @@ def test_ranks_take_successive_slices():
             assert set(a['cpus']).isdisjoint(b['cpus'])
     finally:
         affinity.set_process_affinity(before)
+
+
+def test_ranks_sharing_a_numa_node_take_successive_slices_by_position(monkeypatch):
+    """Round-5 advisor: with GPUs 0 and 2 on one NUMA node (NPS4-style topologies) the raw local rank put ranks 0 and 2 on the same
+    slice.  The slice index is the rank's position among the local ranks whose GPU hangs off the same node."""
+    node_of = {0: [0, 1, 2, 3], 1: [4, 5, 6, 7], 2: [0, 1, 2, 3], 3: [4, 5, 6, 7]}        # GPUs 0, 2 on one node; 1, 3 on the other
+    monkeypatch.setattr(affinity, 'gpu_local_cpus', lambda i: node_of.get(i))
+    assert affinity.node_position(0, 0, 4) == (0, 2) and affinity.node_position(2, 2, 4) == (1, 2)
+    assert affinity.node_position(1, 1, 4) == (0, 2) and affinity.node_position(3, 3, 4) == (1, 2)
+    assert affinity.node_position(0, 3, 4) == (3, 4)              # a rank that does not drive the device of its number: raw local rank
+    monkeypatch.setattr(affinity, 'gpu_local_cpus', lambda i: None)
+    assert affinity.node_position(2, 2, 8) == (2, 8)              # topology unreadable: raw local rank

@@ -37,35 +37,40 @@ def _read(path: str) -> Optional[str]:
 
 
 def gpu_local_cpus(device_index: int) -> Optional[List[int]]:
-    """CPUs of the NUMA node the GPU's PCIe function hangs off (sysfs `local_cpulist`), or None when the topology cannot be
-    read (containers without /sys/class/drm, non-Linux)."""
+    """CPUs of the NUMA node the GPU's PCIe function hangs off (sysfs `local_cpulist` of the PCI address HIP reports for the
+    device — so a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remapping is honoured), or None when the address or the topology
+    cannot be read; no guess from the order of the render nodes (it ignores such masks: round-5 advisor)."""
     try:
         import torch
-        bus = torch.cuda.get_device_properties(device_index).pci_bus_id      # int; with domain / device below
-        dom = getattr(torch.cuda.get_device_properties(device_index), 'pci_domain_id', 0)
-        dev = getattr(torch.cuda.get_device_properties(device_index), 'pci_device_id', 0)
+        props = torch.cuda.get_device_properties(device_index)
+        bus = props.pci_bus_id                                               # int; with domain / device below
+        dom = getattr(props, 'pci_domain_id', 0)
+        dev = getattr(props, 'pci_device_id', 0)
         txt = _read(f'/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/local_cpulist')
         if txt and txt.strip():
             return _parse_cpulist(txt)
     except Exception:                                                        # noqa: BLE001 - placement is best effort
         pass
-    # no PCI address from torch: the AMD render nodes in PCI order (HIP's default enumeration order)
-    try:
-        nodes = []
-        for name in os.listdir('/sys/class/drm'):
-            if not name.startswith('renderD'):
-                continue
-            dev = os.path.realpath(f'/sys/class/drm/{name}/device')
-            if (_read(dev + '/vendor') or '').strip() == '0x1002':
-                nodes.append(dev)
-        nodes.sort()
-        if device_index < len(nodes):
-            txt = _read(nodes[device_index] + '/local_cpulist')
-            if txt and txt.strip():
-                return _parse_cpulist(txt)
-    except OSError:
-        pass
     return None
+
+
+def node_position(device_index: int, local_rank: int, world_on_node: int) -> tuple:
+    """(position of this rank among the local ranks whose GPU hangs off the same NUMA node, how many such ranks there are) —
+    under the launchers' convention that local rank r drives device r.  Ranks that share a node take successive L3 slices of
+    it by this position, not by their raw local rank: with GPUs 0 and 2 on one node of two slices, ranks 0 and 2 would both
+    have taken slice 0.  Falls back to (local_rank, world_on_node) when the topology cannot be read or the rank does not drive
+    the device of its own number."""
+    world_on_node = max(1, int(world_on_node))
+    mine = gpu_local_cpus(device_index)
+    if mine is None or device_index != local_rank:
+        return local_rank, world_on_node
+    pos = peers = 0
+    for r in range(world_on_node):
+        other = mine if r == local_rank else gpu_local_cpus(r)
+        if other is not None and set(other) == set(mine):
+            peers += 1
+            pos += 1 if r < local_rank else 0
+    return pos, max(1, peers)
 
 
 def l3_slices(cpus: Set[int]) -> List[List[int]]:
@@ -130,10 +135,13 @@ def bind_rank(device_index: int = 0, local_rank: int = 0, slices: int = 1, probe
     if not groups:
         return None
     per = max(1, int(slices))
-    start = (local_rank * per) % len(groups)
-    if probe and per == 1 and len(groups) > max(1, world_on_node):
+    # the rank's slice by its position among the ranks of ITS node when the GPU's node is known (`pool` is then that node's CPUs);
+    # by the raw local rank otherwise (the pool is every allowed CPU)
+    pos, peers = node_position(device_index, local_rank, world_on_node) if numa_local else (local_rank, max(1, world_on_node))
+    start = (pos * per) % len(groups)
+    if probe and per == 1 and len(groups) > peers:
         best = None
-        for cand in range(local_rank % max(1, world_on_node), len(groups), max(1, world_on_node)):
+        for cand in range(pos % peers, len(groups), peers):
             try:
                 os.sched_setaffinity(0, set(groups[cand]))
             except OSError:
@@ -151,7 +159,8 @@ def bind_rank(device_index: int = 0, local_rank: int = 0, slices: int = 1, probe
     if not chosen:
         return None
     set_process_affinity(chosen)
-    return {'cpus': sorted(chosen), 'numa_local': numa_local, 'slice': start, 'slices_on_node': len(groups), 'previous': sorted(allowed)}
+    return {'cpus': sorted(chosen), 'numa_local': numa_local, 'slice': start, 'slices_on_node': len(groups), 'position_on_node': pos,
+            'ranks_on_node': peers, 'previous': sorted(allowed)}
 
 
 def restore(previous) -> None:

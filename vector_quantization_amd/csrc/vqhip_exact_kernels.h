@@ -593,15 +593,28 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                 const float4 *trow = tile + ((ct & 1) * 32 + j) * (DB / 4);
                 if constexpr (VEC4) {
                     // zero pieces past D (both operands) add +-0 to accumulators that are never -0: the chain is unchanged
+                    // the tile's 16-byte pieces are read VQ_EXACT_PF pairs of MFMAs ahead of their use, through a ring of register
+                    // sets, and every pair's statements stay together (sched_barrier): left alone, hipcc issues a piece's ds_read
+                    // between the two MFMAs of the pair before and waits for it in front of the next pair — one wave per SIMD, 128
+                    // cycles of MFMA against an LDS round trip: the pipe stood still a quarter of the time (round 6)
+#ifndef VQ_EXACT_PF
+#define VQ_EXACT_PF 2
+#endif
 #pragma unroll
                     for (int g = 0; g < DB / 32; ++g) {
                         if (db + 32 * g < D) {
+                            constexpr int PF = VQ_EXACT_PF, RING = PF + 1;
+                            float4 vr[RING];
+#pragma unroll
+                            for (int i = 0; i < PF; ++i) vr[i] = trow[(8 * g + i) ^ (j & 15)];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const int q = 8 * g + i;
-                                const float4 v = trow[q ^ (j & 15)];
+                                if (i + PF < 8) vr[(i + PF) % RING] = trow[(q + PF) ^ (j & 15)];
+                                const float4 v = vr[i % RING];
                                 acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.y : v.x, xfr[2 * q], acc[ct], 0, 0, 0);
                                 acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v.w : v.z, xfr[2 * q + 1], acc[ct], 0, 0, 0);
+                                if constexpr (PF > 0) __builtin_amdgcn_sched_barrier(0);
                             }
                         }
                     }

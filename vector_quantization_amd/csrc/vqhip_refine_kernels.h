@@ -485,7 +485,10 @@ __device__ __forceinline__ void rerank_rows(float *te, float *tx, int64_t gwave,
 
         // register ring PD segments deep: at step g the wave fetches segment g+PD, runs the chains over segment g (in
         // the tile) and parks segment g+1; LDS operations of one wave execute in order, so one tile is enough
-        constexpr int PD = 2;
+#ifndef VQ_RR_PD
+#define VQ_RR_PD 2
+#endif
+        constexpr int PD = VQ_RR_PD;
         float4 r[PD][4];
         float4 rxf[PD];                                        // latent piece: fp32 (DT 0) or 8 bf16 (DT 1)
         uint4 rxb[PD];

@@ -16,6 +16,7 @@ argument blocks; the callbacks decide WHEN the fused form applies and keep the r
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -68,6 +69,10 @@ class CvqStepState:
         # early count (include/vqhip.h, vqhip_cvq_forward_t.early_word_host): {sequence number << 32 | count}, and the device counter
         self.early_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.seq_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        # the prefetched count reaches the host through a device store into pinned memory read behind an event: only where pinned
+        # host memory is coherent (hipHostMalloc's default).  HIP_HOST_COHERENT=0 switches that off process-wide: the eager step then
+        # counts on the spot (`CVQVAECallback.refresh_list`: one synchronisation per step) instead of trusting the word
+        self.host_word_coherent = os.environ.get('HIP_HOST_COHERENT', '1') != '0'
         self.list_of = None
         self.writer = None        # who wrote rows / slot / count last: 'eager' (a host-known count behind `event`) or a GraphedQuantizer's token
         self.keys = None                                          # int64 [K]: NearestAnchor(sync=True)'s key exchange (lazily)
@@ -78,7 +83,8 @@ class CvqStepState:
         step (or `refresh_list`) for exactly this tensor.  A graph replay writes the list in place without a host-side record —
         `writer` then names the replaying object and the next eager step recounts."""
         lo = self.list_of
-        return self.writer == 'eager' and lo is not None and lo[0] is p and lo[1] == p._version and lo[2] == p.data_ptr()
+        return (self.host_word_coherent and self.writer == 'eager' and lo is not None and lo[0] is p and lo[1] == p._version
+                and lo[2] == p.data_ptr())
 
     def mark_list(self, p: torch.Tensor) -> None:
         self.list_of = (p, p._version, p.data_ptr())
