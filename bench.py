@@ -245,7 +245,8 @@ class Bench:
             sys.exit(f'bench.py: rank {self.rank} has no device {local_rank} (node has {torch.cuda.device_count()})')
         torch.cuda.set_device(local_rank)
         self.dev = torch.device('cuda', local_rank)
-        self.distributed = self.world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # launched by torch.distributed.run
+        # launched by torch.distributed.run — or as the direct-route child of such a rank (its own rendezvous, env:// from the parent)
+        self.distributed = self.world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('VQ_BENCH_CHILD') == '1'
         self.backend = None
         if self.distributed:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -641,7 +642,10 @@ def main():
                              'what': 'the same forward through the tensor-level ops layer (round-1 bench step)'}
         extra['module_train'] = {'ms_per_step': e_tr / side_steps * 1e3, 'tokens_per_s': N * world * side_steps / e_tr,
                                  'what': 'VQGANQuantizer.forward in train mode + backward (fused HIP backward, codebook gradient)'}
-        if world > 1 and not args.no_cvq:
+        # VQ_BENCH_FORCE_CVQ=1: the multi-rank blocks at ANY world size — with `torch.distributed.run --nproc-per-node=1` and
+        # VQ_FORCE_EXCHANGE=1 the closest rehearsal of the multi-GPU line a one-GPU box allows ON RCCL: the per-rank gathers, the
+        # communicating step through the whole exchange flow, the direct-route children beside the parent's communicator
+        if (world > 1 or (B.distributed and os.environ.get('VQ_BENCH_FORCE_CVQ') == '1')) and not args.no_cvq:
             # the communicating workload of the path, so that a scaling run is interpretable
             extra['cvq'] = {}
             # The eager step is ONE library call per forward (vqhip_cvq_forward) and GPU-bound at both sizes; it is what is
@@ -650,7 +654,7 @@ def main():
             # (one-GPU builder boxes) — a capture that goes wrong there would cost the whole scaling run.
             cvq_graphs = os.environ.get('VQ_BENCH_CVQ_GRAPHS') == '1'
             for toks in (12 * TOK_PER_IMAGE, 256 * TOK_PER_IMAGE):
-                rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), graphs=cvq_graphs, settle=120)
+                rec, _ = run_cvq(B, toks, max(20, args.steps), 5, min(1.0, args.min_seconds), graphs=cvq_graphs, settle=int(os.environ.get('VQ_BENCH_CVQ_SETTLE', '120')))
                 if not cvq_graphs:
                     rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph replay of an RCCL collective has run at world size 1 only)'
                 extra['cvq'][str(toks)] = rec

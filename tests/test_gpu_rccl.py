@@ -82,3 +82,31 @@ def test_fsdp_use_orig_params_smoke(ws1):
     of which only sees the first one's codebook update if it landed in FSDP's flat parameter."""
     assert ws1['fsdp_error'] is None, ws1['fsdp_error']
     assert ws1['fsdp_tokens_identical'] is True and ws1['fsdp_loss_diff'] <= 1e-5
+
+
+def test_bench_multi_rank_blocks_on_rccl_at_world_size_one(tmp_path):
+    """The part of `bench.py --gpus N` that only runs with more than one rank — each rank's own clock and kernel time gathered, parity
+    gathered, the communicating cvq blocks, and the direct-route sub-block in a child process with its own rendezvous — on the REAL
+    backend: one rank under `torch.distributed.run` with VQ_BENCH_FORCE_CVQ=1 and VQ_FORCE_EXCHANGE=1.  The child creates the library's
+    own RCCL communicator (VQHIP_ALLREDUCE=direct) on the GPU whose parent process holds torch's: what the first multi-GPU lease will
+    do on every rank."""
+    env = dict(os.environ, VQ_BENCH_FORCE_CVQ='1', VQ_FORCE_EXCHANGE='1', VQ_BENCH_CVQ_SETTLE='30')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.pop('VQHIP_ALLREDUCE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--images', '64',
+           '--min-seconds', '0', '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, f'{res.stdout[-2000:]}\n{res.stderr[-3000:]}'
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['collective_backend'] == 'nccl' and rec['rccl_ranks'] == 1 and rec['parity']['ranks_checked'] == 1
+    assert len(rec['per_rank_ms_per_step']) == 1 and len(rec['roofline']['kernel_ms_per_rank']) == 1
+    direct = rec['cvq'].pop('direct_route')
+    for toks, blk in rec['cvq'].items():
+        assert blk['codebook_in_sync'] is True and blk['one_call_forward'] is True and blk['collectives_per_step'] == 1.0, (toks, blk)
+        assert blk['collective_ms'] is not None and blk['exchange_route']['mode'] in ('auto', 'torch')
+    assert direct['ok'] is True and direct['route_requested'] == 'direct', direct
+    assert direct['exchange_route']['direct'] is True and direct['exchange_route']['error'] is None, direct
+    assert direct['codebook_in_sync'] is True and direct['collectives_per_step'] == 1.0 and direct['ms_per_step'] > 0
