@@ -764,7 +764,8 @@ def main():
                                       'with this very libvqhip.so, gfx950-corrected; NOT measured in this run): ' + str(rec.get('source')))
             except Exception:
                 traffic = None
-        # the proposal kernel's OWN algorithmic bytes (what `traffic` is to be compared with): the fp16 token image read once,
+        # the proposal kernel's OWN algorithmic bytes (what `traffic` is to be compared with): the latents' 2 bytes per element read once
+        # (the bf16 rows themselves since round 6 — the kernel makes its token fragments in its prologue; the fp16 token image before),
         # the fp16 codebook image once, the records written (5 floats per token and codebook slice; two slices at this size)
         dp = 32
         while dp < D:

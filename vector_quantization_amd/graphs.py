@@ -29,11 +29,47 @@ GPU is still busy with the rest of the previous replay (round 4 captured K only:
 """
 from __future__ import annotations
 
+import gc
 import time
 from typing import Optional
 
 import torch
 from torch import nn
+
+
+def _nccl_group() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
+
+
+def _quiesce_process_group() -> None:
+    """ProcessGroupNCCL's watchdog thread polls the events of the collectives it has been handed; while a stream captures in
+    the default (global) capture mode an event query from ANOTHER thread is an error, and the watchdog answers it by aborting
+    the process (observed as a sporadic SIGABRT of the rank: rounds 4-6, `Watchdog::run()` in the backtrace).  Eager collectives
+    issued shortly before a capture are still on its list although they have completed.  Before a capture: everything
+    synchronised, then a few of the watchdog's 100-ms sweeps to let it retire its list."""
+    if _nccl_group():
+        torch.cuda.synchronize()
+        time.sleep(0.35)
+
+
+def _graphed_train_callable(st: nn.Module, sample: torch.Tensor, warmup: int):
+    """torch.cuda.make_graphed_callables(st) — with the warm-up iterations run HERE on an nccl process group: their (eager)
+    collectives must have left ProcessGroupNCCL's watchdog before the capture begins (`_quiesce_process_group`); the helper's own
+    warm-up runs them right in front of it."""
+    if not _nccl_group():
+        return torch.cuda.make_graphed_callables(st, (sample,), num_warmup_iters=warmup, allow_unused_input=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    params = tuple(p for p in st.parameters() if p.requires_grad)
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            outs = tuple(o for o in st(sample) if isinstance(o, torch.Tensor) and o.requires_grad)
+            if outs:
+                torch.autograd.grad(outs, (sample,) + params, grad_outputs=tuple(torch.empty_like(o) for o in outs), allow_unused=True)
+    torch.cuda.current_stream().wait_stream(side)
+    _quiesce_process_group()
+    return torch.cuda.make_graphed_callables(st, (sample,), num_warmup_iters=0, allow_unused_input=True)
 
 
 class _Step(nn.Module):
@@ -88,6 +124,23 @@ class GraphedQuantizer(nn.Module):
         self.poll_timeout_s = 2.0                # how long a replay waits for the previous one's list length before it counts itself
         self._cvq = self._chained_cvq_callback(quantizer, sample_x) if self._train else None
         from . import ops
+        # No cyclic garbage collection while anything captures: an older graph that has become garbage (a GraphedQuantizer the caller
+        # dropped) would be destroyed wherever the collector happens to run — hipGraphExecDestroy during another stream's capture is
+        # "operation not permitted when stream is capturing", raised inside a destructor: the process is terminated (seen as a
+        # sporadic SIGABRT of tests that build several graphed quantizers in a row, round 6).  Collect now, then hold the collector.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_all(quantizer, sample_x, warmup, bucket_caps, step, ops)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+        with torch.no_grad():                                    # undo the side effects of warm-up and capture
+            for k, v in quantizer.state_dict().items():
+                v.copy_(saved[k])
+
+    def _capture_all(self, quantizer, sample_x, warmup, bucket_caps, step, ops) -> None:
         with ops.owned_mse_scratch(self._mse_scratch):
             if self._cvq is not None:
                 K = quantizer.codebook_size
@@ -97,7 +150,7 @@ class GraphedQuantizer(nn.Module):
                         self._cvq.capture_plan = dict(cap=cap, chained=True)
                         st = _Step(quantizer)
                         sample = sample_x.detach().clone().requires_grad_(True)
-                        self._calls.append(torch.cuda.make_graphed_callables(st, (sample,), num_warmup_iters=warmup, allow_unused_input=True))
+                        self._calls.append(_graphed_train_callable(st, sample, warmup))
                         self._steps.append(st)
                 finally:
                     self._cvq.capture_plan = None
@@ -108,7 +161,7 @@ class GraphedQuantizer(nn.Module):
                 # (allow_unused_input: a VQ-KD step gives the codebook no gradient — the commitment term and the straight-through
                 #  output both detach z, configs/vqkd/model.py:76-82 freezes the quantizer anyway — and the one-call forward's
                 #  autograd node says so with None instead of a zero-filled [K, D] tensor)
-                self._call = torch.cuda.make_graphed_callables(step, (sample,), num_warmup_iters=warmup, allow_unused_input=True)
+                self._call = _graphed_train_callable(step, sample, warmup)
             else:
                 self._x = sample_x.detach().clone()
                 side = torch.cuda.Stream()
@@ -117,13 +170,11 @@ class GraphedQuantizer(nn.Module):
                     for _ in range(warmup):
                         step(self._x)
                 torch.cuda.current_stream().wait_stream(side)
+                _quiesce_process_group()
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph), torch.no_grad():
                     z, loss = step(self._x)
                     self._out = (z, loss, step.last_quant)
-        with torch.no_grad():                                    # undo the side effects of warm-up and capture
-            for k, v in quantizer.state_dict().items():
-                v.copy_(saved[k])
 
     @staticmethod
     def _chained_cvq_callback(quantizer: nn.Module, sample_x: torch.Tensor):
