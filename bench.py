@@ -352,6 +352,12 @@ def train_cfg(kind):
         cfg = dict(type='VQKDQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D), distance=dict(type='CosineDistance'),
                    losses=dict(commitment_loss=dict(type='CommitmentLoss', mse=dict(norm=True))), callbacks=cb_cfg)
         return K, D, cfg
+    if kind == 'cluster':      # configs/cluster/model.py:18-30: CodebookLoss, NearestAnchor(sync=True) — the global nearest latent per code
+        K, D = 8192, 768
+        cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor', sync=True))]
+        cfg = dict(type='VQGANQuantizer', embedding=dict(type=EMB, num_embeddings=K, embedding_dim=D), distance=dict(type='CosineDistance'),
+                   losses=dict(vqgan_loss=dict(type='CodebookLoss')), callbacks=cb_cfg)
+        return K, D, cfg
     cb_cfg = [dict(type='CVQVAECallback', ema=dict(), anchor=dict(type='NearestAnchor'))]
     return K_CODES, DIM, quantizer_cfg(K_CODES, DIM, 'Cosine', cb_cfg)
 
@@ -362,7 +368,7 @@ def build_train_module(kind, cfg, dev, w):
     from vector_quantization_amd import Config, build_quantizer
     q = build_quantizer(cfg)
     q.train(True)
-    q.init_weights(Config(type='vqgan') if kind == 'cvq' else Config())
+    q.init_weights(Config(type='vqgan') if kind in ('cvq', 'cluster') else Config())
     q = q.to(dev)
     q._forward_pre_hooks.clear()          # VQ-KD: the k-means lazy init is not part of a steady-state step
     with torch.no_grad():
@@ -438,6 +444,8 @@ def run_cvq(B: Bench, tokens: int, steps: int, warmup: int, min_seconds: float, 
                               'bootstrapped through the torch store); otherwise torch.distributed.all_reduce'}
                              if exchanging() else None)
     rec['dense_exchange_bytes_per_step'] = 8 * (K + 1) + 4 * K * D if B.world > 1 else 0     # int64[K+1] + fp32[K, D]: the reference's flow
+    if kind == 'cluster' and B.world > 1:     # sync=True: the reference all-gathers latents, the [N, K] matrix, tokens and probabilities
+        rec['dense_exchange_bytes_per_step'] = 8 * (K + 1) + B.world * (4 * tokens * D + 4 * tokens * K + 8 * tokens + 4 * K)
     rec['loss'] = float(out[1].item())
     rec['kernel_ms'] = prof[0] / max(1, prof[1])
     rec['kernel_launches_per_step'] = prof[1] / max(1, steps)
@@ -658,6 +666,12 @@ def main():
                 if not cvq_graphs:
                     rec['graphed_note'] = 'not run: set VQ_BENCH_CVQ_GRAPHS=1 (graph replay of an RCCL collective has run at world size 1 only)'
                 extra['cvq'][str(toks)] = rec
+            # the cluster config's step (configs/cluster/model.py:28: NearestAnchor(sync=True), 6 272 x 8192 x 768 per rank): the key
+            # exchange of DESIGN.md §4.5 — a MIN all-reduce of 8-byte keys in front of the packed SUM, no latent gathered
+            rec, _ = run_cvq(B, 6272, max(20, args.steps), 5, min(1.0, args.min_seconds), graphs=False,
+                             settle=int(os.environ.get('VQ_BENCH_CVQ_SETTLE', '120')), kind='cluster')
+            rec['what'] = 'VQGANQuantizer + CVQVAECallback(NearestAnchor(sync=True)) + CodebookLoss, cosine, K=8192 D=768 (configs/cluster/model.py)'
+            extra['cvq']['cluster_sync_6272'] = rec
             if os.environ.get('VQ_BENCH_DIRECT', '1') != '0' and os.environ.get('VQ_BENCH_CHILD') != '1':
                 extra['cvq']['direct_route'] = direct_route_subblock(B, 12 * TOK_PER_IMAGE,
                                                                      timeout_s=float(os.environ.get('VQ_BENCH_DIRECT_TIMEOUT', '240')))

@@ -104,6 +104,8 @@ def test_bench_multi_rank_blocks_on_rccl_at_world_size_one(tmp_path):
     assert rec['collective_backend'] == 'nccl' and rec['rccl_ranks'] == 1 and rec['parity']['ranks_checked'] == 1
     assert len(rec['per_rank_ms_per_step']) == 1 and len(rec['roofline']['kernel_ms_per_rank']) == 1
     direct = rec['cvq'].pop('direct_route')
+    cluster = rec['cvq'].pop('cluster_sync_6272')
+    assert cluster['codebook_in_sync'] is True and cluster['one_call_forward'] is True and cluster['collectives_per_step'] == 2.0, cluster
     for toks, blk in rec['cvq'].items():
         assert blk['codebook_in_sync'] is True and blk['one_call_forward'] is True and blk['collectives_per_step'] == 1.0, (toks, blk)
         assert blk['collective_ms'] is not None and blk['exchange_route']['mode'] in ('auto', 'torch')

@@ -193,7 +193,7 @@ def test_bench_eight_ranks_on_a_shared_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VQ_BENCH_SHARE_GPU='1')
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU='1', VQ_BENCH_CVQ_SETTLE='30')
     res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--images', '16',
                           '--min-seconds', '0', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -207,10 +207,16 @@ def test_bench_eight_ranks_on_a_shared_gpu(tmp_path):
     assert len(rec['per_rank_ms_per_step']) == 8 and max(rec['per_rank_ms_per_step']) <= rec['ms_per_step'] * 1.0001
     assert len(rec['roofline']['kernel_ms_per_rank']) == 8 and abs(rec['roofline']['kernel_ms'] - max(rec['roofline']['kernel_ms_per_rank'])) < 1e-4
     direct = rec['cvq'].pop('direct_route')
+    cluster = rec['cvq'].pop('cluster_sync_6272')
     for toks, blk in rec['cvq'].items():
         assert blk['codebook_in_sync'] is True and blk['collectives_per_step'] == 1.0, (toks, blk)
         assert blk['one_call_forward'] is True
         assert blk['exchange_bytes_per_step'] >= 4 * (2 * 16384 + 4)
+    # the cluster config's anchor: the key exchange — two collectives per step, 8 M + 4 (2K + 4 + M D) bytes, nothing like the gathered flow's
+    m = cluster['exchange_rows']
+    assert cluster['codebook_in_sync'] is True and cluster['one_call_forward'] is True and cluster['collectives_per_step'] in (1.0, 2.0)
+    assert abs(cluster['exchange_bytes_per_step'] - (8 * m + 4 * (2 * 8192 + 4 + m * 768))) < 1e-6 or cluster['collectives_per_step'] < 2.0
+    assert cluster['exchange_bytes_per_step'] < cluster['dense_exchange_bytes_per_step'] / 100
     # the second sub-block: the same step in a child process per rank under a timeout (on RCCL: VQHIP_ALLREDUCE=direct; the shared-GPU
     # rehearsal runs gloo, where only the plumbing — rendezvous of the children, their JSON, the agreement — can be exercised)
     assert direct['ok'] is True and direct['route_requested'] == 'torch' and direct['rccl_ranks'] == 8, direct
@@ -223,7 +229,7 @@ def test_bench_direct_route_timeout_is_a_reported_failure(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VQ_BENCH_SHARE_GPU='1', VQ_BENCH_DIRECT_TIMEOUT='0.5')
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU='1', VQ_BENCH_DIRECT_TIMEOUT='0.5', VQ_BENCH_CVQ_SETTLE='30')
     res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--images', '16',
                           '--min-seconds', '0', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -234,6 +240,7 @@ def test_bench_direct_route_timeout_is_a_reported_failure(tmp_path):
     assert direct['ok'] is False and 'did not finish within' in direct['error'], direct
     assert rec['n_gpus'] == 2 and rec['parity']['ranks_checked'] == 2 and len(rec['per_rank_ms_per_step']) == 2
     assert all(blk['codebook_in_sync'] for k, blk in rec['cvq'].items() if k != 'direct_route')
+    assert rec['cvq']['cluster_sync_6272']['one_call_forward'] is True
 
 
 def test_callbacks_at_world_size_two(tmp_path):
