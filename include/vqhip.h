@@ -528,7 +528,8 @@ int vqhip_profile_enable(int on);
  * tiles per workgroup (1); key 11 = the 32x32x16 proposal kernel at D <= 16 (1); key 13 = whole-image tiles in vqhip_gather_ste_map
  * for maps of 256-position images (1); key 15 = the direct fp32 form of vqhip_col_argmin_rows for short lists (1); key 17 = D = 256 batches of
  * more than 16 384 bf16 rows make their token fragments in the proposal kernel's prologue instead of writing and reading a token
- * image (1; 2 = fp32 rows too, a measurement aid).
+ * image (1; 2 = fp32 rows too, a measurement aid); key 18 = the streamed form of the whole-batch fp32 pass (vqhip_argmin_exact,
+ * vqhip_distance, the column fallback: exact_stream_kernel) where D % 4 == 0 (bf16 rows: D % 8 == 0) (1; 0 = the register form).
  * Key 12 is a verification aid, not an A/B knob: value V > 0 sends rows 0 .. min(V, N, 1024) - 1 of every vqhip_argmin batch
  * through the last-resort whole-codebook fp32 pass as well (its indices replace the ones the earlier stages wrote — the same
  * ones; a histogram requested from the call counts those rows twice); 0 = off (default).  Any other key: VQHIP_EINVAL. */

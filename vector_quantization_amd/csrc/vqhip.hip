@@ -112,6 +112,7 @@ static std::atomic<int> g_tune_groups{1};   // key 9: 0 = per-element update ins
 static std::atomic<int> g_tune_noaux{1};    // key 8: 0 = cosine / dot codebooks read the (all-zero) aux chunk like L2 ones (A/B; results unchanged)
 static std::atomic<int> g_tune_filter{1};   // key 5: 0 = unfiltered epilogue on the small-D instantiations too (A/B; results unchanged)
 static std::atomic<int> g_tune_gather_grid{0}, g_tune_gather_nt{0};   // gather kernel knobs (keys 3, 4)
+static std::atomic<int> g_tune_stream{1};   // key 18: 0 = the whole-batch fp32 pass keeps its register form (exact_tiled_kernel) (A/B; results unchanged)
 static std::atomic<int> g_tune_xdirect{1};  // key 17: 0 = D = 256 batches keep the fp16 token image (x_prep / pre_kernel token side) (A/B; results unchanged)
 
 template <int NSTEP, int TT, int WAVES, int TPS, int NBUF = 2, bool FILTER = false, bool NOAUX = false, bool GROUPS = false, int XD = 0>
@@ -350,16 +351,43 @@ static int launch_coarse(const char *ximg, int64_t N, const VqCbLayout &L, const
     return fail(VQHIP_EINVAL, "vqhip_argmin: unsupported padded D");
 }
 
+// Workgroups a persistent kernel can keep resident: compute units of the current device x workgroups per CU.
+static int resident_grid(int per_cu) {
+    static std::atomic<int> cus[VQ_MAX_DEVICES];
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256 * per_cu;
+    if (dev >= 0 && dev < VQ_MAX_DEVICES && (n = cus[dev].load(std::memory_order_relaxed)) > 0) return n * per_cu;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < VQ_MAX_DEVICES) cus[dev].store(n, std::memory_order_relaxed);
+    return n * per_cu;
+}
+
+// The all-fp32 MFMA pass over a whole batch.  Streamed form (exact_stream_kernel, both operands from LDS, two workgroups per CU,
+// contiguous spans of work items) wherever rows and codes move as whole 16-byte pieces; the register form
+// (exact_tiled_kernel) for the other D and on request (vqhip_set_tuning key 18 = 0, A/B: the results are identical).
 template <int MODE>
 static int run_exact_tiled(const void *x, int x_dtype, const float *e, const float *en, const float *xn, int64_t N, int64_t K,
                            int D, int metric, u64 *keys, float *dout, hipStream_t s) {
+    const int bf = x_dtype == VQHIP_DTYPE_F32 ? 0 : 1;
+    const int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
+    if (g_tune_stream.load() && D % (bf ? 8 : 4) == 0 && items < (int64_t)1 << 31) {
+        static LdsCache ssets[2];
+        const int lds = vq_xs_lds_bytes(bf);
+        const void *kern = bf ? (const void *)exact_stream_kernel<1, MODE> : (const void *)exact_stream_kernel<0, MODE>;
+        if (int rc = ensure_dyn_lds(kern, lds, ssets[bf])) return rc;
+        const int cap = resident_grid(2);
+        const int grid = (int)(items < cap ? items : cap);
+        if (bf) exact_stream_kernel<1, MODE><<<grid, 256, lds, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+        else exact_stream_kernel<0, MODE><<<grid, 256, lds, s>>>(x, e, en, xn, N, K, D, metric, keys, dout);
+        VQ_CHECK_LAUNCH("exact_stream_kernel");
+        return VQHIP_OK;
+    }
     constexpr int LDS = 2 * 32 * 128 * 4 + 8 * 32 * 4;      // two staged tiles + the |e|^2 of an item's 256 codes
     static LdsCache sets[4];
     const void *kerns[4] = {(const void *)exact_tiled_kernel<0, MODE, false>, (const void *)exact_tiled_kernel<1, MODE, false>,
                             (const void *)exact_tiled_kernel<0, MODE, true>, (const void *)exact_tiled_kernel<1, MODE, true>};
-    const int bf = x_dtype == VQHIP_DTYPE_F32 ? 0 : 1, v4 = (D % 4 == 0) ? 2 : 0;
+    const int v4 = (D % 4 == 0) ? 2 : 0;
     if (int rc = ensure_dyn_lds(kerns[v4 + bf], LDS, sets[v4 + bf])) return rc;
-    int64_t items = ((N + 127) / 128) * ((K + 255) / 256);
     int grid = (int)(items < 1024 ? items : 1024);
 #define VQ_TILED(DT, V4) exact_tiled_kernel<DT, MODE, V4><<<grid, 256, LDS, s>>>(x, e, en, xn, N, K, D, metric, keys, dout)
     if (v4) { if (bf) VQ_TILED(1, true); else VQ_TILED(0, true); }
@@ -1742,6 +1770,7 @@ int vqhip_set_tuning(int key, int value) {
     else if (key == 13) g_tune_map256 = value != 0;
     else if (key == 15) g_tune_col_direct = value != 0;
     else if (key == 17) g_tune_xdirect = (value == 0 || value == 1 || value == 2) ? value : 1;       // 2: fp32 rows too (measurement)
+    else if (key == 18) g_tune_stream = value != 0;
     else if (key == 12) g_tune_force_exact = value > 0 ? (value < 1024 ? value : 1024) : 0;
     else return fail(VQHIP_EINVAL, "vqhip_set_tuning: unknown key");
     return VQHIP_OK;

@@ -273,6 +273,7 @@ __device__ __forceinline__ void cb_stats_publish(const VqCbStats *st) {
 #include "vqhip_refine_kernels.h"
 #include "vqhip_proposal32_kernels.h"
 #include "vqhip_exact_kernels.h"
+#include "vqhip_stream_kernels.h"
 #include "vqhip_update_kernels.h"
 #include "vqhip_sort_kernels.h"
 #include "vqhip_aux_kernels.h"
