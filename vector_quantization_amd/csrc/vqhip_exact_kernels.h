@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
             // land in the runner-up) sends the wave through the exact per-code loop.  (Per-code sqrt + key + 64-bit minimum
             // were 28 % of the kernel: with 64 lanes a per-lane "cannot win" test still runs the expensive block at most
             // steps, profiles/r03_exact_rows.txt.)
-            float tmin = INFINITY, t2 = INFINITY;
+            float tmin = INFINITY, t2 = INFINITY, tsum = 0.0f;
             uint32_t kmin = 0xFFFFFFFFu;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
@@ -672,12 +672,14 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
                     t = (t < 0.0f) ? 0.0f : t;
                     t = (k < K) ? t : INFINITY;                       // codes that do not exist: never first, never a near-tie
                     const bool upd = t < tmin;
-                    t2 = fminf(t2, (k < K) ? fmaxf(t, tmin) : INFINITY);   // NaN: fmaxf returns tmin -> flagged below
+                    t2 = fminf(t2, (k < K) ? fmaxf(t, tmin) : INFINITY);
+                    tsum += (k < K) ? t : 0.0f;                           // NaN exactly when a radicand is NaN (they are >= 0 otherwise)
                     kmin = upd ? (uint32_t)k : kmin;
                     tmin = upd ? t : tmin;
                 }
             }
-            const bool unique = t2 > tmin * (1.0f + 0x1p-21f);       // (inf > inf is false: a lane of equal / all-NaN radicands is not unique)
+            // (a NaN radicand must win — torch.argmin: NaN first — and the comparisons above cannot see it: exact_stream_kernel)
+            const bool unique = t2 > tmin * (1.0f + 0x1p-21f) && tsum == tsum;   // (inf > inf is false: equal / all-inf radicands are not unique)
             // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
             if (__any(kmin != 0xFFFFFFFFu ? !unique : kb < K)) {
                 float xn2 = xn;

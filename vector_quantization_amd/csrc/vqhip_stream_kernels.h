@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
             // row argmin, L2, in the radicands (exact_tiled_kernel): smallest radicand with its lowest index and the runner-up value
             // in one pass; a runner-up within 2^-21 of the smallest (near-ties, equal radicands, NaN) sends the wave through the
             // per-code sqrt + key loop.  A code that does not exist has t = +inf: fmaxf(inf, tmin) = inf leaves t2 alone.
-            float tmin = INFINITY, t2 = INFINITY;
+            float tmin = INFINITY, t2 = INFINITY, tsum = 0.0f;
             int omin = -1;
             // (a chunk that lies wholly inside the codebook — all but the last — runs the pass without the existence selects)
             auto radicand_pass = [&](auto whole_chunk) {
@@ -286,14 +286,19 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
                         t = (t < 0.0f) ? 0.0f : t;
                         t = kv ? t : INFINITY;
                         const bool upd = t < tmin;
-                        t2 = fminf(t2, fmaxf(t, tmin));              // NaN: fmaxf returns tmin -> flagged below
+                        t2 = fminf(t2, fmaxf(t, tmin));
+                        tsum += t;                                   // NaN radicands (a code row holding inf or NaN): see below
                         omin = upd ? o : omin;
                         tmin = upd ? t : tmin;
                     }
                 }
             };
             if (kbase + CT * 32 <= K) radicand_pass(std::true_type{}); else radicand_pass(std::false_type{});
-            const bool unique = t2 > tmin * (1.0f + 0x1p-21f);       // (inf > inf is false: a lane of equal / all-NaN radicands is not unique)
+            // A NaN radicand must win (torch.argmin: NaN first) and is invisible to the comparisons above — fmaxf(NaN, tmin) = tmin
+            // only flags it while tmin does not fall any further.  The radicands are >= 0 or NaN, so their sum is NaN exactly when
+            // one of them is (round 6: a codebook row holding +inf, distances inf - inf for half the rows, lost to a NaN row of
+            // higher index in a later chunk — both forms of the pass)
+            const bool unique = t2 > tmin * (1.0f + 0x1p-21f) && tsum == tsum;   // (inf > inf is false: equal / all-inf radicands are not unique)
             // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
             if (__any(omin >= 0 ? !unique : krem > 0)) {
                 float xn2 = xn;
