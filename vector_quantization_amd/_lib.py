@@ -168,6 +168,11 @@ def lib() -> ctypes.CDLL:
         if L.vqhip_version() != ABI_VERSION:
             raise VqhipError(f'{LIB_PATH} has ABI version {L.vqhip_version()}, this package binds {ABI_VERSION}: '
                              'rebuild it with vector_quantization_amd/csrc/build.sh')
+        # VQHIP_TUNING="18=0,2=4": A/B knobs of vqhip_set_tuning applied at load (measurement and debugging; results never change)
+        for kv in filter(None, os.environ.get('VQHIP_TUNING', '').split(',')):
+            key, _, value = kv.partition('=')
+            if L.vqhip_set_tuning(int(key), int(value)) != 0:
+                raise VqhipError(f'VQHIP_TUNING: vqhip_set_tuning({key}, {value}) refused')
         _lib = L
     return _lib
 

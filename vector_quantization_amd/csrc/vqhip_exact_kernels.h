@@ -428,6 +428,126 @@ __global__ void force_exact_rows_kernel(int V, int *__restrict__ exact_list, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue of a whole-batch work item (128 rows x 256 codes: acc[c][q] = the lane's column j of code tile c), both forms of the
+// pass: row argmin -> the lane's best key (returned); column argmin -> atomicMin per code; distances -> stores.
+// en_lds: |e_k|^2 of the item's 256 codes (L2).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ u64 tiled_epilogue(const f32x16 (&acc)[8], const float4 *__restrict__ en_lds, float xn, int64_t kbase,
+                                              int64_t K, int metric, int h, int j, bool rvalid, int64_t row,
+                                              u64 *__restrict__ keys, float *__restrict__ dout) {
+    constexpr int CT = 8;
+    // A lane's code of accumulator element (c, q) is kb + o with the CONSTANT
+    // o = 32 c + mfma_row(q, 0): existence is `o < krem`, the winner is kept as its o (an inline constant in the select) —
+    // no per-element 64-bit index is ever formed (128 of them, computed once for both passes below and kept, were the
+    // register form's spills and, under this kernel's 256 registers, 316 more)
+    u64 best = ~0ull;
+    const int64_t kb = kbase + 4 * h;
+    const int64_t left = K - kb;
+    int krem = (int)(left < 0 ? 0 : (left > CT * 32 ? CT * 32 : left));      // this lane's codes kb + o exist for o < krem
+    uint32_t kb32 = (uint32_t)kb;
+    asm volatile("" : "+v"(krem), "+v"(kb32));
+    float enr[2][16];
+    auto request_en = [&](int c, float (&dst)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = en_lds[c * 8 + 2 * g + h];
+            dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+        }
+    };
+    if (VQ_IS_L2(metric)) request_en(0, enr[0]);
+    if (MODE == 0 && VQ_IS_L2(metric)) {
+        // row argmin, L2, in the radicands (exact_tiled_kernel): smallest radicand with its lowest index and the runner-up value
+        // in one pass; a runner-up within 2^-21 of the smallest (near-ties, equal radicands, NaN) sends the wave through the
+        // per-code sqrt + key loop.  A code that does not exist has t = +inf: fmaxf(inf, tmin) = inf leaves t2 alone.
+        float tmin = INFINITY, t2 = INFINITY, tsum = 0.0f;
+        int omin = -1;
+        // (a chunk that lies wholly inside the codebook — all but the last — runs the pass without the existence selects)
+        auto radicand_pass = [&](auto whole_chunk) {
+            constexpr bool WHOLE = decltype(whole_chunk)::value;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int o = c * 32 + mfma_row(q, 0);
+                    const bool kv = WHOLE || o < krem;
+                    float t = (acc[c][q] + xn) + (kv ? enr[c & 1][q] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    t = kv ? t : INFINITY;
+                    const bool upd = t < tmin;
+                    t2 = fminf(t2, fmaxf(t, tmin));
+                    tsum += t;                                   // NaN radicands (a code row holding inf or NaN): see below
+                    omin = upd ? o : omin;
+                    tmin = upd ? t : tmin;
+                }
+            }
+        };
+        if (kbase + CT * 32 <= K) radicand_pass(std::true_type{}); else radicand_pass(std::false_type{});
+        // A NaN radicand must win (torch.argmin: NaN first) and is invisible to the comparisons above — fmaxf(NaN, tmin) = tmin
+        // only flags it while tmin does not fall any further.  The radicands are >= 0 or NaN, so their sum is NaN exactly when
+        // one of them is (round 6: a codebook row holding +inf, distances inf - inf for half the rows, lost to a NaN row of
+        // higher index in a later chunk — both forms of the pass)
+        const bool unique = t2 > tmin * (1.0f + 0x1p-21f) && tsum == tsum;   // (inf > inf is false: equal / all-inf radicands are not unique)
+        // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
+        if (__any(omin >= 0 ? !unique : krem > 0)) {
+            float xn2 = xn;
+            asm volatile("" : "+v"(xn2));     // the radicands are computed AGAIN: sharing them with the pass above would keep 128 values alive
+            request_en(0, enr[0]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int o = c * 32 + mfma_row(q, 0);
+                    float t = (acc[c][q] + xn2) + ((o < krem) ? enr[c & 1][q] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    if (o < krem) { const u64 key = dist_key(sqrtf(t), kb32 + (uint32_t)o); best = key < best ? key : best; }
+                }
+            }
+        } else if (omin >= 0) {
+            best = dist_key(sqrtf(tmin), kb32 + (uint32_t)omin);
+        }
+    } else {
+        float *dp = MODE == 2 ? dout + row * K + kb : nullptr;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (VQ_IS_L2(metric) && c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = c * 32 + mfma_row(q, 0);
+                const bool kv = o < krem;
+                float d;
+                if (VQ_IS_L2(metric)) {
+                    float t = (acc[c][q] + xn) + (kv ? enr[c & 1][q] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    d = sqrtf(t);
+                } else {
+                    d = cos_distance(acc[c][q], metric);
+                }
+                if (MODE == 0) {
+                    if (kv) { u64 key = dist_key(d, kb32 + (uint32_t)o); best = key < best ? key : best; }
+                } else if (MODE == 1) {
+                    u64 key = (rvalid && kv) ? dist_key(d, (uint32_t)row) : ~0ull;
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        u64 o2 = __shfl_xor(key, off, 64);
+                        key = o2 < key ? o2 : key;
+                    }
+                    if (j == 0 && kv && key != ~0ull) atomicMin(&keys[kb + o], key);
+                } else {
+                    if (rvalid && kv) dp[o] = d;
+                }
+            }
+        }
+    }
+    return best;
+}
+
 // Whole-batch fp32 pass (argmin_exact, col_argmin, distance): a workgroup = 4 waves x 32 rows against a chunk of CT code
 // tiles.  Code tiles are staged through LDS once per workgroup (coalesced float4 loads, register prefetch of the next
 // tile, 16-byte XOR swizzle -> conflict-free ds_read_b128) and shared by the 4 waves; accumulators of all CT tiles stay
@@ -634,103 +754,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const void *__restrict
         }
 
         const float xn = (VQ_IS_L2(metric) && rvalid) ? xn_in[row] : 0.0f;
-        u64 best = ~0ull;
-        // this lane's code of accumulator element (c, q) is kb + (32 c + mfma_row(q, 0)): a constant offset from a per-item
-        // value that the compiler must not see through — it otherwise hoists the 128 sums `4 h + offset` out of the item loop
-        // and keeps (spills) them: 115 registers stored at kernel entry, one scratch load per element
-        int64_t kb = kbase + 4 * h;
-        asm volatile("" : "+v"(kb));
-        // |e_k|^2 of the lane's 16 codes of a tile: four runs of four codes, four 16-byte LDS reads (en_lds above)
-        float enr[2][16];
-        auto request_en = [&](int c, float (&dst)[16]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = en_lds[c * 8 + 2 * g + h];
-                dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
-            }
-        };
-        if (VQ_IS_L2(metric)) request_en(0, enr[0]);
-        if (MODE == 0 && VQ_IS_L2(metric)) {
-            // Row argmin, L2, in the radicands: sqrt is correctly rounded, hence monotone, so the winner is the lowest-index
-            // code among those whose sqrt rounds to sqrt(t_min) — all of them have t <= t_min (1 + 2^-21) (the bucket of a
-            // float d ends below d^2 (1 + 2^-24)^2 and t_min >= d^2 (1 - 2^-24)^2).  One pass keeps the lane's smallest
-            // radicand with its (lowest) index and the second smallest value (6 VALU per code); a runner-up above the
-            // threshold (the rule) means ONE sqrt and key per lane, anything else (near-ties, equal radicands, NaN: they
-            // land in the runner-up) sends the wave through the exact per-code loop.  (Per-code sqrt + key + 64-bit minimum
-            // were 28 % of the kernel: with 64 lanes a per-lane "cannot win" test still runs the expensive block at most
-            // steps, profiles/r03_exact_rows.txt.)
-            float tmin = INFINITY, t2 = INFINITY, tsum = 0.0f;
-            uint32_t kmin = 0xFFFFFFFFu;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int64_t k = kb + (c * 32 + mfma_row(q, 0));
-                    float t = (acc[c][q] + xn) + ((k < K) ? enr[c & 1][q] : 0.0f);
-                    t = (t < 0.0f) ? 0.0f : t;
-                    t = (k < K) ? t : INFINITY;                       // codes that do not exist: never first, never a near-tie
-                    const bool upd = t < tmin;
-                    t2 = fminf(t2, (k < K) ? fmaxf(t, tmin) : INFINITY);
-                    tsum += (k < K) ? t : 0.0f;                           // NaN exactly when a radicand is NaN (they are >= 0 otherwise)
-                    kmin = upd ? (uint32_t)k : kmin;
-                    tmin = upd ? t : tmin;
-                }
-            }
-            // (a NaN radicand must win — torch.argmin: NaN first — and the comparisons above cannot see it: exact_stream_kernel)
-            const bool unique = t2 > tmin * (1.0f + 0x1p-21f) && tsum == tsum;   // (inf > inf is false: equal / all-inf radicands are not unique)
-            // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
-            if (__any(kmin != 0xFFFFFFFFu ? !unique : kb < K)) {
-                float xn2 = xn;
-                asm volatile("" : "+v"(xn2));     // the radicands are computed AGAIN here: sharing them with the pass above would keep 128 values alive
-                request_en(0, enr[0]);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int64_t k = kb + (c * 32 + mfma_row(q, 0));
-                        float t = (acc[c][q] + xn2) + ((k < K) ? enr[c & 1][q] : 0.0f);
-                        t = (t < 0.0f) ? 0.0f : t;
-                        if (k < K) { const u64 key = dist_key(sqrtf(t), (uint32_t)k); best = key < best ? key : best; }
-                    }
-                }
-            } else if (kmin != 0xFFFFFFFFu) {
-                best = dist_key(sqrtf(tmin), kmin);
-            }
-        } else
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            if (VQ_IS_L2(metric) && c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t k = kb + (c * 32 + mfma_row(q, 0));
-                float d;
-                if (VQ_IS_L2(metric)) {
-                    float t = (acc[c][q] + xn) + ((k < K) ? enr[c & 1][q] : 0.0f);
-                    t = (t < 0.0f) ? 0.0f : t;
-                    d = sqrtf(t);
-                } else {
-                    d = cos_distance(acc[c][q], metric);
-                }
-                if (MODE == 0) {
-                    if (k < K) { u64 key = dist_key(d, (uint32_t)k); best = key < best ? key : best; }
-                } else if (MODE == 1) {
-                    u64 key = (rvalid && k < K) ? dist_key(d, (uint32_t)row) : ~0ull;
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {
-                        u64 o = __shfl_xor(key, off, 64);
-                        key = o < key ? o : key;
-                    }
-                    if (j == 0 && k < K && key != ~0ull) atomicMin(&keys[k], key);
-                } else {
-                    if (rvalid && k < K) dout[row * K + k] = d;
-                }
-            }
-        }
+        u64 best = tiled_epilogue<MODE>(acc, en_lds, xn, kbase, K, metric, h, j, rvalid, row, keys, dout);
         if (MODE == 0) {
             u64 o = __shfl_xor(best, 32, 64);
             best = o < best ? o : best;

@@ -93,6 +93,17 @@ __device__ __forceinline__ float cos_distance(float c, int metric) {
     return 1.0f - c;
 }
 
+// The barrier that hands an LDS-DMA tile to the other waves.  __syncthreads() is a workgroup-scope release fence + s_barrier, and a
+// release fence owes nothing to outstanding LOADS — which is what global_load_lds is to the compiler: hipcc emits s_waitcnt vmcnt(0)
+// in front of such a barrier only where something else on the path needs it (exact_stream_kernel had it at one of its two loop
+// barriers, not at the other: right alone on the GPU, where every piece lands long before the barrier, wrong on 1-2 % of the rows
+// with eight processes sharing it — round 6, tools/isa_dma_barriers.py lists the barriers of every kernel that fills LDS this way).
+// The drain is therefore written out wherever a barrier publishes DMA'd data.
+__device__ __forceinline__ void vq_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // single-instruction max (hipcc otherwise wraps fmaxf on MFMA results in canonicalising v_max pairs)
 __device__ __forceinline__ float vmax(float a, float b) {
     float r;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
     }
 
     VQ_PHASE(1);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+    vq_dma_barrier();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
     VQ_PHASE(2);
 #ifdef VQ_PHASE_STAMPS
     const unsigned long long phase_clk0 = __builtin_amdgcn_s_memtime();
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
 #endif
         VQ_STAMP(1);
         const int64_t st = it - lag;
-        if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
+        if (st < st0 || st >= st1 || !wave_active) { vq_dma_barrier(); continue; }
         const int buf = (int)((st - st0) % NBUF);
         const char *base = lds + buf * STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(WAVES * 64, TT >= 2 ? VQ_W32_TT2_OCC : 4) void coar
         __syncthreads();
         VQ_STAMP(4);
 #else
-        __syncthreads();   // next stage landed (vmcnt(0)) and everybody is done reading this one
+        vq_dma_barrier();  // next stage landed (vmcnt(0)) and everybody is done reading this one
 #endif
     }
 #ifdef VQ_STAGE_STAMPS

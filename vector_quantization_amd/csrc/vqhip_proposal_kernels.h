@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
     if (st0 < st1) issue_stage(st0, 0);
     if (AHEAD >= 2 && st0 + 1 < st1) issue_stage(st0 + 1, 1);
     VQ_PHASE(1);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
+    vq_dma_barrier();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to every wave
     VQ_PHASE(2);
 
     f32x4 accA[2][TT], accB[2][TT];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
 #endif
         VQ_STAMP(1);
         const int64_t st = it - lag;
-        if (st < st0 || st >= st1 || !wave_active) { __syncthreads(); continue; }
+        if (st < st0 || st >= st1 || !wave_active) { vq_dma_barrier(); continue; }
         const int buf = (int)((st - st0) % NBUF);
         const char *base = lds + buf * STAGE_BYTES;
         const char *aux = base + TPS * NSTEP * VQ_CHUNK_BYTES;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(WAVES * 64, (FILTER && NSTEP <= 2) ? (GROUPS ? 4 : 
 #elif defined(VQ_EXP_NO_BARRIER)    // timing-only diagnostic build
         asm volatile("" ::: "memory");
 #else
-        __syncthreads();
+        vq_dma_barrier();
 #endif
     }
 #ifdef VQ_STAGE_STAMPS

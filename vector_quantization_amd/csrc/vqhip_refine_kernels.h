@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
                 }
             }
         }
-        __syncthreads();   // stage st0 landed
+        vq_dma_barrier();  // stage st0 landed
         for (int64_t st = st0; st < st1; ++st) {
             const int buf = (int)((st - st0) % NBUF);
             if (st + AHEAD < st1) issue_stage(st + AHEAD, (int)((st + AHEAD - st0) % NBUF));
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void rescan_kernel(const char *__restri
                     if (pos < VQ_RESCAN_LOCAL) lcand[row * VQ_RESCAN_LOCAL + pos] = code;
                 }
             }
-            __syncthreads();   // next stage landed and everybody is done reading this one
+            vq_dma_barrier();  // next stage landed and everybody is done reading this one
         }
         // flush: thread r owns local row r
         for (int r = threadIdx.x; r < BM; r += WAVES * 64) {

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
         auto stage_top = [&](int db, int cs) {
             const bool lastb = db + 1 == nb;
 #ifndef VQ_XS_NO_BAR         // (timing-only diagnostic builds: VQ_XS_NO_BAR / _NO_DMA / _NO_EPI / _NO_ATOMIC)
-            __syncthreads();
+            vq_dma_barrier();    // (the drain written out: __syncthreads() alone does not promise it — vqhip_kernels.h)
 #endif
 #ifndef VQ_XS_NO_DMA
             if (cs + 1 < NS) issue_e(kbase, cs + 1, db, eb ^ 1);
@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
                 if (!lastb) issue_x(rb, db + 1, xb ^ 1);
                 else if (has_next) issue_x(rb2, 0, xb ^ 1);
             }
+#endif
+#ifdef VQ_XS_SYNC_DMA       // (diagnostic: nothing in flight while a stage computes)
+            __syncthreads();
 #endif
         };
         for (int db = 0; db < nbf; ++db) {
@@ -246,113 +249,8 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
             continue;
         }
 #endif
-        // ---- epilogue: exact_tiled_kernel's rules.  A lane's code of accumulator element (c, q) is kb + o with the CONSTANT
-        // o = 32 c + mfma_row(q, 0): existence is `o < krem`, the winner is kept as its o (an inline constant in the select) —
-        // no per-element 64-bit index is ever formed (128 of them, computed once for both passes below and kept, were the
-        // register form's spills and, under this kernel's 256 registers, 316 more)
-        u64 best = ~0ull;
-        const int64_t kb = kbase + 4 * h;
-        const int64_t left = K - kb;
-        int krem = (int)(left < 0 ? 0 : (left > CT * 32 ? CT * 32 : left));      // this lane's codes kb + o exist for o < krem
-        uint32_t kb32 = (uint32_t)kb;
-        asm volatile("" : "+v"(krem), "+v"(kb32));
-        float enr[2][16];
-        auto request_en = [&](int c, float (&dst)[16]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = en_lds[c * 8 + 2 * g + h];
-                dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
-            }
-        };
-        if (VQ_IS_L2(metric)) request_en(0, enr[0]);
-        if (MODE == 0 && VQ_IS_L2(metric)) {
-            // row argmin, L2, in the radicands (exact_tiled_kernel): smallest radicand with its lowest index and the runner-up value
-            // in one pass; a runner-up within 2^-21 of the smallest (near-ties, equal radicands, NaN) sends the wave through the
-            // per-code sqrt + key loop.  A code that does not exist has t = +inf: fmaxf(inf, tmin) = inf leaves t2 alone.
-            float tmin = INFINITY, t2 = INFINITY, tsum = 0.0f;
-            int omin = -1;
-            // (a chunk that lies wholly inside the codebook — all but the last — runs the pass without the existence selects)
-            auto radicand_pass = [&](auto whole_chunk) {
-                constexpr bool WHOLE = decltype(whole_chunk)::value;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int o = c * 32 + mfma_row(q, 0);
-                        const bool kv = WHOLE || o < krem;
-                        float t = (acc[c][q] + xn) + (kv ? enr[c & 1][q] : 0.0f);
-                        t = (t < 0.0f) ? 0.0f : t;
-                        t = kv ? t : INFINITY;
-                        const bool upd = t < tmin;
-                        t2 = fminf(t2, fmaxf(t, tmin));
-                        tsum += t;                                   // NaN radicands (a code row holding inf or NaN): see below
-                        omin = upd ? o : omin;
-                        tmin = upd ? t : tmin;
-                    }
-                }
-            };
-            if (kbase + CT * 32 <= K) radicand_pass(std::true_type{}); else radicand_pass(std::false_type{});
-            // A NaN radicand must win (torch.argmin: NaN first) and is invisible to the comparisons above — fmaxf(NaN, tmin) = tmin
-            // only flags it while tmin does not fall any further.  The radicands are >= 0 or NaN, so their sum is NaN exactly when
-            // one of them is (round 6: a codebook row holding +inf, distances inf - inf for half the rows, lost to a NaN row of
-            // higher index in a later chunk — both forms of the pass)
-            const bool unique = t2 > tmin * (1.0f + 0x1p-21f) && tsum == tsum;   // (inf > inf is false: equal / all-inf radicands are not unique)
-            // (no code selected although the lane has codes: every radicand is NaN or +inf — the exact loop sorts that out)
-            if (__any(omin >= 0 ? !unique : krem > 0)) {
-                float xn2 = xn;
-                asm volatile("" : "+v"(xn2));     // the radicands are computed AGAIN: sharing them with the pass above would keep 128 values alive
-                request_en(0, enr[0]);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int o = c * 32 + mfma_row(q, 0);
-                        float t = (acc[c][q] + xn2) + ((o < krem) ? enr[c & 1][q] : 0.0f);
-                        t = (t < 0.0f) ? 0.0f : t;
-                        if (o < krem) { const u64 key = dist_key(sqrtf(t), kb32 + (uint32_t)o); best = key < best ? key : best; }
-                    }
-                }
-            } else if (omin >= 0) {
-                best = dist_key(sqrtf(tmin), kb32 + (uint32_t)omin);
-            }
-        } else {
-            float *dp = MODE == 2 ? dout + row * K + kb : nullptr;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                if (VQ_IS_L2(metric) && c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int o = c * 32 + mfma_row(q, 0);
-                    const bool kv = o < krem;
-                    float d;
-                    if (VQ_IS_L2(metric)) {
-                        float t = (acc[c][q] + xn) + (kv ? enr[c & 1][q] : 0.0f);
-                        t = (t < 0.0f) ? 0.0f : t;
-                        d = sqrtf(t);
-                    } else {
-                        d = cos_distance(acc[c][q], metric);
-                    }
-                    if (MODE == 0) {
-                        if (kv) { u64 key = dist_key(d, kb32 + (uint32_t)o); best = key < best ? key : best; }
-                    } else if (MODE == 1) {
-                        u64 key = (rvalid && kv) ? dist_key(d, (uint32_t)row) : ~0ull;
-#pragma unroll
-                        for (int off = 16; off >= 1; off >>= 1) {
-                            u64 o2 = __shfl_xor(key, off, 64);
-                            key = o2 < key ? o2 : key;
-                        }
-                        if (j == 0 && kv && key != ~0ull) atomicMin(&keys[kb + o], key);
-                    } else {
-                        if (rvalid && kv) dp[o] = d;
-                    }
-                }
-            }
-        }
+        // ---- epilogue (tiled_epilogue, vqhip_exact_kernels.h: shared with the register form) ----
+        const u64 best = tiled_epilogue<MODE>(acc, en_lds, xn, kbase, K, metric, h, j, rvalid, row, keys, dout);
         if (MODE == 0) {
             run_best = best < run_best ? best : run_best;
             if (!has_next || rb2 != rb) {                            // last chunk of the row block in this span (wave-uniform)
