@@ -107,3 +107,35 @@ def test_histogram_and_repeat_calls_are_deterministic(ops):
     i2 = ops.argmin_exact(xd, wd, 'L2')
     same(i1, i2)
     np.testing.assert_array_equal(hist.cpu().numpy(), np.bincount(i1.cpu().numpy(), minlength=2048))
+
+
+_SHARE_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from vector_quantization_amd import ops, _lib
+g = torch.Generator(device='cuda').manual_seed(int(sys.argv[2]))
+x = torch.randn(4096, 256, device='cuda', generator=g).bfloat16()
+w = torch.randn(16384, 256, device='cuda', generator=g)
+L = _lib.lib()
+L.vqhip_set_tuning(18, 0)
+ref = ops.argmin_exact(x, w, 'L2')
+L.vqhip_set_tuning(18, 1)
+bad = sum(int((ops.argmin_exact(x, w, 'L2') != ref).sum().item() > 0) for _ in range(25))
+print('BAD', bad)
+'''
+
+
+def test_streamed_form_with_eight_processes_on_the_gpu():
+    """The tiles of a stage must have LANDED at the barrier that publishes them, however late the memory system delivers them:
+    eight processes at once on the one GPU stretch the LDS-DMA round trips far enough to show a barrier without its vmcnt drain
+    (round 6: 12 of 32 such processes saw 1-2 % of the rows decided on the previous stage's tiles; vq_dma_barrier)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, '-c', _SHARE_CHILD, root, str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for i in range(8)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        assert 'BAD 0' in out, out
