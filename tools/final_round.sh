@@ -31,3 +31,6 @@ bash tools/rccl_ws1_ab.sh ${tag}_rccl_ab 3 > $o/${tag}_rccl_ab.txt 2>&1; cat $o/
 # round 5: training steps at the per-rank shapes of the shipped configs (eager one-call and graph-replayed) and their per-launch timelines
 python tools/bench_train_shapes.py cvq vqkd cluster llamagen cvq64k 2>&1 | grep "ms per step\|bound to\|listed for" > $o/${tag}_train_shapes.txt; cat $o/${tag}_train_shapes.txt
 (bash tools/timeline_train.sh ${tag}_tl_cvq cvq vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_vqkd vqkd vqkd_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_cluster cluster vq_backward_kernel; bash tools/timeline_train.sh ${tag}_tl_llamagen llamagen normalize_bwd_kernel) > $o/${tag}_train_timelines.txt 2>&1
+# round 6: the closing randomised campaigns (pipeline against the all-fp32 route — whose whole-batch pass is exact_stream_kernel now — and, last line,
+# the streamed against the register form of that pass itself under tools/time_exact_tiled.py's shapes)
+{ sha256sum vector_quantization_amd/libvqhip.so; python tools/fuzz_vs_exact.py 150 2>&1 | tail -1; VQ_FUZZ_BF16=1 VQ_FUZZ_DIMS=256 python tools/fuzz_vs_exact.py 100 2>&1 | tail -1; VQ_FUZZ_DIMS=8,16,24,32 python tools/fuzz_vs_exact.py 100 2>&1 | tail -1; VQ_FUZZ_DIMS=512,768,1024 python tools/fuzz_vs_exact.py 60 2>&1 | tail -1; VQ_FUZZ_FORCE_EXACT=1 python tools/fuzz_vs_exact.py 60 2>&1 | tail -1; } > $o/${tag}_final_fuzz.txt 2>&1; cat $o/${tag}_final_fuzz.txt

@@ -115,7 +115,9 @@ __device__ __forceinline__ void exact_rows_mfma(const void *__restrict__ x, cons
         }
         u64 o = __shfl_xor(best, 32, 64);
         best = o < best ? o : best;
+#ifndef VQ_EXACT_NO_ATOMIC       // (timing-only diagnostic build, tools/micro/exact_rows.hip)
         if (h == 0 && rvalid && best != ~0ull) atomicMin(&keys[row], best);
+#endif
     }
 }
 
