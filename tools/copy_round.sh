@@ -17,3 +17,4 @@ cp $o/${tag}_c3_stalls/pmc_stalls.json $p/${tag}_c3_pmc_stalls.json
 cp $o/${tag}_tok_pmc/pmc_summary.json $p/${tag}_tok_pmc_summary.json
 python tools/pmc_to_latest.py $o/${tag}_pmc/pmc_summary.json 524288 "$note"
 cat $p/${tag}_lib_sha256.txt
+cp $o/${tag}_final_fuzz.txt $p/
