@@ -52,6 +52,17 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert rc == -22
 
 
+def test_tuning_knobs_are_host_state_and_unknown_keys_are_refused(lib):
+    """vqhip_set_tuning touches no device: every documented A/B key is accepted (and restored), any other key is VQHIP_EINVAL;
+    VQHIP_TUNING applies the same knobs at load (vector_quantization_amd/_lib.py)."""
+    for key, default in ((2, 0), (5, 1), (6, 2), (8, 1), (9, 1), (10, 1), (11, 1), (13, 1), (15, 1), (17, 1), (18, 1), (12, 0)):
+        assert lib.vqhip_set_tuning(key, 0) == 0
+        assert lib.vqhip_set_tuning(key, default) == 0
+    for key in (-1, 1, 7, 14, 16, 19, 1000):
+        assert lib.vqhip_set_tuning(key, 1) == -22
+        assert b'vqhip_set_tuning' in lib.vqhip_last_error()
+
+
 def test_undersized_buffers_are_refused_before_any_launch(lib):
     """Every scratch buffer travels with its size: one byte less than the matching *_bytes function asks for is VQHIP_EINVAL,
     with both numbers in the message — never a kernel writing past the end of a caller's allocation.  (Pointers here are
