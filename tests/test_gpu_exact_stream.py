@@ -88,6 +88,21 @@ def test_distance_matrix_and_column_fallback_in_both_forms(ops, forms, N, K, D, 
     np.testing.assert_array_equal(c1.cpu().numpy(), np.argmin(d1.cpu().numpy(), axis=0))
 
 
+@pytest.mark.parametrize('N,K,D,dtype', [(700, 520, 64, torch.bfloat16), (257, 4096, 32, torch.float32), (1000, 260, 96, torch.bfloat16),
+                                         (129, 8, 16, torch.float32), (4100, 1004, 72, torch.float32)])
+def test_distance_rows_staged_through_lds(ops, forms, N, K, D, dtype):
+    """K % 4 == 0: the streamed form writes d[N, K] as 16-byte row segments through a wave-private LDS tile (32 codes wide for fp32
+    rows, 16 for bf16 rows); chunks and row blocks that are not whole, K smaller than a tile."""
+    x, w = synth.make_inputs('normal', 333 + K, N, K, D)
+    xd, wd = dev(x, dtype), dev(w)
+    for metric in ('L2', 'Cosine'):
+        xm, wm = (ops.normalize_rows(xd), ops.normalize_rows(wd)) if metric == 'Cosine' else (xd, wd)
+        d1, d0 = forms(lambda: ops.distance(xm, wm, metric))
+        same(d1, d0)
+        if metric == 'L2':
+            np.testing.assert_array_equal(d1.cpu().numpy(), co.l2_dist(xd.float().cpu().numpy(), w))
+
+
 def test_nonfinite_rows_and_codes_in_both_forms(ops, forms):
     x, w = synth.make_inputs('normal', 5, 700, 900, 64)
     x[3, 5] = np.nan; x[10, :] = np.inf; x[11, 0] = -np.inf; x[200, 63] = 3e38

@@ -435,10 +435,16 @@ __global__ void force_exact_rows_kernel(int V, int *__restrict__ exact_list, int
 // pass: row argmin -> the lane's best key (returned); column argmin -> atomicMin per code; distances -> stores.
 // en_lds: |e_k|^2 of the item's 256 codes (L2).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// HW > 0 (distances, exact_stream_kernel): `stage` is a wave-private LDS tile of 32 rows x HW codes (32, or 16 where the wave's
+// share of a consumed row block is only 2 KiB: bf16 rows) through which the distances leave as ROWS — a lane's 16 values of a code
+// tile are 4 codes x 4 runs down a column of d[N, K], and stored as they lie every wave-store touched 32 lines for 8 bytes each
+// (8192 x 8192 x 64: 268 MB in 0.47 ms, slower than the register form); staged, a wave-store is 8 (16) rows x 128 (64) contiguous
+// bytes.  K % 4 == 0 (16-byte row segments); other K keep the element stores.
+template <int MODE, int HW = 0>
 __device__ __forceinline__ u64 tiled_epilogue(const f32x16 (&acc)[8], const float4 *__restrict__ en_lds, float xn, int64_t kbase,
                                               int64_t K, int metric, int h, int j, bool rvalid, int64_t row,
-                                              u64 *__restrict__ keys, float *__restrict__ dout) {
+                                              u64 *__restrict__ keys, float *__restrict__ dout, float4 *stage = nullptr,
+                                              int64_t N = 0) {
     constexpr int CT = 8;
     // A lane's code of accumulator element (c, q) is kb + o with the CONSTANT
     // o = 32 c + mfma_row(q, 0): existence is `o < krem`, the winner is kept as its o (an inline constant in the select) —
@@ -512,6 +518,48 @@ __device__ __forceinline__ u64 tiled_epilogue(const f32x16 (&acc)[8], const floa
             }
         } else if (omin >= 0) {
             best = dist_key(sqrtf(tmin), kb32 + (uint32_t)omin);
+        }
+    } else if (MODE == 2 && HW > 0 && (K & 3) == 0) {
+        constexpr int HWS = HW > 0 ? HW : 32;                // (HW == 0 never reaches this branch)
+        constexpr int NPR = HWS / 4, RPP = 64 / NPR;         // 16-byte pieces of a staged row; rows per read pass
+        const int lane = j + 32 * h;
+        const int rr = lane / NPR, rp = lane % NPR;
+        const int64_t row0 = row - j;                        // the wave's first row
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (VQ_IS_L2(metric) && c + 1 < CT) request_en(c + 1, enr[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            float dv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = c * 32 + mfma_row(q, 0);
+                if (VQ_IS_L2(metric)) {
+                    float t = (acc[c][q] + xn) + ((o < krem) ? enr[c & 1][q] : 0.0f);
+                    t = (t < 0.0f) ? 0.0f : t;
+                    dv[q] = sqrtf(t);
+                } else {
+                    dv[q] = cos_distance(acc[c][q], metric);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 32 / HWS; ++hh) {           // the tile's halves (HW == 16) or the whole tile
+#pragma unroll
+                for (int gl = 0; gl < HWS / 8; ++gl) {        // this lane's runs of four codes: 8 g + 4 h .. + 3 of the tile
+                    const int g = hh * (HWS / 8) + gl, pc = 2 * gl + h;
+                    stage[j * NPR + (pc ^ (j & (NPR - 1)))] = make_float4(dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]);
+                }
+#pragma unroll
+                for (int pass = 0; pass < 32 / RPP; ++pass) {
+                    const int r = pass * RPP + rr;
+                    const float4 v = stage[r * NPR + (rp ^ (r & (NPR - 1)))];
+                    const int64_t grow = row0 + r, k = kbase + c * 32 + hh * HWS + 4 * rp;
+                    if (grow < N) {
+                        float *dst = dout + grow * K + k;
+                        if (k + 3 < K) *(float4 *)dst = v;
+                        else { if (k < K) dst[0] = v.x; if (k + 1 < K) dst[1] = v.y; if (k + 2 < K) dst[2] = v.z; }
+                    }
+                }
+            }
         }
     } else {
         float *dp = MODE == 2 ? dout + row * K + kb : nullptr;

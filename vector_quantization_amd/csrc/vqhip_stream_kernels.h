@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256, 2) void exact_stream_kernel(const void *__rest
         }
 #endif
         // ---- epilogue (tiled_epilogue, vqhip_exact_kernels.h: shared with the register form) ----
-        const u64 best = tiled_epilogue<MODE>(acc, en_lds, xn, kbase, K, metric, h, j, rvalid, row, keys, dout);
+        // (distances leave through the wave's own 32 rows of the row block just consumed: the other one receives the next item's)
+        const u64 best = tiled_epilogue<MODE, (MODE == 2 ? (DT ? 16 : 32) : 0)>(acc, en_lds, xn, kbase, K, metric, h, j, rvalid, row, keys, dout,
+                                                                               xbuf + (xb ^ 1) * XSL + 32 * wave * XP, N);
         if (MODE == 0) {
             run_best = best < run_best ? best : run_best;
             if (!has_next || rb2 != rb) {                            // last chunk of the row block in this span (wave-uniform)
