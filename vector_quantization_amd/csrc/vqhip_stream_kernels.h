@@ -15,11 +15,16 @@
 //  * blocks of 32 dims.  The row block (128 rows x 128 B; bf16 rows: x 64 B) and the code tile (32 codes x 128 B) arrive by
 //    LDS-DMA in 16-byte pieces, XOR-swizzled by row so that every ds_read_b128 lane group meets 16 distinct slots (mod 16):
 //    piece p of row r sits at slot r * 8 + (p ^ ((r >> 1) & 7)) (bf16 rows, 4 pieces: r * 4 + (p ^ ((r >> 2) & 3)));
-//  * a stage = (block, code tile): 16 pairs of MFMAs, 2048 matrix cycles.  The DMA of the next stage's code tile (and, at the
-//    first tile of a block, of the next block's rows) is requested at the top of the stage and drained by the barrier at the
-//    top of the next: 41 KiB of LDS per workgroup (two row blocks, two code tiles, the item's |e|^2);
+//  * a stage = (block, VQ_XS_TS = 4 code tiles): four independent accumulator chains interleaved MFMA by MFMA, one B operand for
+//    the four, 64 MFMAs = 4096 matrix cycles between barriers.  The DMA of the next stage's code tiles (and, at the first stage of
+//    a block, of the next block's rows) is requested at the top of the stage and drained IN FRONT OF the barrier at the top of the
+//    next (vq_dma_barrier: the s_waitcnt vmcnt(0) is written out — __syncthreads() does not promise it): 65 KiB of LDS per
+//    workgroup with fp32 rows (two row blocks, two stages of code tiles, the item's |e|^2), 49 KiB with bf16 rows;
 //  * 128 accumulators + two small operand rings: under 256 registers, TWO workgroups per CU.  The second wave of a SIMD runs
 //    its MFMAs through the other's barrier, LDS latency at the top of a stage, and epilogue;
+//  * a workgroup takes a CONTIGUOUS span of the work items (row-block-major; column argmin: chunk-major), keeps the lane's best key
+//    across the chunks of a row block and sends one atomicMin per row and row block: per-item atomics on keys shared by 32
+//    concurrently running workgroups were the largest single loss of the first streamed form;
 //  * the stream does not stop at an item's end: the first stage of the workgroup's next item is requested during the last stage.
 // Shapes: D % 4 == 0 for fp32 rows, D % 8 == 0 for bf16 rows (whole 16-byte pieces); the tail block of a D that is not a multiple
 // of 32 runs its valid pieces only (exact_tiled_kernel adds zeros for the rest: +-0 into accumulators that are never -0).
