@@ -38,7 +38,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     — the dominant kernel (fp16-MFMA proposal pass) against the dense MFMA peak, timed live with HIP events
                  recorded on the launch stream (libvqhip's vqhip_profile_* hooks)
   parity       — the timed batch's indices checked, outside the timed region, against the all-fp32 route on every row and
-                 against the CPU oracle on a row sample; which path every row took
+                 against the CPU oracle on a row sample; which path every row took; `checker_ms` / `checker_tflops`: what that
+                 whole-batch fp32 pass (vqhip_argmin_exact: exact_stream_kernel) took, for the record — never part of `value`
   cpu_baseline — the reference's ATen composition (oracle/torch_ref.py, byte-identical to the reference's own files on
                  every fixture: tests/test_reference_pin.py) timed on this box's host cores on a bounded sample.
 """
@@ -546,6 +547,12 @@ def verify_vqgan(B: Bench, q, x, w, out, N, K, D):
     from vector_quantization_amd import ops
     quant = out[2]['quant'].reshape(-1)
     exact = ops.argmin_exact(x, w, 'L2')
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    exact = ops.argmin_exact(x, w, 'L2')                  # (timed on its second run: the whole-batch fp32 route)
+    ev1.record()
+    torch.cuda.synchronize()
+    checker_ms = float(ev0.elapsed_time(ev1))
     mism = int((quant != exact).sum().item())
     rows = torch.linspace(0, N - 1, 256, device=x.device).long()
     ref = co.l2_argmin(x[rows].float().cpu().numpy(), w.cpu().numpy())
@@ -560,6 +567,8 @@ def verify_vqgan(B: Bench, q, x, w, out, N, K, D):
            'oracle_rows': int(rows.numel()), 'oracle_mismatches': omis, 'oracle': 'oracle/vq_oracle.c l2_argmin on evenly spaced rows',
            'paths': {'second_proposal_pass_rows': st[0], 'multi_candidate_rerank_rows': st[1], 'whole_codebook_fp32_rows': st[2],
                      'single_candidate_rows': N - st[0] - st[1] - st[2]},
+           'checker_ms': checker_ms, 'checker_tflops': 2.0 * N * K * D / checker_ms / 1e9,
+           'checker_note': 'one vqhip_argmin_exact call over the whole batch (row norms, exact_stream_kernel, finalize): fp32 MFMA, outside the timed region',
            'deterministic_rerun': same_again, 'loss': loss, 'loss_float64': loss64,
            'loss_rel_err': abs(loss - loss64) / max(1e-30, abs(loss64))}
     rec['ok'] = bool(mism == 0 and omis == 0 and same_again and rec['loss_rel_err'] <= 1e-5)
